@@ -1,0 +1,169 @@
+/* include/mvo_hip.h -- C-ABI of libmvo_hip.so: the MI355X (gfx950) implementation of the per-frame
+ * hot path of felixchenfy/Monocular-Visual-Odometry (ORB extract + grid sampling, Hamming/L1 descriptor
+ * matching with the reference's filters, sliding-window bundle adjustment).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference repo).
+ * Conventions: plain pointers and sizes, caller-allocated buffers, int status (0 = MVO_OK, <0 = error),
+ * never throws, never prints; one mvo_ctx per host thread, one HIP stream per ctx.  Host pointers unless
+ * the name ends in _dev.  There is NO CPU fallback: without a usable HIP device mvo_create fails with
+ * MVO_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef MVO_HIP_H
+#define MVO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVO_OK 0
+#define MVO_ERR_INVALID (-1)   /* bad argument (e.g. wrong method index: feature_match.cpp:225 throws) */
+#define MVO_ERR_NO_DEVICE (-2) /* no HIP device / kernels not loadable */
+#define MVO_ERR_CAPACITY (-3)  /* caller buffer or internal candidate buffer too small */
+#define MVO_ERR_HIP (-4)       /* HIP runtime error, see mvo_last_error */
+#define MVO_ERR_STATE (-5)     /* call order violated (e.g. reuse_pyramid without a pyramid) */
+
+typedef struct mvo_ctx mvo_ctx;
+
+/* cv::KeyPoint, 28 bytes (Frame::keypoints_, include/my_slam/vo/frame.h:32). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} mvo_keypoint;
+
+/* cv::DMatch, 16 bytes (Frame::matches_with_ref_, frame.h:38). */
+typedef struct {
+    int32_t queryIdx, trainIdx, imgIdx;
+    float distance;
+} mvo_dmatch;
+
+/* The values the reference latches from config/config.yaml:65-69,94-95 in function-local statics
+ * (src/geometry/feature_match.cpp:16-19, 42-45, 56-59). */
+typedef struct {
+    int32_t nfeatures;         /* number_of_keypoints_to_extract */
+    float scale_factor;        /* scale_factor */
+    int32_t nlevels;           /* level_pyramid (1..8) */
+    int32_t fast_threshold;    /* score_threshold */
+    int32_t max_keypoints;     /* max_number_of_keypoints */
+    int32_t grid_size;         /* kpts_uniform_selection_grid_size */
+    int32_t grid_max_per_cell; /* kpts_uniform_selection_max_pts_per_grid */
+} mvo_orb_params;
+
+/* ---- context ------------------------------------------------------------------------------- */
+int mvo_create(mvo_ctx** ctx, int device);
+void mvo_destroy(mvo_ctx* ctx);
+const char* mvo_last_error(const mvo_ctx* ctx);
+/* Blocks until all work queued on the ctx stream is done. */
+int mvo_synchronize(mvo_ctx* ctx);
+/* Replaces basics::Config::get<...> latching in feature_match.cpp:16-19,42-45,56-59.  Also resets the
+ * latched grid dimensions (feature_match.cpp:59-62 latches rows/cols from the FIRST image). */
+int mvo_orb_configure(mvo_ctx* ctx, const mvo_orb_params* params);
+
+/* ---- extraction ---------------------------------------------------------------------------- */
+/* geometry::calcKeyPoints (src/geometry/feature_match.cpp:11-36; called from Frame::calcKeyPoints,
+ * include/my_slam/vo/frame.h:73-76): cv::ORB::detect + selectUniformKptsByGrid.  image: u8, `channels`
+ * = 1 (gray) or 3/4 (BGR[A] as cv::imread gives, run_vo.cpp:114).  The device pyramid built here stays
+ * cached in the ctx for mvo_calc_descriptors(reuse_pyramid=1). */
+int mvo_calc_keypoints(mvo_ctx* ctx, const uint8_t* image, int width, int height, int stride,
+                       int channels, mvo_keypoint* kps, int cap, int* n);
+/* Same with the image already resident in HBM (bench: inputs resident when the timed region starts). */
+int mvo_calc_keypoints_dev(mvo_ctx* ctx, const void* d_image, int width, int height, int stride,
+                           int channels, mvo_keypoint* kps, int cap, int* n);
+/* geometry::calcDescriptors (feature_match.cpp:38-49; Frame::calcDescriptors, frame.h:77-86):
+ * cv::ORB::compute.  May DROP keypoints (feature_match.h:15-17): kps/n are in/out.  desc: n*32 bytes.
+ * rgb (optional): n*3 bytes, the per-keypoint colour of frame.h:80-85 / basics::getPixelAt
+ * (src/basics/opencv_funcs.cpp:10-32).  reuse_pyramid != 0: `image` must be the image of the last
+ * mvo_calc_keypoints[_dev] call on this ctx (the pyramid is NOT rebuilt; image is still read for rgb
+ * and may be NULL if rgb is NULL). */
+int mvo_calc_descriptors(mvo_ctx* ctx, const uint8_t* image, int width, int height, int stride,
+                         int channels, int reuse_pyramid, mvo_keypoint* kps, int* n, uint8_t* desc,
+                         uint8_t* rgb);
+/* Descriptors stay on the device as well (d_desc_out receives a device pointer owned by the ctx, valid
+ * until the next extraction on this ctx) so the matcher can consume them without a PCIe round trip. */
+int mvo_calc_descriptors_dev(mvo_ctx* ctx, mvo_keypoint* kps, int* n, uint8_t* desc,
+                             const void** d_desc_out);
+/* geometry::selectUniformKptsByGrid (feature_match.cpp:51-84), host-side, in place. grid dims are the
+ * latched ones (first call: rows = image_rows / grid_size, cols = image_cols / grid_size). */
+int mvo_select_uniform_kpts_by_grid(mvo_ctx* ctx, mvo_keypoint* kps, int* n, int image_rows,
+                                    int image_cols);
+
+/* ---- matching ------------------------------------------------------------------------------ */
+/* cv::BFMatcher("BruteForce-Hamming")::knnMatch(k=2) as used at feature_match.cpp:203-208: exact
+ * 2-NN, equal distances keep the lower train index first.  idx/dist: nq x 2 int32; a missing
+ * neighbour is (-1, INT32_MAX). */
+int mvo_match_knn2(mvo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx,
+                   int32_t* dist);
+int mvo_match_knn2_dev(mvo_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int32_t* idx,
+                       int32_t* dist);
+/* geometry::matchByRadiusAndBruteForce (feature_match.cpp:86-124): per query the first minimum of
+ * sum|a-b| over the 32 descriptor bytes among trains within max_px pixels; idx -1 if none.
+ * `sum` is 32x the reference's mean-abs-difference. qxy/txy: n x 2 float (KeyPoint::pt). */
+int mvo_match_radius_l1(mvo_ctx* ctx, const uint8_t* q, const float* qxy, int nq, const uint8_t* t,
+                        const float* txy, int nt, float max_px, int32_t* idx, int32_t* sum);
+/* geometry::matchFeatures (feature_match.cpp:126-239; callers vo_addFrame.cpp:42,99, vo.cpp:283).
+ * method 1: exact 1-NN (replaces cv::FlannBasedMatcher(LshIndexParams(5,10,2)), which is approximate
+ * and RNG-seeded) + d < max(min_d * xiang_gao_ratio, 30); method 2: Lowe ratio d0 < lowe_ratio * d1;
+ * method 3: radius-gated L1 + the method-1 threshold; anything else MVO_ERR_INVALID.  Always followed
+ * by removeDuplicatedMatches.  The ratios are passed as the reference latches them: get<int> at
+ * feature_match.cpp:137-139 turns 0.8 into 1. */
+int mvo_match_features(mvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int method,
+                       double xiang_gao_ratio, double lowe_ratio, const float* xy1, const float* xy2,
+                       float max_px, mvo_dmatch* out, int cap, int* n);
+/* geometry::removeDuplicatedMatches (feature_match.cpp:241-260), host-side, in place. */
+int mvo_remove_duplicated_matches(mvo_dmatch* m, int* n);
+
+/* ---- bundle adjustment --------------------------------------------------------------------- */
+/* The graph optimization::bundleAdjustment builds (src/optimization/g2o_ba.cpp:172-317), flattened:
+ * pose vertices 0..F-1 (VertexSE3Expmap), point vertices (VertexSBAPointXYZ, marginalized), one
+ * EdgeProjectXYZ2UV + RobustKernelHuber per observation, CameraParameters(f, (cx, cy), 0). */
+typedef struct {
+    int32_t n_poses, n_points, n_edges;
+    double* pose_T_w_c;        /* n_poses x 16 row-major 4x4 cam->world (Frame::T_w_c_), in/out */
+    double* points;            /* n_points x 3, in/out (the adapter stores them back as f32, :308-316) */
+    const int32_t* edge_pose;  /* n_edges: index into poses */
+    const int32_t* edge_point; /* n_edges: index into points */
+    const double* edge_uv;     /* n_edges x 2 measured pixel */
+    double focal, cx, cy;      /* K(0,0), K(0,2), K(1,2) -- fy is ignored by the reference (:219-222) */
+    double info[4];            /* information_matrix (config.yaml:122) */
+    double huber_delta;        /* g2o::RobustKernelHuber default delta = 1 */
+    int32_t fix_points;        /* is_fix_map_pts */
+    const uint8_t* pose_fixed; /* optional per-pose setFixed flags; NULL = none (as the reference) */
+    int32_t max_iterations;    /* optimizer.optimize(50) */
+} mvo_ba_problem;
+
+typedef struct {
+    int32_t iterations, trials, terminated;
+    double chi2_initial, chi2_final, lambda_final;
+} mvo_ba_stats;
+
+/* optimization::bundleAdjustment (g2o_ba.cpp:172-317; caller VisualOdometry::callBundleAdjustment_,
+ * src/vo/vo.cpp:458-462). */
+int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
+
+/* ---- measurement --------------------------------------------------------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per
+ * kernel name until reset. */
+int mvo_profile_enable(mvo_ctx* ctx, int on);
+int mvo_profile_reset(mvo_ctx* ctx);
+/* Returns the number of distinct kernels; fills up to cap entries. */
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+} mvo_kernel_time;
+int mvo_profile_get(mvo_ctx* ctx, mvo_kernel_time* out, int cap);
+
+/* ---- debug / test hooks (used by tests/ to localise a parity failure; not part of the drop-in) ---- */
+/* key "ba_mfma": 1 (default) = matrix-core contractions, 0 = plain VALU loops computing the same sums. */
+int mvo_debug_set(const char* key, int value);
+/* Copies cached pyramid level `level` (raw gray or blurred) WITH its 32-px frame: (h+64) rows of `stride`
+ * bytes.  out == NULL only queries the geometry. */
+int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int cap, int* w, int* h, int* stride);
+/* FAST+NMS survivors of the last detection in canonical (level,row,col) order as 16-byte records
+ * {int16 x, y; int32 level<<16|fast_score; float harris; float angle}. */
+int mvo_debug_get_candidates(mvo_ctx* ctx, void* out, int cap, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,393 @@
+"""mvo_amd -- MI355X-native per-frame VO hot path (ORB extract + Hamming match + sliding-window BA).
+
+This package is plumbing around ``csrc/libmvo_hip.so`` (hand-written HIP kernels behind the C-ABI declared
+in ``include/mvo_hip.h``).  The Python layer only mirrors the reference's *interface* for this path
+(``my_slam::geometry`` / ``my_slam::optimization`` free functions, same names and argument meaning) so that
+tests read like the reference's own call sites; the product host code for a C++ caller is the header-only
+adapter under ``host/include/my_slam``.
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is visible, construction fails loudly.
+The directory name contains a '-', so import it through ``__graft_entry__.load_package()`` (module name
+``mvo_amd``).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import synth  # noqa: F401  (synthetic workloads)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmvo_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mvo_hip.h")
+
+MVO_OK, MVO_ERR_INVALID, MVO_ERR_NO_DEVICE, MVO_ERR_CAPACITY, MVO_ERR_HIP, MVO_ERR_STATE = 0, -1, -2, -3, -4, -5
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])   # cv::KeyPoint
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+CANDIDATE_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("level_score", "<i4"), ("harris", "<f4"), ("angle", "<f4")])
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("fast_threshold", C.c_int32), ("max_keypoints", C.c_int32), ("grid_size", C.c_int32),
+                ("grid_max_per_cell", C.c_int32)]
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("pose_T_w_c", C.c_void_p), ("points", C.c_void_p), ("edge_pose", C.c_void_p),
+                ("edge_point", C.c_void_p), ("edge_uv", C.c_void_p), ("focal", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("info", C.c_double * 4),
+                ("huber_delta", C.c_double), ("fix_points", C.c_int32), ("pose_fixed", C.c_void_p),
+                ("max_iterations", C.c_int32)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+class MvoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libmvo_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads csrc/libmvo_hip.so.  Fails loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("HIP extension %s is missing -- run __graft_entry__.build() (hipcc, gfx950). "
+                          "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.mvo_last_error.restype = C.c_char_p
+    lib.mvo_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _image_args(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        h, w = img.shape
+        ch = 1
+    else:
+        h, w, ch = img.shape
+    return img, w, h, w * ch, ch
+
+
+class Context:
+    """One mvo_ctx (= one HIP stream).  Not thread-safe; use one per host thread."""
+
+    def __init__(self, device=0, **orb_params):
+        self.lib = load_library()
+        h = C.c_void_p()
+        r = self.lib.mvo_create(C.byref(h), int(device))
+        if r != MVO_OK:
+            raise MvoError(r, "mvo_create failed (no usable HIP device?) -- there is no CPU fallback")
+        self.h = h
+        self.params = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500,
+                           grid_size=16, grid_max_per_cell=8)  # config/config.yaml:65-69,94-95
+        if orb_params:
+            self.orb_configure(**orb_params)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mvo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, r):
+        if r != MVO_OK:
+            raise MvoError(r, (self.lib.mvo_last_error(self.h) or b"").decode())
+
+    # ---- extraction
+    def orb_configure(self, **kw):
+        self.params.update(kw)
+        p = OrbParams(**self.params)
+        self._chk(self.lib.mvo_orb_configure(self.h, C.byref(p)))
+
+    def calc_keypoints(self, image, cap=None):
+        """geometry::calcKeyPoints (feature_match.cpp:11-36)."""
+        img, w, h, stride, ch = _image_args(image)
+        self._w, self._h = w, h
+        cap = cap or (self.params["max_keypoints"] + 16)
+        out = np.zeros(cap, KEYPOINT_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.mvo_calc_keypoints(self.h, _p(img), w, h, stride, ch, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def calc_keypoints_dev(self, d_ptr, w, h, stride, ch, cap=None):
+        self._w, self._h = w, h
+        cap = cap or (self.params["max_keypoints"] + 16)
+        out = np.zeros(cap, KEYPOINT_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.mvo_calc_keypoints_dev(self.h, C.c_void_p(d_ptr), w, h, stride, ch, _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    def calc_descriptors(self, image, kps, reuse_pyramid=False, want_rgb=False):
+        """geometry::calcDescriptors (feature_match.cpp:38-49): returns (keypoints', descriptors[, rgb])."""
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+        n = C.c_int(len(kps))
+        desc = np.zeros((max(len(kps), 1), 32), np.uint8)
+        rgb = np.zeros((max(len(kps), 1), 3), np.uint8) if want_rgb else None
+        if image is None:
+            img, w, h, stride, ch = None, self._w, self._h, 0, 1
+        else:
+            img, w, h, stride, ch = _image_args(image)
+        self._chk(self.lib.mvo_calc_descriptors(self.h, _p(img), w, h, stride, ch, int(reuse_pyramid), _p(kps),
+                                                C.byref(n), _p(desc), _p(rgb)))
+        if want_rgb:
+            return kps[:n.value].copy(), desc[:n.value].copy(), rgb[:n.value].copy()
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def calc_descriptors_dev(self, kps, want_host=True):
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+        n = C.c_int(len(kps))
+        desc = np.zeros((max(len(kps), 1), 32), np.uint8) if want_host else None
+        dptr = C.c_void_p()
+        self._chk(self.lib.mvo_calc_descriptors_dev(self.h, _p(kps), C.byref(n), _p(desc), C.byref(dptr)))
+        return kps[:n.value].copy(), (desc[:n.value].copy() if want_host else None), dptr.value
+
+    def select_uniform_kpts_by_grid(self, kps, image_rows, image_cols):
+        kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+        n = C.c_int(len(kps))
+        self._chk(self.lib.mvo_select_uniform_kpts_by_grid(self.h, _p(kps), C.byref(n), image_rows, image_cols))
+        return kps[:n.value].copy()
+
+    # ---- matching
+    def match_knn2(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        idx = np.zeros((len(q), 2), np.int32)
+        dist = np.zeros((len(q), 2), np.int32)
+        self._chk(self.lib.mvo_match_knn2(self.h, _p(q), len(q), _p(t), len(t), _p(idx), _p(dist)))
+        return idx, dist
+
+    def match_knn2_dev(self, d_q, nq, d_t, nt):
+        idx = np.zeros((nq, 2), np.int32)
+        dist = np.zeros((nq, 2), np.int32)
+        self._chk(self.lib.mvo_match_knn2_dev(self.h, C.c_void_p(d_q), nq, C.c_void_p(d_t), nt, _p(idx), _p(dist)))
+        return idx, dist
+
+    def match_radius_l1(self, q, qxy, t, txy, max_px):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        qxy = np.ascontiguousarray(qxy, np.float32).reshape(-1, 2)
+        txy = np.ascontiguousarray(txy, np.float32).reshape(-1, 2)
+        idx = np.zeros(len(q), np.int32)
+        s = np.zeros(len(q), np.int32)
+        self._chk(self.lib.mvo_match_radius_l1(self.h, _p(q), _p(qxy), len(q), _p(t), _p(txy), len(t),
+                                               C.c_float(max_px), _p(idx), _p(s)))
+        return idx, s
+
+    def match_features(self, d1, d2, method=1, xiang_gao_ratio=2.0, lowe_ratio=1.0, xy1=None, xy2=None, max_px=0.0):
+        """geometry::matchFeatures (feature_match.cpp:126-239); ratios as the reference latches them."""
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        if xy1 is not None:
+            xy1 = np.ascontiguousarray(xy1, np.float32).reshape(-1, 2)
+            xy2 = np.ascontiguousarray(xy2, np.float32).reshape(-1, 2)
+        out = np.zeros(max(len(d1), 1), DMATCH_DTYPE)
+        n = C.c_int()
+        r = self.lib.mvo_match_features(self.h, _p(d1), len(d1), _p(d2), len(d2), int(method),
+                                        C.c_double(xiang_gao_ratio), C.c_double(lowe_ratio), _p(xy1), _p(xy2),
+                                        C.c_float(max_px), _p(out), len(out), C.byref(n))
+        if r == MVO_ERR_INVALID and method not in (1, 2, 3):
+            # the reference throws std::runtime_error here (feature_match.cpp:225)
+            raise RuntimeError("feature_match.cpp::matchFeatures: wrong method index.")
+        self._chk(r)
+        return out[:n.value].copy()
+
+    # ---- bundle adjustment
+    def bundle_adjustment(self, poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info=(1, 0, 0, 1),
+                          huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50):
+        """optimization::bundleAdjustment on flattened arrays.  Returns (poses [F,4,4], points [L,3], stats)."""
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 16).copy()
+        points = np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy()
+        ep = np.ascontiguousarray(edge_pose, np.int32)
+        el = np.ascontiguousarray(edge_point, np.int32)
+        uv = np.ascontiguousarray(edge_uv, np.float64).reshape(-1, 2)
+        pf = None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8)
+        pr = BaProblem()
+        pr.n_poses, pr.n_points, pr.n_edges = len(poses), len(points), len(ep)
+        pr.pose_T_w_c, pr.points = poses.ctypes.data, points.ctypes.data
+        pr.edge_pose, pr.edge_point, pr.edge_uv = ep.ctypes.data, el.ctypes.data, uv.ctypes.data
+        pr.focal, pr.cx, pr.cy = focal, cx, cy
+        pr.info = (C.c_double * 4)(*np.asarray(info, np.float64).ravel())
+        pr.huber_delta = huber_delta
+        pr.fix_points = int(bool(fix_points))
+        pr.pose_fixed = None if pf is None else pf.ctypes.data
+        pr.max_iterations = int(max_iterations)
+        st = BaStats()
+        self._chk(self.lib.mvo_bundle_adjustment(self.h, C.byref(pr), C.byref(st)))
+        return poses.reshape(-1, 4, 4), points, {k: getattr(st, k) for k, _ in BaStats._fields_}
+
+    # ---- measurement / debug
+    def synchronize(self):
+        self._chk(self.lib.mvo_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self._chk(self.lib.mvo_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._chk(self.lib.mvo_profile_reset(self.h))
+
+    def profile_get(self):
+        arr = (KernelTime * 64)()
+        n = self.lib.mvo_profile_get(self.h, arr, 64)
+        return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(min(n, 64))}
+
+    def debug_level(self, level, blurred=False):
+        w, h, s = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.lib.mvo_debug_get_level(self.h, level, int(blurred), None, 0, C.byref(w), C.byref(h), C.byref(s)))
+        buf = np.zeros((h.value + 64, s.value), np.uint8)
+        self._chk(self.lib.mvo_debug_get_level(self.h, level, int(blurred), _p(buf), buf.size, None, None, None))
+        return buf[:, :w.value + 64].copy()
+
+    def debug_candidates(self):
+        n = C.c_int()
+        self._chk(self.lib.mvo_debug_get_candidates(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), CANDIDATE_DTYPE)
+        self._chk(self.lib.mvo_debug_get_candidates(self.h, _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+
+def debug_set(key, value):
+    r = load_library().mvo_debug_set(key.encode(), int(value))
+    if r != MVO_OK:
+        raise MvoError(r, "unknown debug key")
+
+
+def remove_duplicated_matches(matches):
+    """geometry::removeDuplicatedMatches (feature_match.cpp:241-260) -- host-side, needs no GPU."""
+    m = np.ascontiguousarray(matches, DMATCH_DTYPE).copy()
+    n = C.c_int(len(m))
+    r = load_library().mvo_remove_duplicated_matches(_p(m), C.byref(n))
+    if r != MVO_OK:
+        raise MvoError(r, "mvo_remove_duplicated_matches")
+    return m[:n.value].copy()
+
+
+# ------------------------------------------------------------------------------------------------------
+# Mirror of the reference's free-function interface (my_slam::geometry / my_slam::optimization) with the
+# same latching behaviour as its function-local statics.  `Config` plays basics::Config (config.h:16-50).
+class Config:
+    """basics::Config stand-in holding config/config.yaml:63-123 values; get_int reproduces the
+    cv::FileNode -> int rounding that turns lowe_method_dist_ratio 0.8 into 1 (feature_match.cpp:137-139)."""
+    values = {
+        "number_of_keypoints_to_extract": 8000, "max_number_of_keypoints": 1500, "scale_factor": 1.2,
+        "level_pyramid": 4, "score_threshold": 20,
+        "xiang_gao_method_match_ratio": 2, "lowe_method_dist_ratio": 0.8, "method_3_feature_dist_threshold": 50.0,
+        "kpts_uniform_selection_grid_size": 16, "kpts_uniform_selection_max_pts_per_grid": 8,
+        "num_prev_frames_to_opti_by_ba": 5, "information_matrix": "1.0 0.0 0.0 1.0", "is_ba_fix_map_points": "true",
+    }
+
+    @classmethod
+    def get(cls, key):
+        if key not in cls.values:
+            raise RuntimeError("Key " + key + " does not exist")  # config.cpp:34-35
+        return cls.values[key]
+
+    @classmethod
+    def get_int(cls, key):
+        return int(np.rint(float(cls.get(key))))  # cv::FileNode real -> int rounds
+
+
+_default_ctx = None
+
+
+def default_context():
+    """The process-wide ctx behind the free functions (the reference's function-local statics)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(nfeatures=Config.get_int("number_of_keypoints_to_extract"),
+                               scale_factor=float(Config.get("scale_factor")),
+                               nlevels=Config.get_int("level_pyramid"),
+                               fast_threshold=Config.get_int("score_threshold"),
+                               max_keypoints=Config.get_int("max_number_of_keypoints"),
+                               grid_size=Config.get_int("kpts_uniform_selection_grid_size"),
+                               grid_max_per_cell=Config.get_int("kpts_uniform_selection_max_pts_per_grid"))
+    return _default_ctx
+
+
+def reset_default_context():
+    global _default_ctx
+    if _default_ctx is not None:
+        _default_ctx.close()
+    _default_ctx = None
+
+
+def calcKeyPoints(image):
+    return default_context().calc_keypoints(image)
+
+
+def calcDescriptors(image, keypoints):
+    return default_context().calc_descriptors(image, keypoints)
+
+
+def selectUniformKptsByGrid(keypoints, image_rows, image_cols):
+    return default_context().select_uniform_kpts_by_grid(keypoints, image_rows, image_cols)
+
+
+def matchFeatures(descriptors_1, descriptors_2, method_index=1, is_print_res=False, keypoints_1=None,
+                  keypoints_2=None, max_matching_pixel_dist=0.0):
+    xy1 = xy2 = None
+    if keypoints_1 is not None and len(keypoints_1):
+        xy1 = np.stack([keypoints_1["x"], keypoints_1["y"]], 1)
+        xy2 = np.stack([keypoints_2["x"], keypoints_2["y"]], 1)
+    return default_context().match_features(descriptors_1, descriptors_2, method_index,
+                                            float(Config.get_int("xiang_gao_method_match_ratio")),
+                                            float(Config.get_int("lowe_method_dist_ratio")), xy1, xy2,
+                                            max_matching_pixel_dist)
+
+
+removeDuplicatedMatches = remove_duplicated_matches
+
+
+def bundleAdjustment(v_pts_2d, v_pts_2d_to_3d_idx, K, pts_3d, v_camera_g2o_poses, information_matrix,
+                     is_fix_map_pts=False, is_update_map_pts=True):
+    """optimization::bundleAdjustment (g2o_ba.h:23-30) with Python containers standing in for the pointer
+    lists: v_pts_2d[i] = float32 [n_i, 2] pixels of frame i, v_pts_2d_to_3d_idx[i] = map-point ids,
+    pts_3d = dict id -> float32[3] (mutated in place when is_update_map_pts), v_camera_g2o_poses = list of
+    4x4 float64 cam->world matrices (mutated in place)."""
+    ids = list(pts_3d.keys())
+    slot = {pid: i for i, pid in enumerate(ids)}
+    pts = np.array([pts_3d[i] for i in ids], np.float64).reshape(-1, 3)
+    ep, el, uv = [], [], []
+    for i, (p2, idx) in enumerate(zip(v_pts_2d, v_pts_2d_to_3d_idx)):
+        for j in range(len(p2)):
+            ep.append(i)
+            el.append(slot[idx[j]])
+            uv.append(p2[j])
+    poses = np.array(v_camera_g2o_poses, np.float64).reshape(-1, 16)
+    K = np.asarray(K, np.float64)
+    P, X, st = default_context().bundle_adjustment(
+        poses, pts, np.array(ep, np.int32), np.array(el, np.int32), np.array(uv, np.float64).reshape(-1, 2),
+        K[0, 0], K[0, 2], K[1, 2], np.asarray(information_matrix, np.float64).ravel(), 1.0, is_fix_map_pts)
+    for i in range(len(v_camera_g2o_poses)):
+        v_camera_g2o_poses[i][...] = P[i]
+    if is_update_map_pts:
+        for pid, x in zip(ids, X):
+            pts_3d[pid][...] = x.astype(np.float32)   # double -> cv::Point3f (g2o_ba.cpp:313-315)
+    return st

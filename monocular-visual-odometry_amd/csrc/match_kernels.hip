@@ -1,0 +1,135 @@
+// csrc/match_kernels.hip -- all-pairs descriptor matching on gfx950.
+//   k_knn2      exact 2-NN in 256-bit Hamming space: replaces cv::BFMatcher("BruteForce-Hamming")::knnMatch(k=2)
+//               (reference src/geometry/feature_match.cpp:141,203-208) and, as the exact 1-NN, the
+//               cv::FlannBasedMatcher(LshIndexParams(5,10,2))::match call at feature_match.cpp:140,162.
+//   k_radius_l1 geometry::matchByRadiusAndBruteForce (feature_match.cpp:86-124).
+// Work decomposition (wave64): one LANE per query, the query's 256 bits live in 4 x u64 VGPRs; the train
+// descriptor of the current step is wave-uniform, so it is fetched with scalar loads (s_load_dwordx8) and
+// broadcast for free; distance = 4 x (v_xor + v_bcnt64).  A workgroup = 16 waves x the same 64 queries, each
+// wave scanning one contiguous slice of the train set in index order; the 16 partial (best, second) pairs are
+// merged through LDS in slice order with strict '<', which reproduces cv::batchDistance's tie rule exactly
+// (equal distances keep the lower train index).  Everything is integer: results are bit-exact.
+// The whole working set (<= 2 x 128 KB) is L2-resident: the bound is VALU integer throughput, not HBM.
+#include "mvo_internal.h"
+
+#include <climits>
+
+typedef unsigned long long u64;
+
+#define MK_WAVES 16
+
+struct Top2 {
+    int d0, i0, d1, i1;
+};
+
+__device__ __forceinline__ void top2_insert(Top2& t, int d, int j) {
+    // strict '<' on both levels: an equal distance never displaces an earlier (lower-index) entry
+    bool lt0 = d < t.d0, lt1 = d < t.d1;
+    int nd1 = lt0 ? t.d0 : (lt1 ? d : t.d1);
+    int ni1 = lt0 ? t.i0 : (lt1 ? j : t.i1);
+    t.d0 = lt0 ? d : t.d0;
+    t.i0 = lt0 ? j : t.i0;
+    t.d1 = nd1;
+    t.i1 = ni1;
+}
+
+__global__ __launch_bounds__(1024) void k_knn2(const u64* __restrict__ q, int nq, const u64* __restrict__ t,
+                                               int nt, int32_t* __restrict__ out_idx,
+                                               int32_t* __restrict__ out_dist) {
+    __shared__ Top2 part[MK_WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.x * 64 + lane;
+    const int qc = min(qi, nq - 1);
+    const u64 q0 = q[4 * (size_t)qc], q1 = q[4 * (size_t)qc + 1], q2 = q[4 * (size_t)qc + 2],
+              q3 = q[4 * (size_t)qc + 3];
+    const int slice = (nt + MK_WAVES - 1) / MK_WAVES;
+    const int j0 = wave * slice, j1 = min(nt, j0 + slice);
+    Top2 b = {INT_MAX, -1, INT_MAX, -1};
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const u64* tj = t + 4 * (size_t)j;  // wave-uniform address -> scalar loads
+        int d = __popcll(q0 ^ tj[0]) + __popcll(q1 ^ tj[1]) + __popcll(q2 ^ tj[2]) + __popcll(q3 ^ tj[3]);
+        top2_insert(b, d, j);
+    }
+    part[wave][lane] = b;
+    __syncthreads();
+    if (wave == 0 && qi < nq) {
+        Top2 r = part[0][lane];
+#pragma unroll
+        for (int w = 1; w < MK_WAVES; ++w) {
+            Top2 p = part[w][lane];
+            if (p.i0 >= 0) top2_insert(r, p.d0, p.i0);
+            if (p.i1 >= 0) top2_insert(r, p.d1, p.i1);
+        }
+        out_idx[2 * qi] = r.i0;
+        out_idx[2 * qi + 1] = r.i1;
+        out_dist[2 * qi] = r.d0;
+        out_dist[2 * qi + 1] = r.d1;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__ q, const float2* __restrict__ qxy,
+                                                    int nq, const uint32_t* __restrict__ t,
+                                                    const float2* __restrict__ txy, int nt, float r2,
+                                                    int32_t* __restrict__ out_idx, int32_t* __restrict__ out_sum) {
+    __shared__ int2 part[MK_WAVES][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int qi = blockIdx.x * 64 + lane;
+    const int qc = min(qi, nq - 1);
+    uint32_t qd[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) qd[k] = q[8 * (size_t)qc + k];
+    const float2 p = qxy[qc];
+    const int slice = (nt + MK_WAVES - 1) / MK_WAVES;
+    const int j0 = wave * slice, j1 = min(nt, j0 + slice);
+    int best = INT_MAX, bi = -1;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) {
+        const float2 p2 = txy[j];
+        const float dx = __fsub_rn(p.x, p2.x), dy = __fsub_rn(p.y, p2.y);
+        const bool in = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)) <= r2;
+        const uint32_t* tj = t + 8 * (size_t)j;
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s = __builtin_amdgcn_sad_u8(qd[k], tj[k], s);
+        const bool take = in && (int)s < best;  // strict '<': the first minimum wins
+        best = take ? (int)s : best;
+        bi = take ? j : bi;
+    }
+    part[wave][lane] = make_int2(best, bi);
+    __syncthreads();
+    if (wave == 0 && qi < nq) {
+        int rb = part[0][lane].x, ri = part[0][lane].y;
+#pragma unroll
+        for (int w = 1; w < MK_WAVES; ++w) {
+            int2 c = part[w][lane];
+            bool take = c.y >= 0 && c.x < rb;
+            rb = take ? c.x : rb;
+            ri = take ? c.y : ri;
+        }
+        out_idx[qi] = ri;
+        out_sum[qi] = rb;
+    }
+}
+
+int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out) {
+    if (nq <= 0) return MVO_OK;
+    ProfScope ps(ctx, "k_knn2");
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(1024), 0, ctx->stream, (const u64*)d_q, nq,
+                       (const u64*)d_t, nt, d_out, d_out + 2 * (size_t)nq);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}
+
+int match_launch_radius_l1(mvo_ctx* ctx, const uint8_t* d_q, const float* d_qxy, int nq, const uint8_t* d_t,
+                           const float* d_txy, int nt, float max_px, int32_t* d_out) {
+    if (nq <= 0) return MVO_OK;
+    ProfScope ps(ctx, "k_radius_l1");
+    hipLaunchKernelGGL(k_radius_l1, dim3((nq + 63) / 64), dim3(1024), 0, ctx->stream, (const uint32_t*)d_q,
+                       (const float2*)d_qxy, nq, (const uint32_t*)d_t, (const float2*)d_txy, nt,
+                       max_px * max_px, d_out, d_out + nq);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}

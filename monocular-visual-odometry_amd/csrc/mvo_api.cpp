@@ -1,0 +1,493 @@
+// csrc/mvo_api.cpp -- the C-ABI of libmvo_hip.so (include/mvo_hip.h).  Thin: argument checks, H2D/D2H staging,
+// the reference's host-side filters (thresholds, Lowe ratio, de-dup) and calls into the kernel launchers.
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "mvo_internal.h"
+
+int orb_setup_geometry(mvo_ctx* ctx, int w, int h);
+int orb_grid_select(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int image_rows, int image_cols);
+int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int channels,
+                      std::vector<mvo_keypoint>& out);
+int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int h, uint8_t* desc_host);
+void orb_border_filter(std::vector<mvo_keypoint>& kps, int w, int h);
+
+int mvo_set_err(mvo_ctx* c, int code, const char* what, hipError_t e) {
+    if (c) {
+        c->err = what ? what : "";
+        if (e != hipSuccess) {
+            c->err += ": ";
+            c->err += hipGetErrorString(e);
+        }
+    }
+    return code;
+}
+
+// ---------------------------------------------------------------------------------------------- profiling
+void mvo_prof_begin(mvo_ctx* c, const char* name) {
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!c->prof_pool.empty()) {
+        ev = c->prof_pool.back();
+        c->prof_pool.pop_back();
+    } else {
+        (void)hipEventCreate(&ev.first);
+        (void)hipEventCreate(&ev.second);
+    }
+    (void)hipEventRecord(ev.first, c->stream);
+    c->prof_pending.push_back({name, ev});
+}
+void mvo_prof_end(mvo_ctx* c) { (void)hipEventRecord(c->prof_pending.back().second.second, c->stream); }
+void mvo_prof_collect(mvo_ctx* c) {
+    if (c->prof_pending.empty()) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof_pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.second.first, p.second.second) == hipSuccess) {
+            ProfEntry& e = c->prof_acc[p.first];
+            e.launches++;
+            e.ms += ms;
+        }
+        c->prof_pool.push_back(p.second);
+    }
+    c->prof_pending.clear();
+}
+
+extern "C" {
+
+int mvo_create(mvo_ctx** out, int device) {
+    if (!out) return MVO_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MVO_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MVO_ERR_NO_DEVICE;
+    mvo_ctx* ctx = new mvo_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return MVO_ERR_NO_DEVICE;
+    }
+    // config/config.yaml:65-69,94-95
+    ctx->orb = mvo_orb_params{8000, 1.2f, 4, 20, 1500, 16, 8};
+    ctx->orb_configured = true;
+    *out = ctx;
+    return MVO_OK;
+}
+
+void mvo_destroy(mvo_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_score, ctx->d_tabs, ctx->d_cell_mask, ctx->d_cell_cnt,
+                   ctx->d_hdr, ctx->d_kp,   ctx->d_desc, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
+                   ctx->d_mout, ctx->d_ba};
+    for (void* p : dev)
+        if (p) (void)hipFree(p);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (auto& p : ctx->prof_pending) ctx->prof_pool.push_back(p.second);
+    for (auto& e : ctx->prof_pool) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    (void)hipEventDestroy(ctx->ev);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* mvo_last_error(const mvo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int mvo_synchronize(mvo_ctx* ctx) {
+    if (!ctx) return MVO_ERR_INVALID;
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    return MVO_OK;
+}
+
+int mvo_orb_configure(mvo_ctx* ctx, const mvo_orb_params* p) {
+    if (!ctx || !p) return MVO_ERR_INVALID;
+    if (p->nlevels < 1 || p->nlevels > MVO_MAX_LEVELS || p->scale_factor <= 1.f || p->nfeatures < 0 ||
+        p->fast_threshold < 1 || p->fast_threshold > 254 || p->grid_size < 1 || p->grid_max_per_cell < 0 ||
+        p->max_keypoints < 0)
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "mvo_orb_configure: parameter out of range", hipSuccess);
+    ctx->orb = *p;
+    ctx->orb_configured = true;
+    ctx->grid_rows = ctx->grid_cols = 0;
+    ctx->img_w = ctx->img_h = 0;  // forces the geometry (level sizes, quotas, tables) to be rebuilt
+    ctx->pyr_valid = ctx->blur_valid = false;
+    return MVO_OK;
+}
+
+static int check_image(mvo_ctx* ctx, const void* img, int w, int h, int stride, int ch) {
+    if (!ctx) return MVO_ERR_INVALID;
+    if (!img || w < 1 || h < 1 || (ch != 1 && ch != 3 && ch != 4) || stride < w * ch)
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad image arguments", hipSuccess);
+    return MVO_OK;
+}
+
+static int upload_image(mvo_ctx* ctx, const uint8_t* img, int h, int stride) {
+    const size_t bytes = (size_t)h * stride;
+    if (ctx->d_img_cap < bytes) {
+        if (ctx->d_img) (void)hipFree(ctx->d_img);
+        ctx->d_img = nullptr;
+        ctx->d_img_cap = 0;
+        MVO_HIP(hipMalloc((void**)&ctx->d_img, bytes + 64));
+        ctx->d_img_cap = bytes;
+    }
+    MVO_HIP(hipMemcpyAsync(ctx->d_img, img, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MVO_OK;
+}
+
+static int calc_keypoints_common(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int ch,
+                                 mvo_keypoint* kps, int cap, int* n) {
+    std::vector<mvo_keypoint> v;
+    int r = orb_detect_device(ctx, d_img, w, h, stride, ch, v);
+    if (r) return r;
+    if ((r = orb_grid_select(ctx, v, h, w))) return r;
+    if (ctx->prof) mvo_prof_collect(ctx);
+    *n = (int)v.size();
+    if ((int)v.size() > cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "keypoint buffer too small", hipSuccess);
+    std::copy(v.begin(), v.end(), kps);
+    return MVO_OK;
+}
+
+int mvo_calc_keypoints(mvo_ctx* ctx, const uint8_t* image, int w, int h, int stride, int ch, mvo_keypoint* kps,
+                       int cap, int* n) {
+    int r = check_image(ctx, image, w, h, stride, ch);
+    if (r) return r;
+    if (!kps || !n) return mvo_set_err(ctx, MVO_ERR_INVALID, "null output", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    if ((r = upload_image(ctx, image, h, stride))) return r;
+    return calc_keypoints_common(ctx, ctx->d_img, w, h, stride, ch, kps, cap, n);
+}
+
+int mvo_calc_keypoints_dev(mvo_ctx* ctx, const void* d_image, int w, int h, int stride, int ch, mvo_keypoint* kps,
+                           int cap, int* n) {
+    int r = check_image(ctx, d_image, w, h, stride, ch);
+    if (r) return r;
+    if (!kps || !n) return mvo_set_err(ctx, MVO_ERR_INVALID, "null output", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    return calc_keypoints_common(ctx, (const uint8_t*)d_image, w, h, stride, ch, kps, cap, n);
+}
+
+static int describe_common(mvo_ctx* ctx, int w, int h, mvo_keypoint* kps, int* n, uint8_t* desc,
+                           std::vector<mvo_keypoint>& v) {
+    v.assign(kps, kps + *n);
+    orb_border_filter(v, w, h);
+    for (const mvo_keypoint& k : v)
+        if (k.octave < 0 || k.octave >= ctx->pyr_levels_built)
+            return mvo_set_err(ctx, MVO_ERR_INVALID, "keypoint octave outside the built pyramid", hipSuccess);
+    int r = orb_describe_device(ctx, v, w, h, desc);
+    if (r) return r;
+    if (ctx->prof) mvo_prof_collect(ctx);
+    std::copy(v.begin(), v.end(), kps);
+    *n = (int)v.size();
+    return MVO_OK;
+}
+
+int mvo_calc_descriptors(mvo_ctx* ctx, const uint8_t* image, int w, int h, int stride, int ch, int reuse_pyramid,
+                         mvo_keypoint* kps, int* n, uint8_t* desc, uint8_t* rgb) {
+    if (!ctx || !kps || !n || !desc || *n < 0) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r;
+    if (reuse_pyramid) {
+        if (!ctx->pyr_valid || !ctx->blur_valid || ctx->img_w != w || ctx->img_h != h)
+            return mvo_set_err(ctx, MVO_ERR_STATE, "reuse_pyramid without a cached pyramid of this size", hipSuccess);
+        if (rgb && (r = check_image(ctx, image, w, h, stride, ch))) return r;
+    } else {
+        if ((r = check_image(ctx, image, w, h, stride, ch))) return r;
+        // cv::ORB::compute: nLevels = max octave + 1 (orb2 is created with level_pyramid, feature_match.cpp:45)
+        int need = 1;
+        for (int i = 0; i < *n; ++i) need = std::max(need, kps[i].octave + 1);
+        if ((r = orb_setup_geometry(ctx, w, h))) return r;
+        if (need > ctx->pyr.nlevels)
+            return mvo_set_err(ctx, MVO_ERR_INVALID, "keypoint octave exceeds level_pyramid", hipSuccess);
+        if ((r = upload_image(ctx, image, h, stride))) return r;
+        ctx->pyr_valid = ctx->blur_valid = false;
+        if ((r = orb_launch_pyramid(ctx, ctx->d_img, stride, ch, need))) return r;
+        if ((r = orb_launch_blur(ctx, need))) return r;
+        ctx->pyr_levels_built = need;
+        ctx->pyr_valid = ctx->blur_valid = true;
+    }
+    std::vector<mvo_keypoint> v;
+    if ((r = describe_common(ctx, w, h, kps, n, desc, v))) return r;
+    if (rgb) {  // frame.h:80-85 + basics::getPixelAt (opencv_funcs.cpp:10-32): BGR -> r,g,b
+        for (size_t j = 0; j < v.size(); ++j) {
+            int x = (int)std::floor(v[j].x), y = (int)std::floor(v[j].y);
+            const uint8_t* px = image + (size_t)y * stride + (size_t)x * ch;
+            if (ch >= 3) {
+                rgb[3 * j] = px[2];
+                rgb[3 * j + 1] = px[1];
+                rgb[3 * j + 2] = px[0];
+            } else {
+                rgb[3 * j] = rgb[3 * j + 1] = rgb[3 * j + 2] = px[0];
+            }
+        }
+    }
+    return MVO_OK;
+}
+
+int mvo_calc_descriptors_dev(mvo_ctx* ctx, mvo_keypoint* kps, int* n, uint8_t* desc, const void** d_desc_out) {
+    if (!ctx || !kps || !n || *n < 0) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    if (!ctx->pyr_valid || !ctx->blur_valid)
+        return mvo_set_err(ctx, MVO_ERR_STATE, "no cached pyramid: call mvo_calc_keypoints[_dev] first", hipSuccess);
+    std::vector<mvo_keypoint> v;
+    int r = describe_common(ctx, ctx->img_w, ctx->img_h, kps, n, desc, v);
+    if (r) return r;
+    if (!desc) MVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (d_desc_out) *d_desc_out = ctx->d_desc;
+    return MVO_OK;
+}
+
+int mvo_select_uniform_kpts_by_grid(mvo_ctx* ctx, mvo_keypoint* kps, int* n, int image_rows, int image_cols) {
+    if (!ctx || !kps || !n || *n < 0) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    std::vector<mvo_keypoint> v(kps, kps + *n);
+    int r = orb_grid_select(ctx, v, image_rows, image_cols);
+    if (r) return r;
+    std::copy(v.begin(), v.end(), kps);
+    *n = (int)v.size();
+    return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- matching
+static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
+    if (nq > ctx->m_cap_q) {
+        if (ctx->d_mq) (void)hipFree(ctx->d_mq);
+        if (ctx->d_mqxy) (void)hipFree(ctx->d_mqxy);
+        if (ctx->d_mout) (void)hipFree(ctx->d_mout);
+        ctx->d_mq = nullptr;
+        ctx->d_mqxy = nullptr;
+        ctx->d_mout = nullptr;
+        ctx->m_cap_q = 0;
+        int cap = std::max(4096, nq + nq / 2);
+        MVO_HIP(hipMalloc((void**)&ctx->d_mq, (size_t)cap * 32));
+        MVO_HIP(hipMalloc((void**)&ctx->d_mqxy, (size_t)cap * 8));
+        MVO_HIP(hipMalloc((void**)&ctx->d_mout, (size_t)cap * 16));
+        ctx->m_cap_q = cap;
+    }
+    if (nt > ctx->m_cap_t) {
+        if (ctx->d_mt) (void)hipFree(ctx->d_mt);
+        if (ctx->d_mtxy) (void)hipFree(ctx->d_mtxy);
+        ctx->d_mt = nullptr;
+        ctx->d_mtxy = nullptr;
+        ctx->m_cap_t = 0;
+        int cap = std::max(4096, nt + nt / 2);
+        MVO_HIP(hipMalloc((void**)&ctx->d_mt, (size_t)cap * 32));
+        MVO_HIP(hipMalloc((void**)&ctx->d_mtxy, (size_t)cap * 8));
+        ctx->m_cap_t = cap;
+    }
+    return MVO_OK;
+}
+
+static int knn2_common(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* idx,
+                       int32_t* dist) {
+    int r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout);
+    if (r) return r;
+    if ((r = mvo_ensure_pinned(ctx, (size_t)nq * 16))) return r;
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_mout, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) mvo_prof_collect(ctx);
+    std::memcpy(idx, ctx->h_pin, (size_t)nq * 8);
+    std::memcpy(dist, ctx->h_pin + (size_t)nq * 8, (size_t)nq * 8);
+    return MVO_OK;
+}
+
+int mvo_match_knn2(mvo_ctx* ctx, const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist) {
+    if (!ctx || nq < 0 || nt < 0 || (nq && (!q || !idx || !dist)) || (nt && !t))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (nq == 0) return MVO_OK;
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = ensure_match_bufs(ctx, nq, nt);
+    if (r) return r;
+    MVO_HIP(hipMemcpyAsync(ctx->d_mq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (nt) MVO_HIP(hipMemcpyAsync(ctx->d_mt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+    return knn2_common(ctx, ctx->d_mq, nq, ctx->d_mt, nt, idx, dist);
+}
+
+int mvo_match_knn2_dev(mvo_ctx* ctx, const void* d_q, int nq, const void* d_t, int nt, int32_t* idx, int32_t* dist) {
+    if (!ctx || nq < 0 || nt < 0 || (nq && (!d_q || !idx || !dist)) || (nt && !d_t))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (nq == 0) return MVO_OK;
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = ensure_match_bufs(ctx, nq, 0);
+    if (r) return r;
+    return knn2_common(ctx, (const uint8_t*)d_q, nq, (const uint8_t*)d_t, nt, idx, dist);
+}
+
+int mvo_match_radius_l1(mvo_ctx* ctx, const uint8_t* q, const float* qxy, int nq, const uint8_t* t, const float* txy,
+                        int nt, float max_px, int32_t* idx, int32_t* sum) {
+    if (!ctx || nq < 0 || nt < 0 || (nq && (!q || !qxy || !idx || !sum)) || (nt && (!t || !txy)))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (nq == 0) return MVO_OK;
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = ensure_match_bufs(ctx, nq, nt);
+    if (r) return r;
+    MVO_HIP(hipMemcpyAsync(ctx->d_mq, q, (size_t)nq * 32, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(ctx->d_mqxy, qxy, (size_t)nq * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (nt) {
+        MVO_HIP(hipMemcpyAsync(ctx->d_mt, t, (size_t)nt * 32, hipMemcpyHostToDevice, ctx->stream));
+        MVO_HIP(hipMemcpyAsync(ctx->d_mtxy, txy, (size_t)nt * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if ((r = match_launch_radius_l1(ctx, ctx->d_mq, ctx->d_mqxy, nq, ctx->d_mt, ctx->d_mtxy, nt, max_px, ctx->d_mout)))
+        return r;
+    if ((r = mvo_ensure_pinned(ctx, (size_t)nq * 8))) return r;
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_mout, (size_t)nq * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) mvo_prof_collect(ctx);
+    std::memcpy(idx, ctx->h_pin, (size_t)nq * 4);
+    std::memcpy(sum, ctx->h_pin + (size_t)nq * 4, (size_t)nq * 4);
+    return MVO_OK;
+}
+
+int mvo_remove_duplicated_matches(mvo_dmatch* m, int* n) {
+    if (!n || *n < 0 || (*n && !m)) return MVO_ERR_INVALID;
+    // feature_match.cpp:241-260: std::sort by trainIdx (unstable; comparator ignores the distance), keep the
+    // first of every run
+    std::sort(m, m + *n, [](const mvo_dmatch& a, const mvo_dmatch& b) { return a.trainIdx < b.trainIdx; });
+    int k = 0;
+    for (int i = 0; i < *n; ++i)
+        if (i == 0 || m[i].trainIdx != m[i - 1].trainIdx) m[k++] = m[i];
+    // (in-place compaction is safe: k <= i, and m[i-1] is read before slot i-1 can be overwritten only by itself)
+    *n = k;
+    return MVO_OK;
+}
+
+int mvo_match_features(mvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int method,
+                       double xiang_gao_ratio, double lowe_ratio, const float* xy1, const float* xy2, float max_px,
+                       mvo_dmatch* out, int cap, int* n) {
+    if (!ctx || !n || n1 < 0 || n2 < 0) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    *n = 0;
+    std::vector<mvo_dmatch> matches;
+    double min_dis = 9999999, max_dis = 0;
+    int r;
+    if (method == 1 || method == 3) {
+        std::vector<mvo_dmatch> all;
+        if (method == 3) {
+            if (n1 && n2 && (!xy1 || !xy2))
+                return mvo_set_err(ctx, MVO_ERR_INVALID, "method 3 needs keypoint positions", hipSuccess);
+            std::vector<int32_t> idx(n1), sum(n1);
+            if ((r = mvo_match_radius_l1(ctx, d1, xy1, n1, d2, xy2, n2, max_px, idx.data(), sum.data()))) return r;
+            for (int i = 0; i < n1; ++i)
+                if (idx[i] >= 0) all.push_back({i, idx[i], -1, (float)((double)sum[i] / 32)});
+        } else {
+            std::vector<int32_t> idx(2 * (size_t)n1), dist(2 * (size_t)n1);
+            if ((r = mvo_match_knn2(ctx, d1, n1, d2, n2, idx.data(), dist.data()))) return r;
+            for (int i = 0; i < n1; ++i)
+                if (idx[2 * i] >= 0) all.push_back({i, idx[2 * i], 0, (float)dist[2 * i]});
+        }
+        for (const mvo_dmatch& m : all) {  // feature_match.cpp:179-186
+            double dist = m.distance;
+            if (dist < min_dis) min_dis = dist;
+            if (dist > max_dis) max_dis = dist;
+        }
+        const double thr = std::max<float>(min_dis * xiang_gao_ratio, 30.0);  // :187
+        for (const mvo_dmatch& m : all)
+            if (m.distance < thr) matches.push_back(m);
+    } else if (method == 2) {
+        std::vector<int32_t> idx(2 * (size_t)n1), dist(2 * (size_t)n1);
+        if ((r = mvo_match_knn2(ctx, d1, n1, d2, n2, idx.data(), dist.data()))) return r;
+        for (int i = 0; i < n1; ++i) {
+            if (idx[2 * i + 1] < 0) continue;  // the reference would read knn_matches[i][1] out of bounds
+            const double d = (float)dist[2 * i];
+            if (d < lowe_ratio * (float)dist[2 * i + 1]) matches.push_back({i, idx[2 * i], 0, (float)dist[2 * i]});
+        }
+    } else {
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "feature_match.cpp::matchFeatures: wrong method index.", hipSuccess);
+    }
+    int cnt = (int)matches.size();
+    mvo_remove_duplicated_matches(matches.data(), &cnt);
+    *n = cnt;
+    if (cnt > cap || (cnt && !out)) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "match buffer too small", hipSuccess);
+    std::copy(matches.begin(), matches.begin() + cnt, out);
+    return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- BA
+int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
+    if (!ctx || !p || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0)
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if ((p->n_poses && !p->pose_T_w_c) || (p->n_points && !p->points) ||
+        (p->n_edges && (!p->edge_pose || !p->edge_point || !p->edge_uv)))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "null array", hipSuccess);
+    for (int e = 0; e < p->n_edges; ++e)
+        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 ||
+            p->edge_point[e] >= p->n_points)
+            return mvo_set_err(ctx, MVO_ERR_INVALID, "edge index out of range", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = ba_solve_device(ctx, p, st);
+    if (ctx->prof) mvo_prof_collect(ctx);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------- debug hooks
+extern int g_ba_use_mfma;
+int mvo_debug_set(const char* key, int value) {
+    if (key && !std::strcmp(key, "ba_mfma")) {
+        g_ba_use_mfma = value;
+        return MVO_OK;
+    }
+    return MVO_ERR_INVALID;
+}
+
+int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int cap, int* w, int* h, int* stride) {
+    if (!ctx || !ctx->pyr_valid || level < 0 || level >= ctx->pyr_levels_built)
+        return mvo_set_err(ctx, MVO_ERR_STATE, "no such cached level", hipSuccess);
+    if (blurred && !ctx->blur_valid) return mvo_set_err(ctx, MVO_ERR_STATE, "no blurred pyramid", hipSuccess);
+    const LevelInfo& L = ctx->pyr.lv[level];
+    const size_t bytes = (size_t)L.stride * (L.h + 2 * MVO_BORDER);
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (stride) *stride = L.stride;
+    if (!out) return MVO_OK;
+    if ((size_t)cap < bytes) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "level buffer too small", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    MVO_HIP(hipMemcpy(out, (blurred ? ctx->d_blur : ctx->d_raw) + L.off, bytes, hipMemcpyDeviceToHost));
+    return MVO_OK;
+}
+
+int mvo_debug_get_candidates(mvo_ctx* ctx, void* out, int cap, int* n) {
+    if (!ctx || !ctx->pyr_valid || !n) return mvo_set_err(ctx, MVO_ERR_STATE, "no detection cached", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    CandHeader hdr;
+    MVO_HIP(hipMemcpy(&hdr, ctx->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
+    *n = hdr.n_total;
+    if (!out) return MVO_OK;
+    if (hdr.n_total > cap || hdr.n_total > ctx->cand_cap)
+        return mvo_set_err(ctx, MVO_ERR_CAPACITY, "candidate buffer too small", hipSuccess);
+    MVO_HIP(hipMemcpy(out, ctx->d_cand, (size_t)hdr.n_total * sizeof(DevCandidate), hipMemcpyDeviceToHost));
+    return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- measurement
+int mvo_profile_enable(mvo_ctx* ctx, int on) {
+    if (!ctx) return MVO_ERR_INVALID;
+    mvo_prof_collect(ctx);
+    ctx->prof = on != 0;
+    return MVO_OK;
+}
+int mvo_profile_reset(mvo_ctx* ctx) {
+    if (!ctx) return MVO_ERR_INVALID;
+    mvo_prof_collect(ctx);
+    ctx->prof_acc.clear();
+    return MVO_OK;
+}
+int mvo_profile_get(mvo_ctx* ctx, mvo_kernel_time* out, int cap) {
+    if (!ctx) return MVO_ERR_INVALID;
+    mvo_prof_collect(ctx);
+    int i = 0;
+    for (auto& kv : ctx->prof_acc) {
+        if (i < cap && out) {
+            std::snprintf(out[i].name, sizeof(out[i].name), "%s", kv.first.c_str());
+            out[i].launches = kv.second.launches;
+            out[i].total_ms = kv.second.ms;
+        }
+        ++i;
+    }
+    return i;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// csrc/mvo_internal.h -- context, device buffers and launch plumbing shared by the HIP translation units.
+#ifndef MVO_INTERNAL_H
+#define MVO_INTERNAL_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mvo_hip.h"
+
+#define MVO_MAX_LEVELS 8
+#define MVO_BORDER 32  // ORB: max(edgeThreshold 31, descPatchSize 22, HARRIS_BLOCK/2) + 1
+
+// One pyramid level inside the device pyramid buffers (raw, blurred share the geometry).
+struct LevelInfo {
+    int w, h;        // interior size
+    int stride;      // bytes per bordered row, multiple of 64
+    int off;         // byte offset of bordered row 0 inside the pyramid buffer
+    int tiles_x;     // 64-px-wide NMS cell columns (FAST tiles are 64 x 16 interior pixels)
+    int tiles_y;
+    int tile_off;    // first FAST tile of this level in the flattened tile list
+    int cell_off;    // first (row, tile column) cell of this level in the cell arrays
+    int btiles_x;    // blur tiles (64 x 16) over the bordered extent
+    int btiles_y;
+    int btile_off;
+    int tab_off;     // offset of this level's resize tables: [x entries w][y entries h]
+    float scale;     // layerScale[level]
+};
+struct PyrInfo {
+    int nlevels;
+    int n_cells;
+    int n_tiles;
+    int n_btiles;
+    LevelInfo lv[MVO_MAX_LEVELS];
+};
+
+// FAST+NMS survivor as the device emits it (16 bytes), canonical order: level, row, column.
+struct DevCandidate {
+    int16_t x, y;
+    int32_t level_score;  // level << 16 | fast score
+    float harris;
+    float angle;
+};
+// Keypoint as uploaded for the rBRIEF kernel.
+struct DevDescKp {
+    int16_t cx, cy;  // cvRound(pt * 1/scale) in level coordinates
+    int32_t level;
+    float a, b;  // cos / sin of the keypoint angle, computed on the host
+};
+struct ResizeEntry {
+    int32_t ofs;
+    int16_t c0, c1;
+};
+
+struct CandHeader {
+    int32_t n_total;
+    int32_t level_start[MVO_MAX_LEVELS + 1];
+    int32_t pad[3];
+};
+
+struct ProfEntry {
+    int64_t launches = 0;
+    double ms = 0;
+};
+
+struct mvo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // --- ORB
+    mvo_orb_params orb{};
+    bool orb_configured = false;
+    int grid_rows = 0, grid_cols = 0;  // latched from the first image
+    int img_w = 0, img_h = 0;
+    PyrInfo pyr{};
+    std::vector<int> quota;
+    bool pyr_valid = false, blur_valid = false;
+    int pyr_levels_built = 0;
+    uint8_t* d_img = nullptr;
+    size_t d_img_cap = 0;
+    uint8_t *d_raw = nullptr, *d_blur = nullptr, *d_score = nullptr;
+    size_t pyr_bytes = 0;
+    ResizeEntry* d_tabs = nullptr;
+    unsigned long long* d_cell_mask = nullptr;
+    int32_t* d_cell_cnt = nullptr;
+    CandHeader* d_hdr = nullptr;
+    DevCandidate* d_cand = nullptr;
+    int cand_cap = 0;
+    DevDescKp* d_kp = nullptr;
+    uint8_t* d_desc = nullptr;
+    int kp_cap = 0;
+    // pinned host staging
+    uint8_t* h_pin = nullptr;
+    size_t h_pin_cap = 0;
+    hipEvent_t ev = nullptr;
+    // --- matcher
+    uint8_t *d_mq = nullptr, *d_mt = nullptr;
+    float *d_mqxy = nullptr, *d_mtxy = nullptr;
+    int32_t* d_mout = nullptr;
+    int m_cap_q = 0, m_cap_t = 0;
+    // --- BA
+    void* d_ba = nullptr;
+    size_t d_ba_cap = 0;
+    // --- profiling
+    bool prof = false;
+    std::map<std::string, ProfEntry> prof_acc;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> prof_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+};
+
+int mvo_set_err(mvo_ctx* c, int code, const char* what, hipError_t e);
+#define MVO_HIP(call)                                                            \
+    do {                                                                         \
+        hipError_t e__ = (call);                                                 \
+        if (e__ != hipSuccess) return mvo_set_err(ctx, MVO_ERR_HIP, #call, e__); \
+    } while (0)
+
+// profiling brackets
+void mvo_prof_begin(mvo_ctx* c, const char* name);
+void mvo_prof_end(mvo_ctx* c);
+void mvo_prof_collect(mvo_ctx* c);
+struct ProfScope {
+    mvo_ctx* c;
+    ProfScope(mvo_ctx* c_, const char* name) : c(c_) {
+        if (c->prof) mvo_prof_begin(c, name);
+    }
+    ~ProfScope() {
+        if (c->prof) mvo_prof_end(c);
+    }
+};
+
+int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes);
+
+// orb_kernels.hip
+int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int channels, int nlevels);
+int orb_launch_detect(mvo_ctx* ctx);
+int orb_launch_blur(mvo_ctx* ctx, int nlevels);
+int orb_launch_brief(mvo_ctx* ctx, int n);
+// match_kernels.hip
+int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out);
+int match_launch_radius_l1(mvo_ctx* ctx, const uint8_t* d_q, const float* d_qxy, int nq, const uint8_t* d_t,
+                           const float* d_txy, int nt, float max_px, int32_t* d_out);
+// ba_kernels.hip
+int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st);
+
+#endif

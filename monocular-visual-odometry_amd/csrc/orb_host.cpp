@@ -1,0 +1,302 @@
+// csrc/orb_host.cpp -- host half of the ORB path: pyramid geometry, per-level feature quotas, resize
+// coefficient tables, the order-sensitive selections (KeyPointsFilter::retainBest, selectUniformKptsByGrid,
+// runByImageBorder) and the orchestration of the device kernels.
+// These steps stay on the host ON PURPOSE: cv::ORB's retainBest is std::nth_element + std::partition and the
+// reference's selectUniformKptsByGrid (src/geometry/feature_match.cpp:51-84) is first-come, so the *set* of
+// surviving keypoints depends on libstdc++'s element order; <= 10^4 items, ~0.1 ms.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "mvo_internal.h"
+
+namespace {
+
+inline int cv_round(double v) { return (int)std::lrint(v); }
+inline int cv_floor(double v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ORB_Impl::getScale: scaleFactor is a float stored in a double member.
+float layer_scale(const mvo_orb_params& p, int level) { return (float)std::pow((double)p.scale_factor, (double)level); }
+
+void feature_quota(const mvo_orb_params& p, std::vector<int>& q) {
+    q.assign(p.nlevels, 0);
+    float factor = (float)(1.0 / (double)p.scale_factor);
+    float nd = p.nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)p.nlevels));
+    int sum = 0;
+    for (int l = 0; l < p.nlevels - 1; ++l) {
+        q[l] = cv_round(nd);
+        sum += q[l];
+        nd *= factor;
+    }
+    q[p.nlevels - 1] = std::max(p.nfeatures - sum, 0);
+}
+
+// cv::resize(INTER_LINEAR, 8-bit): source offset + two 11-bit coefficients per destination sample
+void fill_resize_tab(ResizeEntry* tab, int ssize, int dsize) {
+    const double scale = 1. / ((double)dsize / ssize);
+    for (int d = 0; d < dsize; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor(f);
+        f -= s;
+        if (s < 0) {
+            f = 0;
+            s = 0;
+        }
+        if (s >= ssize - 1) {
+            f = 0;
+            s = ssize - 1;
+        }
+        tab[d].ofs = s;
+        tab[d].c0 = (int16_t)cv_round((1.f - f) * 2048);
+        tab[d].c1 = (int16_t)cv_round(f * 2048);
+    }
+}
+
+template <class T>
+int free_dev(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    return 0;
+}
+
+// KeyPointsFilter::retainBest
+template <class Key>
+void retain_best(std::vector<DevCandidate>& v, int n, Key key) {
+    if (n >= 0 && (int)v.size() > n) {
+        if (n == 0) {
+            v.clear();
+            return;
+        }
+        std::nth_element(v.begin(), v.begin() + n - 1, v.end(),
+                         [&](const DevCandidate& a, const DevCandidate& b) { return key(a) > key(b); });
+        const float amb = key(v[n - 1]);
+        auto new_end = std::partition(v.begin() + n, v.end(), [&](const DevCandidate& a) { return key(a) >= amb; });
+        v.resize(new_end - v.begin());
+    }
+}
+
+}  // namespace
+
+int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes) {
+    if (ctx->h_pin_cap >= bytes) return MVO_OK;
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    ctx->h_pin = nullptr;
+    ctx->h_pin_cap = 0;
+    size_t cap = round_up(bytes + bytes / 2, 1 << 16);
+    MVO_HIP(hipHostMalloc((void**)&ctx->h_pin, cap, hipHostMallocDefault));
+    ctx->h_pin_cap = cap;
+    return MVO_OK;
+}
+
+// (Re)builds the pyramid geometry + device buffers for a (w, h) image.
+int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
+    if (ctx->img_w == w && ctx->img_h == h && ctx->d_raw) return MVO_OK;
+    const mvo_orb_params& p = ctx->orb;
+    PyrInfo P{};
+    P.nlevels = p.nlevels;
+    size_t off = 256, tab = 0;
+    int cells = 0, tiles = 0, btiles = 0;
+    for (int l = 0; l < p.nlevels; ++l) {
+        LevelInfo& L = P.lv[l];
+        L.scale = layer_scale(p, l);
+        L.w = cv_round(w / L.scale);
+        L.h = cv_round(h / L.scale);
+        if (L.w < 8 || L.h < 8) return mvo_set_err(ctx, MVO_ERR_INVALID, "image too small for the pyramid", hipSuccess);
+        L.stride = (int)round_up(L.w + 2 * MVO_BORDER, 64);
+        L.off = (int)off;
+        off = round_up(off + (size_t)L.stride * (L.h + 2 * MVO_BORDER) + 256, 256);
+        L.tiles_x = (L.w + 63) / 64;
+        L.tiles_y = (L.h + 15) / 16;
+        L.tile_off = tiles;
+        tiles += L.tiles_x * L.tiles_y;
+        L.cell_off = cells;
+        cells += L.h * L.tiles_x;
+        L.btiles_x = L.stride / 64;
+        L.btiles_y = (L.h + 2 * MVO_BORDER + 15) / 16;
+        L.btile_off = btiles;
+        btiles += L.btiles_x * L.btiles_y;
+        L.tab_off = (int)tab;
+        tab += L.w + L.h;
+    }
+    P.n_cells = cells;
+    P.n_tiles = tiles;
+    P.n_btiles = btiles;
+    const size_t bytes = off + 4096;
+    free_dev(ctx->d_raw);
+    free_dev(ctx->d_blur);
+    free_dev(ctx->d_score);
+    free_dev(ctx->d_tabs);
+    free_dev(ctx->d_cell_mask);
+    free_dev(ctx->d_cell_cnt);
+    MVO_HIP(hipMalloc((void**)&ctx->d_raw, bytes));
+    MVO_HIP(hipMalloc((void**)&ctx->d_blur, bytes));
+    MVO_HIP(hipMalloc((void**)&ctx->d_score, bytes));
+    MVO_HIP(hipMemsetAsync(ctx->d_raw, 0, bytes, ctx->stream));
+    MVO_HIP(hipMemsetAsync(ctx->d_blur, 0, bytes, ctx->stream));
+    MVO_HIP(hipMemsetAsync(ctx->d_score, 0, bytes, ctx->stream));
+    MVO_HIP(hipMalloc((void**)&ctx->d_tabs, tab * sizeof(ResizeEntry)));
+    MVO_HIP(hipMalloc((void**)&ctx->d_cell_mask, (size_t)cells * 8));
+    MVO_HIP(hipMalloc((void**)&ctx->d_cell_cnt, (size_t)cells * 4));
+    std::vector<ResizeEntry> tabs(tab);
+    for (int l = 1; l < p.nlevels; ++l) {
+        fill_resize_tab(&tabs[P.lv[l].tab_off], P.lv[l - 1].w, P.lv[l].w);
+        fill_resize_tab(&tabs[P.lv[l].tab_off + P.lv[l].w], P.lv[l - 1].h, P.lv[l].h);
+    }
+    MVO_HIP(hipMemcpy(ctx->d_tabs, tabs.data(), tab * sizeof(ResizeEntry), hipMemcpyHostToDevice));
+    if (!ctx->d_hdr) {
+        ctx->cand_cap = 1 << 16;
+        void* blk = nullptr;
+        MVO_HIP(hipMalloc(&blk, sizeof(CandHeader) + (size_t)ctx->cand_cap * sizeof(DevCandidate)));
+        ctx->d_hdr = (CandHeader*)blk;
+        ctx->d_cand = (DevCandidate*)((char*)blk + sizeof(CandHeader));
+    }
+    ctx->pyr = P;
+    ctx->pyr_bytes = bytes;
+    ctx->img_w = w;
+    ctx->img_h = h;
+    ctx->pyr_valid = ctx->blur_valid = false;
+    feature_quota(p, ctx->quota);
+    return MVO_OK;
+}
+
+static int ensure_kp_cap(mvo_ctx* ctx, int n) {
+    if (ctx->kp_cap >= n) return MVO_OK;
+    free_dev(ctx->d_kp);
+    free_dev(ctx->d_desc);
+    int cap = std::max(4096, n + n / 2);
+    MVO_HIP(hipMalloc((void**)&ctx->d_kp, (size_t)cap * sizeof(DevDescKp)));
+    MVO_HIP(hipMalloc((void**)&ctx->d_desc, (size_t)cap * 32));
+    ctx->kp_cap = cap;
+    return MVO_OK;
+}
+
+// geometry::selectUniformKptsByGrid (feature_match.cpp:51-84)
+int orb_grid_select(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int image_rows, int image_cols) {
+    const mvo_orb_params& p = ctx->orb;
+    if (ctx->grid_rows == 0) {  // latched from the first image (feature_match.cpp:59-62)
+        ctx->grid_rows = image_rows / p.grid_size;
+        ctx->grid_cols = image_cols / p.grid_size;
+    }
+    const int rows = ctx->grid_rows, cols = ctx->grid_cols;
+    std::vector<int> grid((size_t)rows * cols, 0);
+    std::vector<mvo_keypoint> tmp;
+    int cnt = 0;
+    for (const mvo_keypoint& k : kps) {
+        int row = ((int)k.y) / p.grid_size, col = ((int)k.x) / p.grid_size;
+        if (row < 0 || row >= rows || col < 0 || col >= cols)
+            return mvo_set_err(ctx, MVO_ERR_INVALID, "keypoint outside the latched grid", hipSuccess);
+        int& g = grid[(size_t)row * cols + col];
+        if (g < p.grid_max_per_cell) {
+            tmp.push_back(k);
+            g++;
+            cnt++;
+            if (cnt > p.max_keypoints) break;  // feature_match.cpp:77: yields max+1 keypoints
+        }
+    }
+    kps.swap(tmp);
+    return MVO_OK;
+}
+
+// cv::ORB::detect on an image already in device memory; leaves the raw pyramid (and a speculatively blurred
+// copy) cached in the ctx.
+int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int channels,
+                      std::vector<mvo_keypoint>& out) {
+    int r = orb_setup_geometry(ctx, w, h);
+    if (r) return r;
+    const PyrInfo& P = ctx->pyr;
+    ctx->pyr_valid = ctx->blur_valid = false;
+    if ((r = orb_launch_pyramid(ctx, d_img, stride, channels, P.nlevels))) return r;
+    if ((r = orb_launch_detect(ctx))) return r;
+    const int chunk = std::min(ctx->cand_cap, 16384);
+    const size_t first = sizeof(CandHeader) + (size_t)chunk * sizeof(DevCandidate);
+    if ((r = mvo_ensure_pinned(ctx, sizeof(CandHeader) + (size_t)ctx->cand_cap * sizeof(DevCandidate)))) return r;
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_hdr, first, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
+    // the blur does not depend on the selection: it runs while the host selects
+    if ((r = orb_launch_blur(ctx, P.nlevels))) return r;
+    MVO_HIP(hipEventSynchronize(ctx->ev));
+    const CandHeader* hdr = (const CandHeader*)ctx->h_pin;
+    const int n_total = hdr->n_total;
+    if (n_total > ctx->cand_cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "candidate buffer overflow", hipSuccess);
+    if (n_total > chunk) {
+        MVO_HIP(hipMemcpyAsync(ctx->h_pin + first, (const char*)ctx->d_hdr + first,
+                               (size_t)(n_total - chunk) * sizeof(DevCandidate), hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    const DevCandidate* cand = (const DevCandidate*)(ctx->h_pin + sizeof(CandHeader));
+    out.clear();
+    std::vector<DevCandidate> lv;
+    for (int l = 0; l < P.nlevels; ++l) {
+        lv.assign(cand + hdr->level_start[l], cand + hdr->level_start[l + 1]);
+        // FAST score first (keep 2x), then Harris (cv::ORB computeKeyPoints)
+        retain_best(lv, 2 * ctx->quota[l], [](const DevCandidate& a) { return (float)(a.level_score & 0xffff); });
+        retain_best(lv, ctx->quota[l], [](const DevCandidate& a) { return a.harris; });
+        const float sf = P.lv[l].scale;
+        for (const DevCandidate& a : lv) {
+            mvo_keypoint k;
+            k.x = (float)a.x * sf;
+            k.y = (float)a.y * sf;
+            k.size = 31 * sf;
+            k.angle = a.angle;
+            k.response = a.harris;
+            k.octave = l;
+            k.class_id = -1;
+            out.push_back(k);
+        }
+    }
+    ctx->pyr_valid = true;
+    ctx->blur_valid = true;
+    ctx->pyr_levels_built = P.nlevels;
+    return MVO_OK;
+}
+
+// cv::ORB::compute given keypoints; the blurred pyramid must be valid for levels < nlevels_needed.
+int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int h, uint8_t* desc_host) {
+    const PyrInfo& P = ctx->pyr;
+    const int n = (int)kps.size();
+    if (n == 0) return MVO_OK;
+    int r = ensure_kp_cap(ctx, n);
+    if (r) return r;
+    if ((r = mvo_ensure_pinned(ctx, (size_t)n * (sizeof(DevDescKp) + 32)))) return r;
+    DevDescKp* hk = (DevDescKp*)ctx->h_pin;
+    for (int i = 0; i < n; ++i) {
+        const mvo_keypoint& k = kps[i];
+        const float scale = 1.f / P.lv[k.octave].scale;
+        const float angle = k.angle * (float)(M_PI / 180.f);
+        hk[i].cx = (int16_t)cv_round(k.x * scale);
+        hk[i].cy = (int16_t)cv_round(k.y * scale);
+        hk[i].level = k.octave;
+        hk[i].a = (float)std::cos((double)angle);
+        hk[i].b = (float)std::sin((double)angle);
+        const LevelInfo& L = P.lv[k.octave];
+        // the tap window must stay inside the 32-px frame
+        if (hk[i].cx < -12 || hk[i].cx > L.w + 11 || hk[i].cy < -12 || hk[i].cy > L.h + 11)
+            return mvo_set_err(ctx, MVO_ERR_INVALID, "keypoint outside its pyramid level", hipSuccess);
+    }
+    MVO_HIP(hipMemcpyAsync(ctx->d_kp, hk, (size_t)n * sizeof(DevDescKp), hipMemcpyHostToDevice, ctx->stream));
+    if ((r = orb_launch_brief(ctx, n))) return r;
+    if (desc_host) {
+        uint8_t* hd = ctx->h_pin + (size_t)n * sizeof(DevDescKp);
+        MVO_HIP(hipMemcpyAsync(hd, ctx->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(desc_host, hd, (size_t)n * 32);
+    }
+    (void)w;
+    (void)h;
+    return MVO_OK;
+}
+
+// KeyPointsFilter::runByImageBorder(keypoints, image.size(), 31): Point2f -> Point rounds half-to-even
+void orb_border_filter(std::vector<mvo_keypoint>& kps, int w, int h) {
+    std::vector<mvo_keypoint> keep;
+    keep.reserve(kps.size());
+    for (const mvo_keypoint& k : kps) {
+        int xi = cv_round(k.x), yi = cv_round(k.y);
+        if (xi >= 31 && xi < w - 31 && yi >= 31 && yi < h - 31) keep.push_back(k);
+    }
+    kps.swap(keep);
+}

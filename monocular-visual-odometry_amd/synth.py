@@ -1,0 +1,159 @@
+"""Deterministic synthetic workloads for the VO hot path.
+
+* S640 / S1242 image sequences: windows of one random world texture under a smooth planar camera path
+  (the reference's datasets -- data/dataset_images_matlab, TUM fr1_desk -- are not in the repo and there
+  is no network), replicated to BGR like cv::imread (run_vo.cpp:114).
+* matcher micro-inputs (uniform / perturbed copy / tie-heavy).
+* BA5 / BA10 sliding-window problems shaped like callBundleAdjustment_ builds them (vo.cpp:384-478).
+"""
+import numpy as np
+
+FR1_K = dict(fx=517.3, fy=516.5, cx=325.1, cy=249.7)       # config/config.yaml:40-43
+KITTI_K = dict(fx=718.856, fy=718.856, cx=607.19, cy=185.22)
+
+
+def world_texture(seed=1234, size=2048, n_rect=4000):
+    from scipy import ndimage
+    rng = np.random.RandomState(seed)
+    tex = np.zeros((size, size), np.float64)
+    for octave, sigma in enumerate((32.0, 12.0, 4.0, 1.5)):
+        n = ndimage.gaussian_filter(rng.uniform(-1, 1, (size, size)), sigma, mode="wrap")
+        tex += n / n.std() * (40.0 / (1 + 0.5 * octave))
+    tex += 128
+    for _ in range(n_rect):
+        w, h = rng.randint(6, 60, 2)
+        x, y = rng.randint(0, size - w), rng.randint(0, size - h)
+        tex[y:y + h, x:x + w] = rng.uniform(20, 235)
+    return np.clip(tex, 0, 255)
+
+
+class Sequence:
+    """frames(i) -> HxWx3 uint8 (BGR, the three channels equal)."""
+
+    def __init__(self, width=640, height=480, n_frames=150, seed=1234, tex_size=2048):
+        self.w, self.h, self.n = width, height, n_frames
+        self.seed = seed
+        self.tex = world_texture(seed, tex_size)
+        self.tex_size = tex_size
+
+    def frame(self, i, channels=3):
+        from scipy import ndimage
+        rng = np.random.RandomState(self.seed * 1000003 + i)
+        t = i / max(self.n - 1, 1)
+        # smooth planar path: ~4 px/frame translation, 0.2 deg/frame roll, +-5 % scale
+        cx = self.tex_size / 2 + 4.0 * i * np.cos(0.3) + 60 * np.sin(2 * np.pi * t)
+        cy = self.tex_size / 2 + 4.0 * i * np.sin(0.3) * 0.5 + 40 * np.sin(4 * np.pi * t)
+        ang = np.deg2rad(0.2 * i)
+        sc = 1.0 + 0.05 * np.sin(2 * np.pi * t)
+        ys, xs = np.mgrid[0:self.h, 0:self.w].astype(np.float64)
+        xs -= self.w / 2
+        ys -= self.h / 2
+        u = cx + sc * (np.cos(ang) * xs - np.sin(ang) * ys)
+        v = cy + sc * (np.sin(ang) * xs + np.cos(ang) * ys)
+        img = ndimage.map_coordinates(self.tex, [v, u], order=1, mode="reflect")
+        img = img + rng.normal(0, 2.0, img.shape)
+        g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        if channels == 1:
+            return g
+        return np.repeat(g[:, :, None], 3, axis=2)
+
+
+def small_test_image(seed=0, w=160, h=120, channels=3):
+    """Corner-rich small image for fast CPU tests."""
+    rng = np.random.RandomState(seed)
+    img = np.full((h, w), 128.0)
+    from scipy import ndimage
+    img += ndimage.gaussian_filter(rng.uniform(-1, 1, (h, w)), 3.0) * 200
+    for _ in range(max(8, w * h // 500)):
+        rw, rh = rng.randint(4, 24, 2)
+        x, y = rng.randint(0, w - rw), rng.randint(0, h - rh)
+        img[y:y + rh, x:x + rw] = rng.uniform(10, 245)
+    img += rng.normal(0, 1.5, img.shape)
+    g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    if channels == 1:
+        return g
+    out = np.repeat(g[:, :, None], 3, axis=2)
+    # make the channels differ so that BGR2GRAY weights are exercised
+    out[:, :, 0] = np.clip(out[:, :, 0].astype(int) + rng.randint(-20, 20, (h, w)), 0, 255)
+    out[:, :, 2] = np.clip(out[:, :, 2].astype(int) + rng.randint(-20, 20, (h, w)), 0, 255)
+    return np.ascontiguousarray(out)
+
+
+# ---------------------------------------------------------------- matcher micro-inputs (seed 42)
+def match_inputs(kind, nq=2000, nt=2000, seed=42):
+    rng = np.random.RandomState(seed)
+    if kind == "uniform":
+        return rng.randint(0, 256, (nq, 32)).astype(np.uint8), rng.randint(0, 256, (nt, 32)).astype(np.uint8)
+    if kind == "perturbed":
+        q = rng.randint(0, 256, (nq, 32)).astype(np.uint8)
+        n_copy = min(nq, max(nt - nt // 4, 1))
+        perm = rng.permutation(nq)[:n_copy]
+        bits = np.unpackbits(q[perm], axis=1)
+        flips = rng.uniform(size=bits.shape) < 0.08
+        t = np.packbits(bits ^ flips, axis=1)
+        distract = rng.randint(0, 256, (nt - n_copy, 32)).astype(np.uint8)
+        t = np.concatenate([t, distract])[rng.permutation(nt)]
+        return q, np.ascontiguousarray(t)
+    if kind == "ties":
+        base = rng.randint(0, 256, (64, 32)).astype(np.uint8)
+        return base[rng.randint(0, 64, nq)].copy(), base[rng.randint(0, 64, nt)].copy()
+    raise ValueError(kind)
+
+
+# ---------------------------------------------------------------- bundle-adjustment problems
+def _rot(axis, ang):
+    axis = np.asarray(axis, float)
+    axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def ba_problem(n_poses=5, n_points=2000, seed=7, width=640, height=480, K=FR1_K, pix_noise=0.5,
+               outlier_frac=0.02, pose_rot_noise=0.01, pose_trans_noise=0.01, point_noise=0.01,
+               f32_storage=True):
+    """Returns dict(poses_gt, poses0 [F,4,4] cam->world, points_gt, points0, edge_pose, edge_point,
+    edge_uv, focal, cx, cy).  Frames are listed newest->oldest like vo.cpp:417-421."""
+    rng = np.random.RandomState(seed)
+    f, cx, cy = K["fx"], K["cx"], K["cy"]
+    poses_gt = []
+    for i in range(n_poses):
+        yaw = np.deg2rad(3.0) * i / max(n_poses - 1, 1)
+        R_wc = _rot([0, 1, 0], yaw)
+        t_wc = np.array([0.05 * i, 0.005 * np.sin(i), 0.01 * i])
+        T = np.eye(4)
+        T[:3, :3] = R_wc
+        T[:3, 3] = t_wc
+        poses_gt.append(T)
+    poses_gt = np.array(poses_gt)
+    # points uniform in the first camera's frustum, depth 0.5 .. 3 m
+    z = rng.uniform(0.5, 3.0, n_points)
+    u = rng.uniform(0.05 * width, 0.95 * width, n_points)
+    v = rng.uniform(0.05 * height, 0.95 * height, n_points)
+    pts = np.stack([(u - cx) / f * z, (v - cy) / f * z, z], 1)
+    ep, el, uv = [], [], []
+    for i in range(n_poses):
+        Tcw = np.linalg.inv(poses_gt[i])
+        pc = pts @ Tcw[:3, :3].T + Tcw[:3, 3]
+        pu = f * pc[:, 0] / pc[:, 2] + cx
+        pv = f * pc[:, 1] / pc[:, 2] + cy
+        vis = (pc[:, 2] > 0.1) & (pu >= 0) & (pu < width) & (pv >= 0) & (pv < height)
+        ids = np.nonzero(vis)[0]
+        ids = ids[rng.permutation(len(ids))]  # unordered_map iteration order is arbitrary
+        nz = rng.normal(0, pix_noise, (len(ids), 2))
+        out = rng.uniform(size=len(ids)) < outlier_frac
+        nz[out] += rng.uniform(-20, 20, (int(out.sum()), 2))
+        ep.append(np.full(len(ids), i, np.int32))
+        el.append(ids.astype(np.int32))
+        uv.append(np.stack([pu[ids], pv[ids]], 1) + nz)
+    ep, el, uv = np.concatenate(ep), np.concatenate(el), np.concatenate(uv)
+    poses0 = poses_gt.copy()
+    for i in range(n_poses):
+        dR = _rot(rng.normal(size=3), rng.normal(0, pose_rot_noise))
+        poses0[i, :3, :3] = dR @ poses0[i, :3, :3]
+        poses0[i, :3, 3] += rng.normal(0, pose_trans_noise, 3)
+    points0 = pts + rng.normal(0, point_noise, pts.shape)
+    if f32_storage:  # cv::Point2f / cv::Point3f storage in Frame / MapPoint
+        uv = uv.astype(np.float32).astype(np.float64)
+        points0 = points0.astype(np.float32).astype(np.float64)
+    return dict(poses_gt=poses_gt, poses0=poses0, points_gt=pts, points0=points0, edge_pose=ep,
+                edge_point=el, edge_uv=uv, focal=f, cx=cx, cy=cy)

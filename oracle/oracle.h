@@ -1,0 +1,138 @@
+/* oracle/oracle.h -- C interface of the CPU ORACLE.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This directory is a scalar, dependency-free CPU restatement of the
+ * reference's per-frame hot path (ORB extract + grid sampling, Hamming / L1 matching + filters,
+ * sliding-window bundle adjustment).  Only tests/, __graft_entry__.smoke() and the cpu_baseline leg
+ * of bench.py may load it -- as the checker, never as the thing measured or shipped.  The product
+ * (monocular-visual-odometry_amd/) never includes, links or calls anything in here.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in OpenCV (cv::ORB, cv::BFMatcher,
+ * cv::FlannBasedMatcher) and g2o, neither of which is vendored under /root/reference nor
+ * installed in this image, and the reference's own tests hold no golden vectors for it
+ * (SURVEY.md section 4 / 8c).  The oracle therefore restates the published upstream algorithms
+ *  and is anchored on the reference's call sites:
+ *   src/geometry/feature_match.cpp:11-260, include/my_slam/vo/frame.h:73-86,
+ *   src/optimization/g2o_ba.cpp:172-317, src/vo/vo.cpp:384-478, config/config.yaml:63-123.
+ * It is checked against analytic known-answer cases in tests/ (tests/golden/), not against
+ * outputs of OpenCV/g2o themselves.
+ */
+#ifndef MVO_ORACLE_H
+#define MVO_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id). */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+
+/* Parameters the reference latches from config.yaml in function-local statics
+ * (feature_match.cpp:16-19, 42-45, 56-59). */
+typedef struct {
+    int32_t nfeatures;         /* number_of_keypoints_to_extract (8000) */
+    float scale_factor;        /* scale_factor (1.2) -- ORB::create takes a float */
+    int32_t nlevels;           /* level_pyramid (4) */
+    int32_t fast_threshold;    /* score_threshold (20) */
+    int32_t max_keypoints;     /* max_number_of_keypoints (1500) */
+    int32_t grid_size;         /* kpts_uniform_selection_grid_size (16) */
+    int32_t grid_max_per_cell; /* kpts_uniform_selection_max_pts_per_grid (8) */
+} orc_orb_params;
+
+/* One FAST+NMS survivor inside the 31-px border of a pyramid level, in canonical order
+ * (level-major, then row-major), with both scores and the IC angle attached. */
+typedef struct {
+    int16_t x, y;       /* level coordinates */
+    int32_t level;
+    int32_t fast_score; /* cornerScore<16> */
+    float harris;       /* HarrisResponses(blockSize 7, k 0.04) */
+    float angle;        /* IC_Angle in degrees via the fastAtan2 polynomial */
+} orc_candidate;
+
+/* --- ORB stages (each returns a count or a negative error) --------------------------------- */
+int orc_orb_level_size(int w, int h, const orc_orb_params* p, int level, int* lw, int* lh, float* scale);
+int orc_orb_feature_quota(const orc_orb_params* p, int32_t* quota /* nlevels */);
+/* Writes level `level` of the gray pyramid WITH its 32-px BORDER_REFLECT_101 frame:
+ * out must hold (lh+64)*(lw+64) bytes, row stride lw+64.  blurred!=0 -> interior is the 7x7
+ * sigma=2 fixed-point Gaussian, frame left unblurred (cv::ORB::compute blurs the level ROI in place). */
+int orc_orb_pyramid_level(const uint8_t* img, int w, int h, int stride, int channels,
+                          const orc_orb_params* p, int level, int blurred, uint8_t* out);
+int orc_orb_candidates(const uint8_t* img, int w, int h, int stride, int channels,
+                       const orc_orb_params* p, orc_candidate* out, int cap);
+/* geometry::calcKeyPoints (feature_match.cpp:11-36): ORB detect + selectUniformKptsByGrid.
+ * grid_rows/grid_cols <= 0 -> derive from (h, w) as the first call of the reference does. */
+int orc_calc_keypoints(const uint8_t* img, int w, int h, int stride, int channels,
+                       const orc_orb_params* p, int grid_rows, int grid_cols,
+                       orc_keypoint* out, int cap);
+/* Only cv::ORB::detect (no grid sampling). */
+int orc_orb_detect(const uint8_t* img, int w, int h, int stride, int channels,
+                   const orc_orb_params* p, orc_keypoint* out, int cap);
+/* geometry::selectUniformKptsByGrid (feature_match.cpp:51-84); in place, returns new count. */
+int orc_select_uniform_kpts_by_grid(orc_keypoint* kps, int n, int grid_rows, int grid_cols,
+                                    const orc_orb_params* p);
+/* geometry::calcDescriptors (feature_match.cpp:38-49): may drop keypoints (in place);
+ * desc gets n_out*32 bytes; rgb (optional) n_out*3 bytes as frame.h:80-85 computes them. */
+int orc_calc_descriptors(const uint8_t* img, int w, int h, int stride, int channels,
+                         const orc_orb_params* p, orc_keypoint* kps, int n, uint8_t* desc,
+                         uint8_t* rgb);
+
+/* --- matching ------------------------------------------------------------------------------ */
+/* cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) (feature_match.cpp:203-208): idx/dist are nq x 2,
+ * missing neighbours are (-1, INT32_MAX). */
+int orc_match_knn2(const uint8_t* q, int nq, const uint8_t* t, int nt, int32_t* idx, int32_t* dist);
+/* geometry::matchByRadiusAndBruteForce (feature_match.cpp:86-124): per query the first minimum of
+ * the byte-L1 sum among trains within the pixel radius; idx -1 if none. sum is 32x the reference's
+ * mean-abs-difference. */
+int orc_match_radius_l1(const uint8_t* q, const float* qxy, int nq, const uint8_t* t,
+                        const float* txy, int nt, float max_px, int32_t* idx, int32_t* sum);
+
+typedef struct {
+    int32_t queryIdx, trainIdx, imgIdx;
+    float distance;
+} orc_dmatch; /* cv::DMatch */
+
+/* geometry::matchFeatures (feature_match.cpp:126-239). method 1 uses the exact 1-NN in place of
+ * FLANN-LSH (documented deviation). ratios are passed as the reference latches
+ * them (get<int> -> 0.8 becomes 1; pass 0.8 for the intended behaviour). Returns match count. */
+int orc_match_features(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int method,
+                       double xiang_gao_ratio, double lowe_ratio, const float* xy1,
+                       const float* xy2, float max_px, orc_dmatch* out, int cap);
+/* geometry::removeDuplicatedMatches (feature_match.cpp:241-260), in place. */
+int orc_remove_duplicated_matches(orc_dmatch* m, int n);
+
+/* --- bundle adjustment --------------------------------------------------------------------- */
+typedef struct {
+    int32_t n_poses, n_points, n_edges;
+    double* pose_T_w_c;        /* n_poses x 16, row-major 4x4 cam->world (Frame::T_w_c_), in/out */
+    double* points;            /* n_points x 3 world xyz, in/out (the caller rounds to f32) */
+    const int32_t* edge_pose;  /* n_edges */
+    const int32_t* edge_point; /* n_edges */
+    const double* edge_uv;     /* n_edges x 2 */
+    double focal, cx, cy;      /* g2o::CameraParameters(K(0,0), (K(0,2),K(1,2)), 0): fy ignored */
+    double info[4];            /* 2x2 information matrix */
+    double huber_delta;        /* RobustKernelHuber default 1.0 */
+    int32_t fix_points;        /* is_fix_map_pts */
+    const uint8_t* pose_fixed; /* optional n_poses flags (reference: none fixed); may be NULL */
+    int32_t max_iterations;    /* 50 */
+} orc_ba_problem;
+
+typedef struct {
+    int32_t iterations;  /* outer LM iterations executed */
+    int32_t trials;      /* total linear solves */
+    int32_t terminated;  /* 1 if g2o's Terminate condition ended the run early */
+    double chi2_initial, chi2_final, lambda_final;
+} orc_ba_stats;
+
+/* optimization::bundleAdjustment (g2o_ba.cpp:172-317). */
+int orc_bundle_adjustment(orc_ba_problem* prob, orc_ba_stats* stats);
+/* One linearisation at the current state: dense H (n x n, n = 6*free poses + 3*free points),
+ * b, robust chi2.  For known-answer tests of the Jacobians. */
+int orc_ba_linearize(const orc_ba_problem* prob, double* H, double* b, double* chi2, int ncap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,243 @@
+"""ctypes wrapper around the CPU ORACLE (oracle/_build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY (see oracle/oracle.h): imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "liboracle.so")
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+class OrbParams(C.Structure):
+    _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
+                ("fast_threshold", C.c_int32), ("max_keypoints", C.c_int32), ("grid_size", C.c_int32),
+                ("grid_max_per_cell", C.c_int32)]
+
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                           ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CANDIDATE_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("level", "<i4"), ("fast_score", "<i4"),
+                            ("harris", "<f4"), ("angle", "<f4")])
+DMATCH_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+
+
+class BaProblem(C.Structure):
+    _fields_ = [("n_poses", C.c_int32), ("n_points", C.c_int32), ("n_edges", C.c_int32),
+                ("pose_T_w_c", C.c_void_p), ("points", C.c_void_p), ("edge_pose", C.c_void_p),
+                ("edge_point", C.c_void_p), ("edge_uv", C.c_void_p), ("focal", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("info", C.c_double * 4),
+                ("huber_delta", C.c_double), ("fix_points", C.c_int32), ("pose_fixed", C.c_void_p),
+                ("max_iterations", C.c_int32)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def default_params(**kw):
+    """config/config.yaml:65-69, 94-95 defaults."""
+    p = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500,
+             grid_size=16, grid_max_per_cell=8)
+    p.update(kw)
+    return OrbParams(**p)
+
+
+def _img_args(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.ndim == 2:
+        h, w = img.shape
+        ch = 1
+    else:
+        h, w, ch = img.shape
+    return img, img.ctypes.data_as(C.c_void_p), w, h, w * ch, ch
+
+
+def level_size(w, h, p, level):
+    lw, lh, sc = C.c_int(), C.c_int(), C.c_float()
+    lib().orc_orb_level_size(w, h, C.byref(p), level, C.byref(lw), C.byref(lh), C.byref(sc))
+    return lw.value, lh.value, sc.value
+
+
+def feature_quota(p):
+    q = (C.c_int32 * p.nlevels)()
+    lib().orc_orb_feature_quota(C.byref(p), q)
+    return list(q)
+
+
+def pyramid_level(img, p, level, blurred=False):
+    img, ptr, w, h, stride, ch = _img_args(img)
+    lw, lh, _ = level_size(w, h, p, level)
+    out = np.zeros((lh + 64, lw + 64), np.uint8)
+    r = lib().orc_orb_pyramid_level(ptr, w, h, stride, ch, C.byref(p), level, int(blurred),
+                                    out.ctypes.data_as(C.c_void_p))
+    assert r == out.size, r
+    return out
+
+
+def candidates(img, p, cap=1 << 18):
+    img, ptr, w, h, stride, ch = _img_args(img)
+    out = np.zeros(cap, CANDIDATE_DTYPE)
+    n = lib().orc_orb_candidates(ptr, w, h, stride, ch, C.byref(p), out.ctypes.data_as(C.c_void_p), cap)
+    assert n >= 0, n
+    return out[:n].copy()
+
+
+def orb_detect(img, p, cap=1 << 18):
+    img, ptr, w, h, stride, ch = _img_args(img)
+    out = np.zeros(cap, KEYPOINT_DTYPE)
+    n = lib().orc_orb_detect(ptr, w, h, stride, ch, C.byref(p), out.ctypes.data_as(C.c_void_p), cap)
+    assert n >= 0, n
+    return out[:n].copy()
+
+
+def calc_keypoints(img, p, grid_rows=0, grid_cols=0, cap=1 << 18):
+    img, ptr, w, h, stride, ch = _img_args(img)
+    out = np.zeros(cap, KEYPOINT_DTYPE)
+    n = lib().orc_calc_keypoints(ptr, w, h, stride, ch, C.byref(p), grid_rows, grid_cols,
+                                 out.ctypes.data_as(C.c_void_p), cap)
+    assert n >= 0, n
+    return out[:n].copy()
+
+
+def select_uniform_kpts_by_grid(kps, rows, cols, p):
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+    n = lib().orc_select_uniform_kpts_by_grid(kps.ctypes.data_as(C.c_void_p), len(kps), rows, cols, C.byref(p))
+    assert n >= 0, n
+    return kps[:n].copy()
+
+
+def calc_descriptors(img, kps, p, want_rgb=False):
+    img, ptr, w, h, stride, ch = _img_args(img)
+    kps = np.ascontiguousarray(kps, KEYPOINT_DTYPE).copy()
+    desc = np.zeros((max(len(kps), 1), 32), np.uint8)
+    rgb = np.zeros((max(len(kps), 1), 3), np.uint8)
+    n = lib().orc_calc_descriptors(ptr, w, h, stride, ch, C.byref(p), kps.ctypes.data_as(C.c_void_p),
+                                   len(kps), desc.ctypes.data_as(C.c_void_p),
+                                   rgb.ctypes.data_as(C.c_void_p) if want_rgb else None)
+    assert n >= 0, n
+    if want_rgb:
+        return kps[:n].copy(), desc[:n].copy(), rgb[:n].copy()
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def match_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(q), 2), np.int32)
+    dist = np.zeros((len(q), 2), np.int32)
+    lib().orc_match_knn2(q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t),
+                         idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p))
+    return idx, dist
+
+
+def match_radius_l1(q, qxy, t, txy, max_px):
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    qxy = np.ascontiguousarray(qxy, np.float32).reshape(-1, 2)
+    txy = np.ascontiguousarray(txy, np.float32).reshape(-1, 2)
+    idx = np.zeros(len(q), np.int32)
+    s = np.zeros(len(q), np.int32)
+    lib().orc_match_radius_l1(q.ctypes.data_as(C.c_void_p), qxy.ctypes.data_as(C.c_void_p), len(q),
+                              t.ctypes.data_as(C.c_void_p), txy.ctypes.data_as(C.c_void_p), len(t),
+                              C.c_float(max_px), idx.ctypes.data_as(C.c_void_p), s.ctypes.data_as(C.c_void_p))
+    return idx, s
+
+
+def match_features(d1, d2, method=1, xiang_gao_ratio=2.0, lowe_ratio=1.0, xy1=None, xy2=None, max_px=0.0):
+    d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+    d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+    out = np.zeros(max(len(d1), 1), DMATCH_DTYPE)
+    p1 = p2 = None
+    if xy1 is not None:
+        xy1 = np.ascontiguousarray(xy1, np.float32)
+        xy2 = np.ascontiguousarray(xy2, np.float32)
+        p1, p2 = xy1.ctypes.data_as(C.c_void_p), xy2.ctypes.data_as(C.c_void_p)
+    n = lib().orc_match_features(d1.ctypes.data_as(C.c_void_p), len(d1), d2.ctypes.data_as(C.c_void_p), len(d2),
+                                 method, C.c_double(xiang_gao_ratio), C.c_double(lowe_ratio), p1, p2,
+                                 C.c_float(max_px), out.ctypes.data_as(C.c_void_p), len(out))
+    if n < 0:
+        raise RuntimeError("feature_match.cpp::matchFeatures: wrong method index.")
+    return out[:n].copy()
+
+
+def remove_duplicated_matches(m):
+    m = np.ascontiguousarray(m, DMATCH_DTYPE).copy()
+    n = lib().orc_remove_duplicated_matches(m.ctypes.data_as(C.c_void_p), len(m))
+    return m[:n].copy()
+
+
+def _ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
+                fix_points, pose_fixed, max_iterations):
+    keep = dict(
+        poses=np.ascontiguousarray(poses, np.float64).reshape(-1, 16).copy(),
+        points=np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy(),
+        ep=np.ascontiguousarray(edge_pose, np.int32), el=np.ascontiguousarray(edge_point, np.int32),
+        uv=np.ascontiguousarray(edge_uv, np.float64).reshape(-1, 2),
+        pf=None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8))
+    pr = BaProblem()
+    pr.n_poses, pr.n_points, pr.n_edges = len(keep["poses"]), len(keep["points"]), len(keep["ep"])
+    pr.pose_T_w_c = keep["poses"].ctypes.data
+    pr.points = keep["points"].ctypes.data
+    pr.edge_pose = keep["ep"].ctypes.data
+    pr.edge_point = keep["el"].ctypes.data
+    pr.edge_uv = keep["uv"].ctypes.data
+    pr.focal, pr.cx, pr.cy = focal, cx, cy
+    pr.info = (C.c_double * 4)(*np.asarray(info, np.float64).ravel())
+    pr.huber_delta = huber_delta
+    pr.fix_points = int(fix_points)
+    pr.pose_fixed = None if keep["pf"] is None else keep["pf"].ctypes.data
+    pr.max_iterations = max_iterations
+    return pr, keep
+
+
+def bundle_adjustment(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info=(1, 0, 0, 1),
+                      huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50):
+    """Returns (poses_T_w_c [F,4,4] f64, points [L,3] f64, stats dict)."""
+    pr, keep = _ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
+                           fix_points, pose_fixed, max_iterations)
+    st = BaStats()
+    r = lib().orc_bundle_adjustment(C.byref(pr), C.byref(st))
+    if r != 0:
+        raise RuntimeError("oracle BA failed: %d" % r)
+    stats = {k: getattr(st, k) for k, _ in BaStats._fields_}
+    return keep["poses"].reshape(-1, 4, 4), keep["points"], stats
+
+
+def ba_linearize(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info=(1, 0, 0, 1),
+                 huber_delta=1.0, fix_points=False, pose_fixed=None):
+    pr, keep = _ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
+                           fix_points, pose_fixed, 0)
+    nf = pr.n_poses if pose_fixed is None else int(pr.n_poses - np.count_nonzero(keep["pf"]))
+    n = 6 * nf + (0 if fix_points else 3 * pr.n_points)
+    H = np.zeros((n, n))
+    b = np.zeros(n)
+    chi = C.c_double()
+    r = lib().orc_ba_linearize(C.byref(pr), H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                               C.byref(chi), n)
+    assert r == n, (r, n)
+    return H, b, chi.value
