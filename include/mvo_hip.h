@@ -79,7 +79,7 @@ int mvo_calc_descriptors(mvo_ctx* ctx, const uint8_t* image, int width, int heig
                          int channels, int reuse_pyramid, mvo_keypoint* kps, int* n, uint8_t* desc,
                          uint8_t* rgb);
 /* Descriptors stay on the device as well (d_desc_out receives a device pointer owned by the ctx, valid
- * until the next extraction on this ctx) so the matcher can consume them without a PCIe round trip. */
+ * until the extraction after the next one on this ctx: two buffers alternate) so the matcher can consume them without a PCIe round trip. */
 int mvo_calc_descriptors_dev(mvo_ctx* ctx, mvo_keypoint* kps, int* n, uint8_t* desc,
                              const void** d_desc_out);
 /* geometry::selectUniformKptsByGrid (feature_match.cpp:51-84), host-side, in place. grid dims are the
@@ -109,6 +109,10 @@ int mvo_match_radius_l1(mvo_ctx* ctx, const uint8_t* q, const float* qxy, int nq
 int mvo_match_features(mvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int method,
                        double xiang_gao_ratio, double lowe_ratio, const float* xy1, const float* xy2,
                        float max_px, mvo_dmatch* out, int cap, int* n);
+/* matchFeatures methods 1 / 2 with both descriptor sets already in HBM (device pointers, e.g. the ones
+ * mvo_calc_descriptors_dev returns for frame i-1 and frame i). */
+int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d_d2, int n2, int method,
+                           double xiang_gao_ratio, double lowe_ratio, mvo_dmatch* out, int cap, int* n);
 /* geometry::removeDuplicatedMatches (feature_match.cpp:241-260), host-side, in place. */
 int mvo_remove_duplicated_matches(mvo_dmatch* m, int* n);
 
@@ -139,6 +143,16 @@ typedef struct {
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317; caller VisualOdometry::callBundleAdjustment_,
  * src/vo/vo.cpp:458-462). */
 int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
+
+/* The same solve with the window resident in HBM: mvo_ba_prepare uploads the graph once (inputs + the
+ * pose / point adjacency the kernels need), mvo_ba_solve_resident runs one full optimize(50) from the
+ * resident initial state (asynchronous on the ctx stream; may be repeated), mvo_ba_fetch copies the
+ * refined poses (n_poses x 16) / points (n_points x 3, untouched when fix_points) / stats back. */
+typedef struct mvo_ba_handle mvo_ba_handle;
+int mvo_ba_prepare(mvo_ctx* ctx, const mvo_ba_problem* problem, mvo_ba_handle** handle);
+int mvo_ba_solve_resident(mvo_ctx* ctx, mvo_ba_handle* handle);
+int mvo_ba_fetch(mvo_ctx* ctx, mvo_ba_handle* handle, double* poses, double* points, mvo_ba_stats* stats);
+void mvo_ba_release(mvo_ctx* ctx, mvo_ba_handle* handle);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per

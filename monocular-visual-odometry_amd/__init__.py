@@ -219,7 +219,58 @@ class Context:
         self._chk(r)
         return out[:n.value].copy()
 
+    def match_features_dev(self, d_d1, n1, d_d2, n2, method=2, xiang_gao_ratio=2.0, lowe_ratio=1.0):
+        out = np.zeros(max(n1, 1), DMATCH_DTYPE)
+        n = C.c_int()
+        self._chk(self.lib.mvo_match_features_dev(self.h, C.c_void_p(d_d1), n1, C.c_void_p(d_d2), n2, int(method),
+                                                  C.c_double(xiang_gao_ratio), C.c_double(lowe_ratio), _p(out),
+                                                  len(out), C.byref(n)))
+        return out[:n.value].copy()
+
     # ---- bundle adjustment
+    def _ba_problem(self, poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
+                    fix_points, pose_fixed, max_iterations):
+        keep = dict(poses=np.ascontiguousarray(poses, np.float64).reshape(-1, 16).copy(),
+                    points=np.ascontiguousarray(points, np.float64).reshape(-1, 3).copy(),
+                    ep=np.ascontiguousarray(edge_pose, np.int32), el=np.ascontiguousarray(edge_point, np.int32),
+                    uv=np.ascontiguousarray(edge_uv, np.float64).reshape(-1, 2),
+                    pf=None if pose_fixed is None else np.ascontiguousarray(pose_fixed, np.uint8))
+        pr = BaProblem()
+        pr.n_poses, pr.n_points, pr.n_edges = len(keep["poses"]), len(keep["points"]), len(keep["ep"])
+        pr.pose_T_w_c, pr.points = keep["poses"].ctypes.data, keep["points"].ctypes.data
+        pr.edge_pose, pr.edge_point, pr.edge_uv = keep["ep"].ctypes.data, keep["el"].ctypes.data, keep["uv"].ctypes.data
+        pr.focal, pr.cx, pr.cy = focal, cx, cy
+        pr.info = (C.c_double * 4)(*np.asarray(info, np.float64).ravel())
+        pr.huber_delta = huber_delta
+        pr.fix_points = int(bool(fix_points))
+        pr.pose_fixed = None if keep["pf"] is None else keep["pf"].ctypes.data
+        pr.max_iterations = int(max_iterations)
+        return pr, keep
+
+    def ba_prepare(self, poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info=(1, 0, 0, 1),
+                   huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50):
+        """Uploads a window once; returns an opaque handle for ba_solve_resident / ba_fetch / ba_release."""
+        pr, keep = self._ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
+                                    fix_points, pose_fixed, max_iterations)
+        h = C.c_void_p()
+        self._chk(self.lib.mvo_ba_prepare(self.h, C.byref(pr), C.byref(h)))
+        return (h, pr.n_poses, pr.n_points)
+
+    def ba_solve_resident(self, handle):
+        self._chk(self.lib.mvo_ba_solve_resident(self.h, handle[0]))
+
+    def ba_fetch(self, handle, want_points=True):
+        h, F, L = handle
+        poses = np.zeros((F, 16))
+        points = np.zeros((L, 3)) if want_points else None
+        st = BaStats()
+        self._chk(self.lib.mvo_ba_fetch(self.h, h, _p(poses), _p(points), C.byref(st)))
+        return poses.reshape(-1, 4, 4), points, {k: getattr(st, k) for k, _ in BaStats._fields_}
+
+    def ba_release(self, handle):
+        self.lib.mvo_ba_release.restype = None
+        self.lib.mvo_ba_release(self.h, handle[0])
+
     def bundle_adjustment(self, poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info=(1, 0, 0, 1),
                           huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50):
         """optimization::bundleAdjustment on flattened arrays.  Returns (poses [F,4,4], points [L,3], stats)."""

@@ -36,7 +36,8 @@ struct BaDev {
     double lc00, lc01, lc11;  // upper Cholesky factor of the information matrix: Omega = Lc^T Lc
     const double* poses_in;   // F x 16
     double* poses_out;        // F x 16
-    double* pts;              // L x 3 (in/out)
+    const double* pts_in;     // L x 3 initial landmarks (never written: the window can be re-solved)
+    double* pts;              // L x 3 working copy / result
     double* pts_bak;          // L x 3
     const int* e_pose;        // E (sorted by pose)
     const int* e_point;       // E
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
         quat_to_R(q, sR + 9 * tid);
         for (int i = 0; i < 3; ++i) sT[3 * tid + i] = ti[i];
     }
+    for (int i = tid; i < 3 * B.L; i += BA_THREADS) B.pts[i] = B.pts_in[i];
     __syncthreads();
 
     double lambda = 0, ni = 2;
@@ -674,7 +676,19 @@ struct Carver {
 
 int g_ba_use_mfma = 1;  // debug knob (mvo_debug_set)
 
-int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
+// A window whose inputs are resident in HBM: upload once (mvo_ba_prepare), solve any number of times.
+struct mvo_ba_handle {
+    char* dev = nullptr;  // one allocation holding inputs, CSR tables and workspace
+    size_t bytes = 0;
+    BaDev B{};
+    int F = 0, L = 0;
+    size_t o_stats = 0, o_pout = 0, o_pts = 0;
+    size_t lds = 16;
+    bool fix_points = false;
+};
+
+int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out) {
+    *out = nullptr;
     const int F = p->n_poses, L = p->n_points;
     if (F > BA_MAX_POSES) return mvo_set_err(ctx, MVO_ERR_INVALID, "more than 20 poses in the window (vo.h kBuffSize_)", hipSuccess);
     // information matrix must be symmetric positive definite: Omega = Lc^T Lc
@@ -687,8 +701,6 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
     int nfree = 0;
     for (int i = 0; i < F; ++i)
         if (!(p->pose_fixed && p->pose_fixed[i])) pose_slot[i] = nfree++;
-    std::vector<int> order;
-    order.reserve(p->n_edges);
     std::vector<int> pstart(F + 1, 0);
     for (int e = 0; e < p->n_edges; ++e) {
         if (pose_slot[p->edge_pose[e]] < 0 && p->fix_points) continue;
@@ -696,7 +708,7 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
     }
     for (int i = 0; i < F; ++i) pstart[i + 1] += pstart[i];
     const int E = pstart[F];
-    order.assign(E, 0);
+    std::vector<int> order(E, 0);
     {
         std::vector<int> cur(pstart.begin(), pstart.end() - 1);
         for (int e = 0; e < p->n_edges; ++e) {
@@ -719,8 +731,6 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
         for (int k = 0; k < E; ++k) ptlist[cur[e_point[k]]++] = k;
     }
     std::vector<unsigned char> pt_free(L, p->fix_points ? 0 : 1);
-    if (st) std::memset(st, 0, sizeof(*st));
-    if (F == 0 && (L == 0 || p->fix_points)) return MVO_OK;
 
     const int n = 6 * nfree;
     const int NT = (n + 1 + 15) / 16, W = NT * 16;
@@ -729,42 +739,55 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
     Carver cv;
     const size_t o_stats = cv.take(sizeof(BaStatsDev));
     const size_t o_pin = cv.take((size_t)F * 16 * 8), o_pout = cv.take((size_t)F * 16 * 8);
-    const size_t o_pts = cv.take((size_t)L * 3 * 8), o_bak = cv.take((size_t)L * 3 * 8);
+    const size_t o_ptsin = cv.take((size_t)L * 3 * 8);
     const size_t o_ep = cv.take((size_t)E * 4), o_el = cv.take((size_t)E * 4), o_uv = cv.take((size_t)E * 16);
     const size_t o_ps = cv.take((size_t)(F + 1) * 4), o_slot = cv.take((size_t)F * 4 + 4);
     const size_t o_pts_s = cv.take((size_t)(L + 1) * 4), o_ptl = cv.take((size_t)E * 4 + 4), o_pf = cv.take((size_t)L + 4);
     const size_t upload_end = cv.off;
+    const size_t o_pts = cv.take((size_t)L * 3 * 8), o_bak = cv.take((size_t)L * 3 * 8);
     const size_t o_M = cv.take((size_t)E * 16 * 8 + 256), o_X = cv.take((size_t)E * 6 * 8 + 256);
     const size_t o_H = cv.take((size_t)L * 6 * 8), o_b = cv.take((size_t)L * 3 * 8), o_D = cv.take((size_t)L * 6 * 8);
     const size_t o_C = cv.take((size_t)L * 6 * 8), o_dx = cv.take((size_t)L * 3 * 8);
     const size_t o_part = cv.take((size_t)std::max(BA_WAVES, ntile * KS) * 256 * 8);
     const size_t o_UT = cv.take(p->fix_points ? 256 : (size_t)3 * L * W * 8 + 256);
     const size_t total = cv.off;
-    if (ctx->d_ba_cap < total) {
-        if (ctx->d_ba) (void)hipFree(ctx->d_ba);
-        ctx->d_ba = nullptr;
-        ctx->d_ba_cap = 0;
-        MVO_HIP(hipMalloc(&ctx->d_ba, total + total / 4));
-        ctx->d_ba_cap = total + total / 4;
+    mvo_ba_handle* H = new mvo_ba_handle();
+    hipError_t he = hipMalloc((void**)&H->dev, total);
+    if (he != hipSuccess) {
+        delete H;
+        return mvo_set_err(ctx, MVO_ERR_HIP, "hipMalloc(BA window)", he);
     }
+    H->bytes = total;
     int r = mvo_ensure_pinned(ctx, upload_end);
-    if (r) return r;
+    if (r) {
+        (void)hipFree(H->dev);
+        delete H;
+        return r;
+    }
     uint8_t* h = ctx->h_pin;
-    std::memset(h + o_stats, 0, sizeof(BaStatsDev));
-    std::memcpy(h + o_pin, p->pose_T_w_c, (size_t)F * 16 * 8);
-    std::memcpy(h + o_pts, p->points, (size_t)L * 3 * 8);
-    std::memcpy(h + o_ep, e_pose.data(), (size_t)E * 4);
-    std::memcpy(h + o_el, e_point.data(), (size_t)E * 4);
-    std::memcpy(h + o_uv, e_uv.data(), (size_t)E * 16);
+    std::memset(h, 0, upload_end);
+    if (F) std::memcpy(h + o_pin, p->pose_T_w_c, (size_t)F * 16 * 8);
+    if (L) std::memcpy(h + o_ptsin, p->points, (size_t)L * 3 * 8);
+    if (E) {
+        std::memcpy(h + o_ep, e_pose.data(), (size_t)E * 4);
+        std::memcpy(h + o_el, e_point.data(), (size_t)E * 4);
+        std::memcpy(h + o_uv, e_uv.data(), (size_t)E * 16);
+        std::memcpy(h + o_ptl, ptlist.data(), (size_t)E * 4);
+    }
     std::memcpy(h + o_ps, pstart.data(), (size_t)(F + 1) * 4);
-    std::memcpy(h + o_slot, pose_slot.data(), (size_t)F * 4);
+    if (F) std::memcpy(h + o_slot, pose_slot.data(), (size_t)F * 4);
     std::memcpy(h + o_pts_s, ptstart.data(), (size_t)(L + 1) * 4);
-    std::memcpy(h + o_ptl, ptlist.data(), (size_t)E * 4);
-    std::memcpy(h + o_pf, pt_free.data(), (size_t)L);
-    char* D = (char*)ctx->d_ba;
-    MVO_HIP(hipMemcpyAsync(D, h, upload_end, hipMemcpyHostToDevice, ctx->stream));
-    if (!p->fix_points) MVO_HIP(hipMemsetAsync(D + o_UT, 0, (size_t)3 * L * W * 8, ctx->stream));
-    BaDev B{};
+    if (L) std::memcpy(h + o_pf, pt_free.data(), (size_t)L);
+    char* D = H->dev;
+    hipError_t e1 = hipMemcpyAsync(D, h, upload_end, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e2 = p->fix_points ? hipSuccess : hipMemsetAsync(D + o_UT, 0, (size_t)3 * L * W * 8, ctx->stream);
+    hipError_t e3 = hipStreamSynchronize(ctx->stream);  // the pinned staging buffer is reused by later calls
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        (void)hipFree(H->dev);
+        delete H;
+        return mvo_set_err(ctx, MVO_ERR_HIP, "BA upload", e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3));
+    }
+    BaDev& B = H->B;
     B.F = F;
     B.L = L;
     B.E = E;
@@ -785,6 +808,7 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
     B.lc11 = lc11;
     B.poses_in = (const double*)(D + o_pin);
     B.poses_out = (double*)(D + o_pout);
+    B.pts_in = (const double*)(D + o_ptsin);
     B.pts = (double*)(D + o_pts);
     B.pts_bak = (double*)(D + o_bak);
     B.e_pose = (const int*)(D + o_ep);
@@ -805,23 +829,53 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
     B.UT = (double*)(D + o_UT);
     B.part = (double*)(D + o_part);
     B.stats = (BaStatsDev*)(D + o_stats);
-    const size_t lds = std::max<size_t>((size_t)n * (n + 1) * 8, 16);
-    if (lds > 32768)
-        MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    H->F = F;
+    H->L = L;
+    H->o_stats = o_stats;
+    H->o_pout = o_pout;
+    H->o_pts = o_pts;
+    H->fix_points = p->fix_points != 0;
+    H->lds = std::max<size_t>((size_t)n * (n + 1) * 8, 16);
+    *out = H;
+    return MVO_OK;
+}
+
+// One full LM solve from the resident initial state; results stay on the device.
+int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
+    if (H->F == 0 && (H->L == 0 || H->fix_points)) return MVO_OK;
+    H->B.use_mfma = g_ba_use_mfma;
+    if (H->lds > 32768)
+        MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->lds));
     {
         ProfScope ps(ctx, "k_ba_lm");
-        hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_THREADS), lds, ctx->stream, B);
+        hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_THREADS), H->lds, ctx->stream, H->B);
     }
     MVO_HIP(hipGetLastError());
-    // results: stats | poses_out | points are contiguous enough for three small copies
-    MVO_HIP(hipMemcpyAsync(h + o_stats, D + o_stats, sizeof(BaStatsDev), hipMemcpyDeviceToHost, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(h + o_pout, D + o_pout, (size_t)F * 16 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (!p->fix_points) MVO_HIP(hipMemcpyAsync(h + o_pts, D + o_pts, (size_t)L * 24, hipMemcpyDeviceToHost, ctx->stream));
+    return MVO_OK;
+}
+
+int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* points, mvo_ba_stats* st) {
+    const size_t need = sizeof(BaStatsDev) + (size_t)H->F * 128 + (size_t)H->L * 24 + 768;
+    int r = mvo_ensure_pinned(ctx, need);
+    if (r) return r;
+    uint8_t* h = ctx->h_pin;
+    uint8_t* hp = h + 256;
+    uint8_t* hx = hp + (((size_t)H->F * 128 + 255) & ~(size_t)255);
+    const bool ran = !(H->F == 0 && (H->L == 0 || H->fix_points));
+    if (st) std::memset(st, 0, sizeof(*st));
+    if (ran) {
+        MVO_HIP(hipMemcpyAsync(h, H->dev + H->o_stats, sizeof(BaStatsDev), hipMemcpyDeviceToHost, ctx->stream));
+        if (poses && H->F)
+            MVO_HIP(hipMemcpyAsync(hp, H->dev + H->o_pout, (size_t)H->F * 128, hipMemcpyDeviceToHost, ctx->stream));
+        if (points && H->L && !H->fix_points)
+            MVO_HIP(hipMemcpyAsync(hx, H->dev + H->o_pts, (size_t)H->L * 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MVO_HIP(hipStreamSynchronize(ctx->stream));
-    std::memcpy(p->pose_T_w_c, h + o_pout, (size_t)F * 16 * 8);
-    if (!p->fix_points) std::memcpy(p->points, h + o_pts, (size_t)L * 24);
+    if (!ran) return MVO_OK;
+    if (poses && H->F) std::memcpy(poses, hp, (size_t)H->F * 128);
+    if (points && H->L && !H->fix_points) std::memcpy(points, hx, (size_t)H->L * 24);
     if (st) {
-        const BaStatsDev* s = (const BaStatsDev*)(h + o_stats);
+        const BaStatsDev* s = (const BaStatsDev*)h;
         st->iterations = s->iterations;
         st->trials = s->trials;
         st->terminated = s->terminated;
@@ -830,4 +884,20 @@ int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
         st->lambda_final = s->lambda_final;
     }
     return MVO_OK;
+}
+
+void ba_release_device(mvo_ba_handle* H) {
+    if (!H) return;
+    if (H->dev) (void)hipFree(H->dev);
+    delete H;
+}
+
+int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
+    mvo_ba_handle* H = nullptr;
+    int r = ba_prepare_device(ctx, p, &H);
+    if (r) return r;
+    r = ba_run_device(ctx, H);
+    if (!r) r = ba_fetch_device(ctx, H, p->pose_T_w_c, p->points, st);
+    ba_release_device(H);
+    return r;
 }

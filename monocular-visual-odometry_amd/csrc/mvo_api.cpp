@@ -82,8 +82,8 @@ void mvo_destroy(mvo_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_score, ctx->d_tabs, ctx->d_cell_mask, ctx->d_cell_cnt,
-                   ctx->d_hdr, ctx->d_kp,   ctx->d_desc, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
-                   ctx->d_mout, ctx->d_ba};
+                   ctx->d_hdr, ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
+                   ctx->d_mout};
     for (void* p : dev)
         if (p) (void)hipFree(p);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
@@ -419,6 +419,72 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
     int r = ba_solve_device(ctx, p, st);
     if (ctx->prof) mvo_prof_collect(ctx);
     return r;
+}
+
+int mvo_ba_prepare(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** handle) {
+    if (!ctx || !p || !handle || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0)
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if ((p->n_poses && !p->pose_T_w_c) || (p->n_points && !p->points) ||
+        (p->n_edges && (!p->edge_pose || !p->edge_point || !p->edge_uv)))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "null array", hipSuccess);
+    for (int e = 0; e < p->n_edges; ++e)
+        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 ||
+            p->edge_point[e] >= p->n_points)
+            return mvo_set_err(ctx, MVO_ERR_INVALID, "edge index out of range", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    return ba_prepare_device(ctx, p, handle);
+}
+int mvo_ba_solve_resident(mvo_ctx* ctx, mvo_ba_handle* handle) {
+    if (!ctx || !handle) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    return ba_run_device(ctx, handle);
+}
+int mvo_ba_fetch(mvo_ctx* ctx, mvo_ba_handle* handle, double* poses, double* points, mvo_ba_stats* stats) {
+    if (!ctx || !handle) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = ba_fetch_device(ctx, handle, poses, points, stats);
+    if (ctx->prof) mvo_prof_collect(ctx);
+    return r;
+}
+void mvo_ba_release(mvo_ctx* ctx, mvo_ba_handle* handle) {
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    ba_release_device(handle);
+}
+
+// matchFeatures with both descriptor sets already in HBM (e.g. the ping-pong buffers of mvo_calc_descriptors_dev)
+int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d_d2, int n2, int method,
+                           double xiang_gao_ratio, double lowe_ratio, mvo_dmatch* out, int cap, int* n) {
+    if (!ctx || !n || n1 < 0 || n2 < 0) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    *n = 0;
+    if (method != 1 && method != 2)
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "feature_match.cpp::matchFeatures: wrong method index.", hipSuccess);
+    std::vector<int32_t> idx(2 * (size_t)n1), dist(2 * (size_t)n1);
+    int r = mvo_match_knn2_dev(ctx, d_d1, n1, d_d2, n2, idx.data(), dist.data());
+    if (r) return r;
+    std::vector<mvo_dmatch> matches;
+    if (method == 1) {
+        double min_dis = 9999999;
+        for (int i = 0; i < n1; ++i)
+            if (idx[2 * i] >= 0 && dist[2 * i] < min_dis) min_dis = dist[2 * i];
+        const double thr = std::max<float>(min_dis * xiang_gao_ratio, 30.0);
+        for (int i = 0; i < n1; ++i)
+            if (idx[2 * i] >= 0 && (float)dist[2 * i] < thr) matches.push_back({i, idx[2 * i], 0, (float)dist[2 * i]});
+    } else {
+        for (int i = 0; i < n1; ++i) {
+            if (idx[2 * i + 1] < 0) continue;
+            const double d = (float)dist[2 * i];
+            if (d < lowe_ratio * (float)dist[2 * i + 1]) matches.push_back({i, idx[2 * i], 0, (float)dist[2 * i]});
+        }
+    }
+    int cnt = (int)matches.size();
+    mvo_remove_duplicated_matches(matches.data(), &cnt);
+    *n = cnt;
+    if (cnt > cap || (cnt && !out)) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "match buffer too small", hipSuccess);
+    std::copy(matches.begin(), matches.begin() + cnt, out);
+    return MVO_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- debug hooks

@@ -89,7 +89,9 @@ struct mvo_ctx {
     DevCandidate* d_cand = nullptr;
     int cand_cap = 0;
     DevDescKp* d_kp = nullptr;
-    uint8_t* d_desc = nullptr;
+    uint8_t* d_desc = nullptr;      // descriptors of the current extraction (one of the two halves below)
+    uint8_t* d_desc_buf = nullptr;  // 2 x kp_cap x 32: ping-pong so that frame i-1 survives frame i
+    int desc_flip = 0;
     int kp_cap = 0;
     // pinned host staging
     uint8_t* h_pin = nullptr;
@@ -100,9 +102,6 @@ struct mvo_ctx {
     float *d_mqxy = nullptr, *d_mtxy = nullptr;
     int32_t* d_mout = nullptr;
     int m_cap_q = 0, m_cap_t = 0;
-    // --- BA
-    void* d_ba = nullptr;
-    size_t d_ba_cap = 0;
     // --- profiling
     bool prof = false;
     std::map<std::string, ProfEntry> prof_acc;
@@ -143,6 +142,11 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
 int match_launch_radius_l1(mvo_ctx* ctx, const uint8_t* d_q, const float* d_qxy, int nq, const uint8_t* d_t,
                            const float* d_txy, int nt, float max_px, int32_t* d_out);
 // ba_kernels.hip
+struct mvo_ba_handle;
 int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st);
+int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out);
+int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H);
+int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* points, mvo_ba_stats* st);
+void ba_release_device(mvo_ba_handle* H);
 
 #endif

@@ -164,13 +164,18 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
 }
 
 static int ensure_kp_cap(mvo_ctx* ctx, int n) {
-    if (ctx->kp_cap >= n) return MVO_OK;
-    free_dev(ctx->d_kp);
-    free_dev(ctx->d_desc);
-    int cap = std::max(4096, n + n / 2);
-    MVO_HIP(hipMalloc((void**)&ctx->d_kp, (size_t)cap * sizeof(DevDescKp)));
-    MVO_HIP(hipMalloc((void**)&ctx->d_desc, (size_t)cap * 32));
-    ctx->kp_cap = cap;
+    if (ctx->kp_cap < n) {
+        // (growing drops the previous frame's device descriptors: callers keep n <= 4096 or re-extract)
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        free_dev(ctx->d_kp);
+        free_dev(ctx->d_desc_buf);
+        int cap = std::max(4096, n + n / 2);
+        MVO_HIP(hipMalloc((void**)&ctx->d_kp, (size_t)cap * sizeof(DevDescKp)));
+        MVO_HIP(hipMalloc((void**)&ctx->d_desc_buf, (size_t)cap * 64));
+        ctx->kp_cap = cap;
+    }
+    ctx->desc_flip ^= 1;
+    ctx->d_desc = ctx->d_desc_buf + (size_t)ctx->desc_flip * ctx->kp_cap * 32;
     return MVO_OK;
 }
 

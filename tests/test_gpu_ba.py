@@ -1,0 +1,131 @@
+"""HIP bundle adjustment vs the oracle (f64): poses / landmarks within 1e-4 relative (north-star tolerance)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _args(pb, poses=None):
+    return (pb["poses0"] if poses is None else poses, pb["points0"], pb["edge_pose"], pb["edge_point"],
+            pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _check(mvo, O, ctx, pb, **kw):
+    P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
+    msg = "gpu %s\noracle %s" % (st, sto)
+    assert np.isfinite(P).all(), msg
+    assert _rel(P[:, :3, 3], Po[:, :3, 3]) < TOL and np.abs(P[:, :3, :3] - Po[:, :3, :3]).max() < TOL, msg
+    assert _rel(X, Xo) < TOL, msg
+    assert abs(st["chi2_initial"] - sto["chi2_initial"]) <= 1e-9 * sto["chi2_initial"], msg
+    assert abs(st["chi2_final"] - sto["chi2_final"]) <= 1e-6 * max(sto["chi2_final"], 1e-12), msg
+    return st, sto
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("F,L,seed", [(1, 100, 1), (3, 200, 2), (5, 2000, 7)])
+def test_pose_only_ba_shipped_default(mvo, O, ctx, F, L, seed, mfma):
+    """is_ba_fix_map_points: true (config.yaml:123)."""
+    mvo.debug_set("ba_mfma", mfma)
+    try:
+        st, sto = _check(mvo, O, ctx, mvo.synth.ba_problem(F, L, seed), fix_points=True)
+        assert st["iterations"] >= 1
+    finally:
+        mvo.debug_set("ba_mfma", 1)
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("F,L,seed", [(2, 60, 3), (5, 500, 4), (5, 2000, 7)])
+def test_full_ba_pose0_fixed(mvo, O, ctx, F, L, seed, mfma):
+    mvo.debug_set("ba_mfma", mfma)
+    try:
+        fixed = np.zeros(F, np.uint8)
+        fixed[0] = 1
+        _check(mvo, O, ctx, mvo.synth.ba_problem(F, L, seed), fix_points=False, pose_fixed=fixed)
+    finally:
+        mvo.debug_set("ba_mfma", 1)
+
+
+def test_full_ba_faithful_no_fixed_pose(mvo, O, ctx):
+    """The reference fixes no vertex (g2o_ba.cpp:210-211 commented out): gauge held only by the LM damping."""
+    _check(mvo, O, ctx, mvo.synth.ba_problem(5, 800, 9), fix_points=False)
+
+
+def test_ba10_and_information_matrix(mvo, O, ctx):
+    pb = mvo.synth.ba_problem(10, 1500, 11, width=1242, height=375, K=mvo.synth.KITTI_K)
+    fixed = np.zeros(10, np.uint8)
+    fixed[0] = 1
+    _check(mvo, O, ctx, pb, fix_points=False, pose_fixed=fixed, info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5)
+    _check(mvo, O, ctx, pb, fix_points=True, info=(2.0, 0.3, 0.3, 1.5))
+
+
+def test_noise_free_optimum_is_ground_truth(mvo, ctx):
+    pb = mvo.synth.ba_problem(4, 300, seed=1, pix_noise=0, outlier_frac=0, point_noise=0, f32_storage=False)
+    P, X, st = ctx.bundle_adjustment(pb["poses0"], pb["points_gt"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"],
+                                     pb["focal"], pb["cx"], pb["cy"], fix_points=True)
+    assert np.abs(P - pb["poses_gt"]).max() < 1e-8 and st["chi2_final"] < 1e-10
+
+
+def test_degenerate_windows_and_errors(mvo, O, ctx):
+    pb = mvo.synth.ba_problem(3, 50, 5)
+    P, X, st = ctx.bundle_adjustment(*_args(pb), fix_points=True, max_iterations=0)
+    assert st["iterations"] == 0 and np.abs(P - pb["poses0"]).max() < 1e-12
+    e = np.zeros(0, np.int32)
+    P, X, st = ctx.bundle_adjustment(np.zeros((0, 16)), np.zeros((0, 3)), e, e, np.zeros((0, 2)), 500, 320, 240)
+    assert len(P) == 0
+    P, X, st = ctx.bundle_adjustment(*_args(pb), fix_points=True, pose_fixed=np.ones(3, np.uint8))
+    assert st["iterations"] == 0 and np.abs(P - pb["poses0"]).max() < 1e-12
+    with pytest.raises(mvo.MvoError):
+        ctx.bundle_adjustment(pb["poses0"], pb["points0"], pb["edge_pose"] + 10, pb["edge_point"], pb["edge_uv"],
+                              pb["focal"], pb["cx"], pb["cy"])
+    # duplicate (pose, point) observations accumulate like g2o's shared Hessian block
+    pb2 = mvo.synth.ba_problem(3, 80, 6)
+    ep = np.concatenate([pb2["edge_pose"], pb2["edge_pose"][:40]])
+    el = np.concatenate([pb2["edge_point"], pb2["edge_point"][:40]])
+    uv = np.concatenate([pb2["edge_uv"], pb2["edge_uv"][:40] + 0.3])
+    fixed = np.array([1, 0, 0], np.uint8)
+    a = ctx.bundle_adjustment(pb2["poses0"], pb2["points0"], ep, el, uv, pb2["focal"], pb2["cx"], pb2["cy"],
+                              fix_points=False, pose_fixed=fixed)
+    b = O.bundle_adjustment(pb2["poses0"], pb2["points0"], ep, el, uv, pb2["focal"], pb2["cx"], pb2["cy"],
+                            fix_points=False, pose_fixed=fixed)
+    assert _rel(a[0][:, :3, 3], b[0][:, :3, 3]) < TOL and _rel(a[1], b[1]) < TOL
+
+
+def test_reference_style_bundle_adjustment(mvo, O):
+    """optimization::bundleAdjustment signature (g2o_ba.h:23-30) with pointer-list stand-ins."""
+    mvo.reset_default_context()
+    pb = mvo.synth.ba_problem(3, 120, 8)
+    v2d, vidx = [], []
+    for i in range(3):
+        sel = pb["edge_pose"] == i
+        v2d.append(pb["edge_uv"][sel].astype(np.float32))
+        vidx.append((pb["edge_point"][sel] + 1000).tolist())          # map-point ids need not be 0..L-1
+    pts = {int(i + 1000): pb["points0"][i].astype(np.float32) for i in np.unique(pb["edge_point"])}
+    poses = [pb["poses0"][i].copy() for i in range(3)]
+    K = np.array([[pb["focal"], 0, pb["cx"]], [0, 516.5, pb["cy"]], [0, 0, 1]])
+    before = {k: v.copy() for k, v in pts.items()}
+    mvo.bundleAdjustment(v2d, vidx, K, pts, poses, np.eye(2), True, False)
+    assert all(np.array_equal(before[k], pts[k]) for k in pts)          # fixed + not updated
+    Po, _, _ = O.bundle_adjustment(*_args(pb), fix_points=True)
+    assert np.abs(np.array(poses) - Po).max() < TOL
+    mvo.reset_default_context()
+
+
+def test_resident_window_can_be_resolved_repeatedly(mvo, O, ctx):
+    pb = mvo.synth.ba_problem(5, 600, 12)
+    h = ctx.ba_prepare(*_args(pb), fix_points=False)
+    res = []
+    for _ in range(3):
+        ctx.ba_solve_resident(h)
+        res.append(ctx.ba_fetch(h))
+    ctx.ba_release(h)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), fix_points=False)
+    for P, X, st in res:
+        assert np.array_equal(P, res[0][0]) and np.array_equal(X, res[0][1])      # deterministic re-solve
+        assert _rel(P[:, :3, 3], Po[:, :3, 3]) < TOL and _rel(X, Xo) < TOL

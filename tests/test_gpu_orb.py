@@ -1,0 +1,135 @@
+"""HIP ORB path vs the oracle, stage by stage, through the C-ABI.  Integer / byte work: bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import assert_struct_equal
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(160, 120, 3), (320, 240, 3), (333, 251, 1), (640, 480, 3)]
+
+
+def _cfg(mvo, O, ctx, **kw):
+    ctx.orb_configure(**kw)
+    return O.default_params(**ctx.params)
+
+
+def _cand_cmp(mvo, gc, oc):
+    assert len(gc) == len(oc), "candidate count %d vs %d" % (len(gc), len(oc))
+    g = np.zeros(len(gc), oc.dtype)
+    g["x"], g["y"] = gc["x"], gc["y"]
+    g["level"] = gc["level_score"] >> 16
+    g["fast_score"] = gc["level_score"] & 0xffff
+    g["harris"], g["angle"] = gc["harris"], gc["angle"]
+    assert_struct_equal(g, oc, "candidates")
+
+
+@pytest.mark.parametrize("w,h,ch", SIZES)
+def test_pyramid_blur_candidates_bit_exact(mvo, O, ctx, w, h, ch):
+    p = _cfg(mvo, O, ctx, max_keypoints=2000)
+    img = mvo.synth.small_test_image(w + h, w, h, channels=ch)
+    ctx.calc_keypoints(img)
+    for l in range(p.nlevels):
+        for blurred in (False, True):
+            g = ctx.debug_level(l, blurred)
+            o = O.pyramid_level(img, p, l, blurred)
+            assert g.shape == o.shape, (l, g.shape, o.shape)
+            bad = np.argwhere(g != o)
+            assert len(bad) == 0, "level %d blurred=%d: %d px differ, first %s (gpu %d oracle %d)" % (
+                l, blurred, len(bad), bad[0], g[tuple(bad[0])], o[tuple(bad[0])])
+    _cand_cmp(mvo, ctx.debug_candidates(), O.candidates(img, p))
+
+
+@pytest.mark.parametrize("w,h,ch", SIZES)
+def test_keypoints_and_descriptors_bit_exact(mvo, O, ctx, w, h, ch):
+    p = _cfg(mvo, O, ctx, max_keypoints=2000)
+    img = mvo.synth.small_test_image(7 * w + h, w, h, channels=ch)
+    k = ctx.calc_keypoints(img, cap=4096)
+    ko = O.calc_keypoints(img, p)
+    assert_struct_equal(k, ko.astype(k.dtype), "calcKeyPoints")
+    k2, d, rgb = ctx.calc_descriptors(img, k, reuse_pyramid=True, want_rgb=True)
+    ko2, do, rgbo = O.calc_descriptors(img, ko, p, want_rgb=True)
+    assert_struct_equal(k2, ko2.astype(k.dtype), "calcDescriptors keypoints")
+    assert np.array_equal(d, do), "descriptors: %d rows differ" % (d != do).any(1).sum()
+    assert np.array_equal(rgb, rgbo)
+    # the non-reuse path rebuilds the pyramid and must agree
+    k3, d3 = ctx.calc_descriptors(img, k, reuse_pyramid=False)
+    assert np.array_equal(d3, do)
+
+
+def test_quota_limited_selection_and_small_thresholds(mvo, O, ctx):
+    """nfeatures small enough that retainBest (nth_element + ties) actually cuts, FAST threshold low."""
+    img = mvo.synth.small_test_image(11, 480, 360)
+    for nf, thr in ((300, 20), (1000, 7), (50, 40)):
+        p = _cfg(mvo, O, ctx, nfeatures=nf, fast_threshold=thr, max_keypoints=5000)
+        k = ctx.calc_keypoints(img, cap=8192)
+        ko = O.calc_keypoints(img, p)
+        assert_struct_equal(k, ko.astype(k.dtype), "nfeatures=%d thr=%d" % (nf, thr))
+        _, d = ctx.calc_descriptors(img, k, reuse_pyramid=True)
+        _, do = O.calc_descriptors(img, ko, p)
+        assert np.array_equal(d, do)
+
+
+def test_other_pyramid_shapes(mvo, O, ctx):
+    img = mvo.synth.small_test_image(5, 400, 300)
+    for nlevels, sf in ((1, 1.2), (2, 1.5), (6, 1.2), (8, 1.1)):
+        p = _cfg(mvo, O, ctx, nlevels=nlevels, scale_factor=sf, max_keypoints=3000, nfeatures=4000)
+        k = ctx.calc_keypoints(img, cap=8192)
+        ko = O.calc_keypoints(img, p)
+        assert_struct_equal(k, ko.astype(k.dtype), "nlevels=%d" % nlevels)
+        _, d = ctx.calc_descriptors(img, k, reuse_pyramid=True)
+        _, do = O.calc_descriptors(img, ko, p)
+        assert np.array_equal(d, do)
+
+
+def test_grid_latching_and_degenerate_images(mvo, O, ctx):
+    _cfg(mvo, O, ctx, max_keypoints=1500)
+    flat = np.full((240, 320, 3), 90, np.uint8)
+    k = ctx.calc_keypoints(flat)
+    assert len(k) == 0
+    k, d = ctx.calc_descriptors(flat, k, reuse_pyramid=True)
+    assert len(k) == 0
+    # S640-shaped frame 0 of the bench sequence: full-size parity
+    seq = mvo.synth.Sequence(640, 480, 4, seed=1234, tex_size=1024)
+    p = _cfg(mvo, O, ctx, max_keypoints=2000)
+    for i in range(2):
+        img = seq.frame(i)
+        k = ctx.calc_keypoints(img, cap=4096)
+        ko = O.calc_keypoints(img, p)
+        assert_struct_equal(k, ko.astype(k.dtype), "S640 frame %d" % i)
+        k, d = ctx.calc_descriptors(img, k, reuse_pyramid=True)
+        ko, do = O.calc_descriptors(img, ko, p)
+        assert np.array_equal(d, do)
+        assert 1500 < len(k) <= 2001
+
+
+def test_device_resident_image_and_descriptors(mvo, O, ctx):
+    import torch
+    p = _cfg(mvo, O, ctx, max_keypoints=1000)
+    img = mvo.synth.small_test_image(21, 320, 240)
+    t = torch.from_numpy(img).cuda()
+    torch.cuda.synchronize()
+    k = ctx.calc_keypoints_dev(t.data_ptr(), 320, 240, 320 * 3, 3, cap=2048)
+    ko = O.calc_keypoints(img, p)
+    assert_struct_equal(k, ko.astype(k.dtype), "calc_keypoints_dev")
+    k2, d, dptr = ctx.calc_descriptors_dev(k)
+    _, do = O.calc_descriptors(img, ko, p)
+    assert np.array_equal(d, do) and dptr
+    # device descriptors feed the matcher without a host round trip
+    idx, dist = ctx.match_knn2_dev(dptr, len(k2), dptr, len(k2))
+    assert (idx[:, 0] == np.arange(len(k2))).all() or (dist[:, 0] == 0).all()
+
+
+def test_error_paths(mvo, ctx):
+    with pytest.raises(mvo.MvoError):
+        ctx.orb_configure(nlevels=99)
+    ctx.orb_configure(nlevels=4)
+    img = mvo.synth.small_test_image(1, 160, 120)
+    k = ctx.calc_keypoints(img)
+    with pytest.raises(mvo.MvoError) as e:
+        ctx.calc_keypoints(img, cap=1)
+    assert e.value.code == mvo.MVO_ERR_CAPACITY
+    ctx.orb_configure(nlevels=4)     # drops the cached pyramid
+    with pytest.raises(mvo.MvoError) as e:
+        ctx.calc_descriptors(img, k, reuse_pyramid=True)
+    assert e.value.code == mvo.MVO_ERR_STATE

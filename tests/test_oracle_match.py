@@ -1,0 +1,121 @@
+"""Known-answer tests for the ORACLE's matcher restatement (feature_match.cpp:86-260)."""
+import numpy as np
+import pytest
+
+
+def _desc(bits_set):
+    d = np.zeros(256, np.uint8)
+    d[list(bits_set)] = 1
+    return np.packbits(d, bitorder="little")
+
+
+def test_hamming_known_distances(O):
+    q = np.stack([_desc([]), _desc(range(256)), _desc(range(128)), _desc([7])])
+    t = np.stack([_desc([]), _desc([0]), _desc(range(128)), _desc(range(256))])
+    idx, dist = O.match_knn2(q, t)
+    assert dist[0].tolist() == [0, 1] and idx[0].tolist() == [0, 1]
+    assert dist[1].tolist() == [0, 128] and idx[1].tolist() == [3, 2]
+    assert dist[2].tolist() == [0, 127] and idx[2].tolist() == [2, 1]
+    assert dist[3].tolist() == [1, 2] and idx[3].tolist() == [0, 1]
+
+
+def test_ties_keep_lower_train_index(O):
+    base = _desc([1, 5, 9])
+    t = np.stack([_desc([1, 5, 9, 200]), base, base, _desc([1, 5]), base])
+    idx, dist = O.match_knn2(base[None], t)
+    assert idx[0].tolist() == [1, 2] and dist[0].tolist() == [0, 0]
+    # equal distance 1: indices 0 and 3 -> lower first
+    idx, dist = O.match_knn2(base[None], t[[0, 3]])
+    assert idx[0].tolist() == [0, 1] and dist[0].tolist() == [1, 1]
+
+
+def test_knn2_small_train_sets(O):
+    q = np.random.RandomState(0).randint(0, 256, (5, 32)).astype(np.uint8)
+    idx, dist = O.match_knn2(q, q[:1])
+    assert (idx[:, 0] == 0).all() and (idx[:, 1] == -1).all() and (dist[:, 1] == np.iinfo(np.int32).max).all()
+    idx, dist = O.match_knn2(q, q[:0])
+    assert (idx == -1).all()
+    # method 2 guards the reference's out-of-bounds knn_matches[i][1] read (feature_match.cpp:216)
+    assert len(O.match_features(q, q[:1], 2)) == 0
+
+
+def test_against_numpy_bruteforce(O):
+    rng = np.random.RandomState(1)
+    q = rng.randint(0, 256, (70, 32)).astype(np.uint8)
+    t = rng.randint(0, 256, (90, 32)).astype(np.uint8)
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    order = np.argsort(D, axis=1, kind="stable")[:, :2]
+    idx, dist = O.match_knn2(q, t)
+    assert np.array_equal(idx, order)
+    assert np.array_equal(dist, np.take_along_axis(D, order, 1))
+
+
+def test_remove_duplicated_matches_is_std_sort_then_unique(O):
+    m = np.zeros(6, O.DMATCH_DTYPE)
+    m["queryIdx"] = [0, 1, 2, 3, 4, 5]
+    m["trainIdx"] = [9, 2, 9, 2, 7, 0]
+    m["distance"] = [5, 6, 1, 2, 3, 4]
+    out = O.remove_duplicated_matches(m)
+    assert out["trainIdx"].tolist() == [0, 2, 7, 9]
+    # every survivor is one of the originals with that trainIdx (which one is libstdc++'s business)
+    for r in out:
+        assert any((m["queryIdx"] == r["queryIdx"]) & (m["trainIdx"] == r["trainIdx"]))
+    assert len(O.remove_duplicated_matches(m[:0])) == 0
+
+
+def test_match_features_method1_threshold(O):
+    # distances 10, 25, 29, 30, 45 -> min 10 -> threshold max(10*2, 30) = 30, strict '<'
+    t = np.stack([_desc(range(i * 50, i * 50 + n)) for i, n in enumerate([0, 0, 0, 0, 0])])
+    q = np.stack([_desc(range(0, 10)), _desc(range(0, 25)), _desc(range(0, 29)), _desc(range(0, 30)), _desc(range(0, 45))])
+    tt = _desc([])[None]
+    m = O.match_features(q, tt, 1, xiang_gao_ratio=2.0)
+    # all queries match train 0; de-dup keeps one
+    assert len(m) == 1 and m[0]["trainIdx"] == 0 and m[0]["distance"] < 30
+    # distinct trains: pair i lives in its own 80-bit region: 30 identifying bits + d_i extra bits in the train
+    qs, ts = [], []
+    for i, d in enumerate([10, 29, 30]):
+        base = list(range(i * 80, i * 80 + 30))
+        qs.append(_desc(base))
+        ts.append(_desc(base + list(range(i * 80 + 30, i * 80 + 30 + d))))
+    m = O.match_features(np.stack(qs), np.stack(ts), 1, xiang_gao_ratio=2.0)
+    assert sorted(m["distance"].tolist()) == [10.0, 29.0]                 # threshold max(10*2, 30) = 30, strict
+    m = O.match_features(np.stack(qs[1:]), np.stack(ts[1:]), 1, xiang_gao_ratio=2.0)
+    assert sorted(m["distance"].tolist()) == [29.0, 30.0]                 # min 29 -> threshold 58
+    assert t is not None
+
+
+def test_match_features_lowe_ratio_latching(O):
+    """lowe_method_dist_ratio 0.8 is read with get<int> -> 1 (feature_match.cpp:138): 'd0 < 1*d1'."""
+    q = _desc(range(0, 20))[None]
+    t = np.stack([_desc(range(0, 20 + 9)), _desc(range(0, 20 + 10))])   # d = 9, 10
+    assert len(O.match_features(q, t, 2, lowe_ratio=1.0)) == 1             # faithful: 9 < 10
+    assert len(O.match_features(q, t, 2, lowe_ratio=0.8)) == 0             # intended: 9 < 8 false
+    t2 = np.stack([_desc(range(0, 29)), _desc(range(1, 30))])              # d = 9, 11? no: equal-distance tie
+    idx, dist = O.match_knn2(q, t2)
+    if dist[0, 0] == dist[0, 1]:
+        assert len(O.match_features(q, t2, 2, lowe_ratio=1.0)) == 0         # strict '<'
+
+
+def test_match_features_wrong_method_raises(O):
+    q = np.zeros((2, 32), np.uint8)
+    with pytest.raises(RuntimeError):
+        O.match_features(q, q, 4)
+
+
+def test_radius_l1_gate_and_first_minimum(O):
+    q = np.zeros((1, 32), np.uint8)
+    t = np.zeros((4, 32), np.uint8)
+    t[0, 0] = 5        # sum 5, inside
+    t[1, 0] = 3        # sum 3, outside the radius
+    t[2, 1] = 5        # sum 5, inside (later -> loses the tie)
+    t[3, 2] = 9
+    qxy = np.array([[10.0, 10.0]], np.float32)
+    txy = np.array([[13, 14], [10, 15.01], [10, 5], [10, 10]], np.float32)   # dists 5, 5.01, 5, 0
+    idx, s = O.match_radius_l1(q, qxy, t, txy, 5.0)
+    assert idx[0] == 0 and s[0] == 5                                     # '<=' r^2 admits distance exactly 5
+    idx, s = O.match_radius_l1(q, qxy, t, txy, 4.99)
+    assert idx[0] == 3 and s[0] == 9
+    idx, s = O.match_radius_l1(q, qxy + 1000, t, txy, 5.0)
+    assert idx[0] == -1
+    m = O.match_features(q, t, 3, xy1=qxy, xy2=txy, max_px=5.0)
+    assert len(m) == 1 and m[0]["imgIdx"] == -1 and abs(m[0]["distance"] - 5 / 32) < 1e-7
