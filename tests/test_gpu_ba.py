@@ -40,28 +40,74 @@ def test_pose_only_ba_shipped_default(mvo, O, ctx, F, L, seed, mfma):
         mvo.debug_set("ba_mfma", 1)
 
 
+def _fix(F, k):
+    f = np.zeros(F, np.uint8)
+    f[:k] = 1
+    return f
+
+
 @pytest.mark.parametrize("mfma", [1, 0])
-@pytest.mark.parametrize("F,L,seed", [(2, 60, 3), (5, 500, 4), (5, 2000, 7)])
-def test_full_ba_pose0_fixed(mvo, O, ctx, F, L, seed, mfma):
+@pytest.mark.parametrize("iters", [1, 2, 4])
+@pytest.mark.parametrize("F,L,seed,nfix", [(2, 60, 3, 1), (5, 500, 4, 0), (5, 2000, 7, 2), (3, 100, 5, 0)])
+def test_full_ba_first_iterations_tight(mvo, O, ctx, F, L, seed, nfix, iters, mfma):
+    """A few LM iterations are pure linear algebra: the Schur path must agree with the oracle to rounding."""
     mvo.debug_set("ba_mfma", mfma)
     try:
-        fixed = np.zeros(F, np.uint8)
-        fixed[0] = 1
-        _check(mvo, O, ctx, mvo.synth.ba_problem(F, L, seed), fix_points=False, pose_fixed=fixed)
+        pb = mvo.synth.ba_problem(F, L, seed)
+        kw = dict(fix_points=False, pose_fixed=_fix(F, nfix) if nfix else None, max_iterations=iters)
+        P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+        Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
+        msg = "gpu %s\noracle %s" % (st, sto)
+        assert st["iterations"] == sto["iterations"] and st["trials"] == sto["trials"], msg
+        assert np.abs(P - Po).max() < 1e-8 and np.abs(X - Xo).max() < 1e-8, msg
+        assert abs(st["chi2_final"] - sto["chi2_final"]) < 1e-8 * sto["chi2_final"], msg
+        assert abs(st["lambda_final"] - sto["lambda_final"]) < 1e-6 * sto["lambda_final"], msg
     finally:
         mvo.debug_set("ba_mfma", 1)
 
 
-def test_full_ba_faithful_no_fixed_pose(mvo, O, ctx):
-    """The reference fixes no vertex (g2o_ba.cpp:210-211 commented out): gauge held only by the LM damping."""
-    _check(mvo, O, ctx, mvo.synth.ba_problem(5, 800, 9), fix_points=False)
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("F,L,seed", [(3, 200, 3), (5, 500, 4), (5, 2000, 7)])
+def test_full_ba_gauge_anchored(mvo, O, ctx, F, L, seed, mfma):
+    """Two fixed poses remove the 7-dof gauge (similarity) -> unique optimum -> <= 1e-4 on poses and landmarks."""
+    mvo.debug_set("ba_mfma", mfma)
+    try:
+        pb = mvo.synth.ba_problem(F, L, seed)
+        pb["poses0"][:2] = pb["poses_gt"][:2]
+        _check(mvo, O, ctx, pb, fix_points=False, pose_fixed=_fix(F, 2))
+    finally:
+        mvo.debug_set("ba_mfma", 1)
+
+
+def _reproj(pb, P, X):
+    r = []
+    for i in range(len(P)):
+        Tcw = np.linalg.inv(P[i])
+        sel = pb["edge_pose"] == i
+        pc = X[pb["edge_point"][sel]] @ Tcw[:3, :3].T + Tcw[:3, 3]
+        r.append(pb["focal"] * pc[:, :2] / pc[:, 2:] + [pb["cx"], pb["cy"]] - pb["edge_uv"][sel])
+    return np.concatenate(r)
+
+
+@pytest.mark.parametrize("nfix", [0, 1])
+def test_full_ba_faithful_gauge_free(mvo, O, ctx, nfix):
+    """The reference fixes no vertex (g2o_ba.cpp:210-211 commented out): the 7-dof gauge (6-dof scale with pose 0
+    fixed) is held only by the LM damping, so 50 iterations do not pin poses/landmarks to 1e-4 -- the path taken
+    depends on accept/reject decisions at rounding level.  Compared here: the gauge-invariant quantities."""
+    pb = mvo.synth.ba_problem(5, 800, 9)
+    kw = dict(fix_points=False, pose_fixed=_fix(5, nfix) if nfix else None)
+    P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
+    assert abs(st["chi2_final"] - sto["chi2_final"]) < 5e-3 * sto["chi2_final"], (st, sto)
+    assert st["chi2_final"] < 0.1 * st["chi2_initial"]
+    r, ro = _reproj(pb, P, X), _reproj(pb, Po, Xo)
+    assert np.abs(r - ro).max() < 0.5, np.abs(r - ro).max()      # pixels
 
 
 def test_ba10_and_information_matrix(mvo, O, ctx):
     pb = mvo.synth.ba_problem(10, 1500, 11, width=1242, height=375, K=mvo.synth.KITTI_K)
-    fixed = np.zeros(10, np.uint8)
-    fixed[0] = 1
-    _check(mvo, O, ctx, pb, fix_points=False, pose_fixed=fixed, info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5)
+    pb["poses0"][:2] = pb["poses_gt"][:2]
+    _check(mvo, O, ctx, pb, fix_points=False, pose_fixed=_fix(10, 2), info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5)
     _check(mvo, O, ctx, pb, fix_points=True, info=(2.0, 0.3, 0.3, 1.5))
 
 
@@ -91,10 +137,10 @@ def test_degenerate_windows_and_errors(mvo, O, ctx):
     uv = np.concatenate([pb2["edge_uv"], pb2["edge_uv"][:40] + 0.3])
     fixed = np.array([1, 0, 0], np.uint8)
     a = ctx.bundle_adjustment(pb2["poses0"], pb2["points0"], ep, el, uv, pb2["focal"], pb2["cx"], pb2["cy"],
-                              fix_points=False, pose_fixed=fixed)
+                              fix_points=False, pose_fixed=fixed, max_iterations=3)
     b = O.bundle_adjustment(pb2["poses0"], pb2["points0"], ep, el, uv, pb2["focal"], pb2["cx"], pb2["cy"],
-                            fix_points=False, pose_fixed=fixed)
-    assert _rel(a[0][:, :3, 3], b[0][:, :3, 3]) < TOL and _rel(a[1], b[1]) < TOL
+                            fix_points=False, pose_fixed=fixed, max_iterations=3)
+    assert np.abs(a[0] - b[0]).max() < 1e-8 and np.abs(a[1] - b[1]).max() < 1e-8
 
 
 def test_reference_style_bundle_adjustment(mvo, O):
@@ -119,13 +165,15 @@ def test_reference_style_bundle_adjustment(mvo, O):
 
 def test_resident_window_can_be_resolved_repeatedly(mvo, O, ctx):
     pb = mvo.synth.ba_problem(5, 600, 12)
-    h = ctx.ba_prepare(*_args(pb), fix_points=False)
+    pb["poses0"][:2] = pb["poses_gt"][:2]
+    kw = dict(fix_points=False, pose_fixed=_fix(5, 2))
+    h = ctx.ba_prepare(*_args(pb), **kw)
     res = []
     for _ in range(3):
         ctx.ba_solve_resident(h)
         res.append(ctx.ba_fetch(h))
     ctx.ba_release(h)
-    Po, Xo, sto = O.bundle_adjustment(*_args(pb), fix_points=False)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
     for P, X, st in res:
         assert np.array_equal(P, res[0][0]) and np.array_equal(X, res[0][1])      # deterministic re-solve
         assert _rel(P[:, :3, 3], Po[:, :3, 3]) < TOL and _rel(X, Xo) < TOL
