@@ -70,6 +70,12 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError("HIP extension %s is missing -- run __graft_entry__.build() (hipcc, gfx950). "
                           "There is no CPU fallback." % LIB_PATH)
+    try:
+        # torch bundles its own libamdhip64; when both end up in one process the FIRST one loaded must be
+        # torch's (otherwise torch.cuda reports "No HIP GPUs are available"), so import it before dlopen.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.mvo_last_error.restype = C.c_char_p
     lib.mvo_destroy.restype = None
