@@ -168,7 +168,8 @@ typedef struct {
 int mvo_profile_get(mvo_ctx* ctx, mvo_kernel_time* out, int cap);
 
 /* ---- debug / test hooks (used by tests/ to localise a parity failure; not part of the drop-in) ---- */
-/* key "ba_mfma": 1 (default) = matrix-core contractions, 0 = plain VALU loops computing the same sums. */
+/* key "ba_mfma": 1 (default) = matrix-core contractions, 0 = plain VALU loops computing the same sums;
+ * key "ba_wgs": workgroups (CUs) one BA window is split over, 0 (default) = automatic. */
 int mvo_debug_set(const char* key, int value);
 /* Copies cached pyramid level `level` (raw gray or blurred) WITH its 32-px frame: (h+64) rows of `stride`
  * bytes.  out == NULL only queries the geometry. */

@@ -2,62 +2,82 @@
 // optimization::bundleAdjustment drives (src/optimization/g2o_ba.cpp:193-289: SparseOptimizer::optimize(50) with
 // OptimizationAlgorithmLevenberg, BlockSolver<6,3>, LinearSolverDense, EdgeProjectXYZ2UV + RobustKernelHuber).
 //
-// One persistent workgroup (16 waves) runs the WHOLE Levenberg-Marquardt loop -- 50 outer iterations with their
-// data-dependent accept/reject trials -- in a single launch: the problem (a few MB) stays L2/LDS resident and
-// there is no host round trip per trial.  Several windows (sequences) run concurrently on different CUs.
-// Both dense contractions run on the f64 matrix cores (v_mfma_f64_16x16x4_f64):
-//   * pose blocks:  [H_pp | -b_p] = M^T M with M = sqrt(rho') * L_Omega * [J_pose | e] (2 rows per edge, K = 2 E_p)
-//   * Schur:        [sum_l W_l D_l^-1 W_l^T | sum_l W_l D_l^-1 b_l] = UT^T UT with UT[3l+k][6p+i] = (W_lp C_l)[i][k],
-//                   D_l^-1 = C_l C_l^T, and one extra column C_l^T b_l (a (6F+1)-wide SYRK over K = 3 L)
-// everything else (edge linearisation, 3x3 point blocks, back-substitution, SE3 exp update, robust chi2) is
-// per-edge / per-point VALU work; the reduced 6F x 6F system is LDL^T-factorised by one wave in LDS.
-// Arithmetic is f64 throughout like g2o.  Parity target: <= 1e-4 relative on poses / landmarks vs the oracle.
+// ONE persistent launch runs the whole Levenberg-Marquardt loop (50 outer iterations with their data-dependent
+// accept/reject trials): there is no host round trip per trial.  The window is split over G workgroups (one per
+// CU) by LANDMARK: a workgroup owns a contiguous range of landmarks and every observation (edge) of them, and
+// keeps ALL its per-edge / per-landmark state -- whitened Jacobians, landmark blocks, the landmarks themselves --
+// in its 160 KB LDS for the lifetime of the launch; G is chosen so that this fits.  Per-edge and per-landmark
+// phases are therefore workgroup-local LDS work.  Only three small reductions cross workgroups, each through a
+// counter barrier (agent-scope atomics, write-through partials, no L2 flush):
+//   * [H_pp | -b_p] pose blocks  = sum over edges of M^T M,   M = sqrt(rho') L_Omega [J_pose | e]     (7x7 / pose)
+//   * Schur blocks   sum_l W_l D_l^-1 W_l^T and sum_l W_l D_l^-1 b_l = U^T U with U = (W_l C_l), D_l^-1 = C_l C_l^T
+//   * robust chi2 / predicted decrease
+// The first two are accumulated on the f64 matrix cores (v_mfma_f64_16x16x4_f64): one MFMA per pair of edges /
+// per landmark (3 of the 4 k-slots carry the columns of U_l); after a barrier EVERY workgroup redundantly sums the
+// G partials in a fixed order, factorises the reduced 6F x 6F system (LDL^T, one wave, LDS) and takes the same
+// accept/reject decision -- no broadcast step.  All arithmetic is f64 like g2o and every reduction has a fixed
+// order (bit-reproducible runs).  Parity target: <= 1e-4 relative on poses / landmarks vs the oracle.
 #include "mvo_internal.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
 
-#define BA_THREADS 1024
-#define BA_WAVES 16
+#define BA_THREADS 512
+#define BA_WAVES 8
 #define BA_MAX_POSES 20
+#define BA_MFMA_MAX_NT 4  // matrix-core Schur path up to 64 rows (10 free poses + rhs); beyond: VALU loops
+#define BA_MSTRIDE 14     // doubles per edge in M: two rows [A~(6) | e~]
+#define BA_LDS_BUDGET (150 * 1024)
+#define BA_MAX_WGS 128
 
 struct BaStatsDev {
-    int iterations, trials, terminated, pad;
+    int iterations, trials, terminated, error;
     double chi2_initial, chi2_final, lambda_final;
 };
 
 struct BaDev {
-    int F, L, E, nfree, n, NT, W, KS, fix_points, max_it, use_mfma;
+    int F, L, E, G, nfree, n, NT, ntile, fix_points, max_it, use_mfma, maxEg, maxLg;
     double f, cx, cy, delta;
     double lc00, lc01, lc11;  // upper Cholesky factor of the information matrix: Omega = Lc^T Lc
     const double* poses_in;   // F x 16
     double* poses_out;        // F x 16
-    const double* pts_in;     // L x 3 initial landmarks (never written: the window can be re-solved)
-    double* pts;              // L x 3 working copy / result
-    double* pts_bak;          // L x 3
-    const int* e_pose;        // E (sorted by pose)
-    const int* e_point;       // E
+    const double* pts_in;     // L x 3
+    double* pts_out;          // L x 3
+    const int* wg_pt_start;   // G + 1   (landmark ranges)
+    const int* wg_edge_start; // G + 1   (edges sorted by owner workgroup, then pose)
+    const int* wg_pose_start; // G x (F + 1): absolute edge index where pose p starts inside workgroup g
+    const int* e_pose;        // E
+    const int* e_point;       // E (global landmark index)
     const double* e_uv;       // E x 2
-    const int* pose_edge_start;  // F + 1
-    const int* pose_slot;        // F: index among the free poses or -1
-    const int* pt_edge_start;    // L + 1
-    const int* pt_edge_list;     // E
-    const unsigned char* pt_free;  // L
-    double* M;     // E x 16: two rows [A~(6) | e~ | 0] per edge
-    double* Xt;    // E x 6:  X~ = sqrt(rho') Lc J_point (2 x 3)
-    double* Hll;   // L x 6 (xx xy xz yy yz zz)
-    double* bl;    // L x 3
-    double* Dinv;  // L x 6
-    double* Cc;    // L x 6 (c00 c10 c11 c20 c21 c22)
-    double* dxl;   // L x 3
-    double* UT;    // 3L x W
-    double* part;  // max(16, items) x 256
+    const int* pt_edge_start; // L + 1 -> pt_edge_list
+    const int* pt_edge_list;  // E absolute edge indices, grouped by landmark
+    const short* eof;         // L x nfree: LOCAL index of the first edge (landmark, pose slot), -1 if none
+    const short* dup_next;    // E: next LOCAL edge with the same (landmark, pose), -1 if none
+    const int* pose_slot;     // F
+    const int* slot_pose;     // nfree
+    // cross-workgroup exchange (agent-scope atomics only)
+    double* xHpp;             // G x F x 49
+    double* xG;               // G x ntile x 256
+    double* xSc;              // G x 4: chi2, scale, maxdiag
+    unsigned* barrier;        // monotonically increasing arrival counter (zeroed before every launch)
     BaStatsDev* stats;
 };
+
+// ------------------------------------------------------------------------------------------------ small helpers
+__device__ __forceinline__ void xstore(double* p, double v) {  // write-through (sc1) store
+    __hip_atomic_store(reinterpret_cast<u64*>(p), (u64)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xload(const double* p) {  // L1-bypassing (sc1) load
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -69,8 +89,7 @@ __device__ __forceinline__ double wave_max_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
-
-// deterministic block reductions (fixed lane order inside a wave, waves summed in index order)
+// deterministic block reductions (fixed lane order inside a wave, waves combined in index order)
 __device__ double block_sum(double v, double* scratch) {
     v = wave_sum_d(v);
     __syncthreads();
@@ -90,6 +109,34 @@ __device__ double block_max(double v, double* scratch) {
 #pragma unroll
     for (int w = 0; w < BA_WAVES; ++w) s = fmax(s, scratch[w]);
     return s;
+}
+
+// Grid barrier over the G co-resident workgroups: arrive on a monotonic counter, poll relaxed, bounded spin.
+// Every cross-workgroup datum is written with xstore (write-through) BEFORE and read with xload AFTER it, so no
+// release / acquire fence (L2 write-back / L1 invalidate) is needed.
+__device__ bool grid_barrier(const BaDev& B, unsigned& epoch, int* sFlag) {
+    if (B.G == 1) {
+        __syncthreads();
+        return true;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have left
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(B.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = epoch * (unsigned)B.G;
+        int ok = 0;
+        for (unsigned spin = 0; spin < (1u << 24); ++spin) {
+            if (__hip_atomic_load(B.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+                ok = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        sFlag[1] = ok;
+    }
+    __syncthreads();
+    return sFlag[1] != 0;
 }
 
 __device__ void quat_normalize(double* q) {
@@ -207,48 +254,208 @@ __device__ __forceinline__ void huber(double e, double delta, double& rho0, doub
     }
 }
 
-// EdgeProjectXYZ2UV::computeError with the information factor applied: returns chi2, fills whitened error
-__device__ __forceinline__ double edge_error(const BaDev& B, int e, const double* sR, const double* sT, double* Xc,
-                                             double* ew) {
-    const int p = B.e_pose[e], l = B.e_point[e];
+// LDS layout of one workgroup, carved from the dynamic segment.
+struct WgLds {
+    double* S;     // n x (n+1) reduced system
+    double* M;     // maxEg x 14
+    double* uv;    // maxEg x 2
+    double* pts;   // maxLg x 3
+    double* X;     // maxEg x 6   X~ = sqrt(rho') Lc J_point
+    double* Y;     // maxEg x 6   Y  = X~ C
+    double* bak;   // maxLg x 3
+    double* Hll;   // maxLg x 6
+    double* bl;    // maxLg x 3
+    double* Cc;    // maxLg x 6   Cholesky factor of (H_ll + lambda I)^-1
+    double* cl;    // maxLg x 3   C^T b_l
+    double* tile;  // ntile x 256
+    short* epose;  // maxEg
+    short* ept;    // maxEg  local landmark index
+    short* dup;    // maxEg  next local edge with the same (landmark, pose)
+    short* ptl;    // maxEg  local edge indices grouped by landmark
+    short* pts0;   // maxLg + 1 offsets into ptl
+    short* eof;    // maxLg x nfree
+};
+__host__ __device__ inline size_t wg_lds_doubles(int n, int ntile, int maxEg, int maxLg, int fix_points) {
+    size_t d = (size_t)n * (n + 1) + (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
+    if (!fix_points) d += (size_t)maxEg * 12 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256;
+    return d;
+}
+__host__ __device__ inline size_t wg_lds_bytes(int n, int ntile, int nfree, int maxEg, int maxLg, int fix_points) {
+    size_t shorts = (size_t)maxEg * 4 + (size_t)maxLg + 1 + (size_t)maxLg * (nfree > 0 ? nfree : 1);
+    return wg_lds_doubles(n, ntile, maxEg, maxLg, fix_points) * 8 + ((shorts * 2 + 15) & ~(size_t)15) + 64;
+}
+
+// EdgeProjectXYZ2UV::computeError with the information factor applied: returns chi2, fills the whitened error
+__device__ __forceinline__ double edge_error(const BaDev& B, const WgLds& W, int el, const double* sR,
+                                             const double* sT, double* Xc, double* ew) {
+    const int p = W.epose[el], l = W.ept[el];
     const double* R = sR + 9 * p;
     const double* t = sT + 3 * p;
-    const double X0 = B.pts[3 * l], X1 = B.pts[3 * l + 1], X2 = B.pts[3 * l + 2];
+    const double X0 = W.pts[3 * l], X1 = W.pts[3 * l + 1], X2 = W.pts[3 * l + 2];
     Xc[0] = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0];
     Xc[1] = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1];
     Xc[2] = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
-    const double e0 = B.e_uv[2 * e] - (Xc[0] / Xc[2] * B.f + B.cx);
-    const double e1 = B.e_uv[2 * e + 1] - (Xc[1] / Xc[2] * B.f + B.cy);
+    const double e0 = W.uv[2 * el] - (Xc[0] / Xc[2] * B.f + B.cx);
+    const double e1 = W.uv[2 * el + 1] - (Xc[1] / Xc[2] * B.f + B.cy);
     ew[0] = B.lc00 * e0 + B.lc01 * e1;
     ew[1] = B.lc11 * e1;
     return ew[0] * ew[0] + ew[1] * ew[1];
 }
 
-__device__ double robust_chi2(const BaDev& B, const double* sR, const double* sT, double* scratch) {
+__device__ double robust_chi2_local(const BaDev& B, const WgLds& W, int Eg, const double* sR, const double* sT,
+                                    double* scratch) {
     double s = 0;
-    for (int e = threadIdx.x; e < B.E; e += BA_THREADS) {
+    for (int el = threadIdx.x; el < Eg; el += BA_THREADS) {
         double Xc[3], ew[2], r0, r1;
-        huber(edge_error(B, e, sR, sT, Xc, ew), B.delta, r0, r1);
+        huber(edge_error(B, W, el, sR, sT, Xc, ew), B.delta, r0, r1);
         s += r0;
     }
     return block_sum(s, scratch);
 }
 
+// row `row` of U_l (landmark l, k-slot k < 3): pose slot row/6, component row%6 -> sum over the (landmark, pose)
+// edges of A~^T Y; row n is C_l^T b_l (the rhs column); rows beyond are zero padding.
+__device__ __forceinline__ double u_entry(const WgLds& W, int nfree, int n, int l, int row, int k) {
+    if (row < n) {
+        const int sl = row / 6, c = row - 6 * sl;
+        int el = W.eof[l * nfree + sl];
+        double v = 0;
+        while (el >= 0) {
+            v += W.M[BA_MSTRIDE * el + c] * W.Y[6 * el + k] + W.M[BA_MSTRIDE * el + 7 + c] * W.Y[6 * el + 3 + k];
+            el = W.dup[el];
+        }
+        return v;
+    }
+    return row == n ? W.cl[3 * l + k] : 0.0;
+}
+
+// partial G = U^T U over the own landmarks: every wave takes every 8th landmark, one MFMA per landmark and
+// tile pair (k-slots 0..2 = columns of U_l, slot 3 = 0); the waves' accumulators are combined in wave order.
+template <int NT>
+__device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int wave) {
+    constexpr int NPAIR = NT * (NT + 1) / 2;
+    v4d acc[NPAIR];
+#pragma unroll
+    for (int a = 0; a < NPAIR; ++a) acc[a] = (v4d){0, 0, 0, 0};
+    const int k = lane >> 4, i = lane & 15;
+    for (int l = wave; l < Lg; l += BA_WAVES) {
+        double op[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) op[t] = k < 3 ? u_entry(W, B.nfree, B.n, l, 16 * t + i, k) : 0.0;
+        int a = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = ti; tj < NT; ++tj, ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[a], 0, 0, 0);
+    }
+    for (int w = 0; w < BA_WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < NPAIR; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int idx = a * 256 + 16 * ((lane >> 4) + 4 * j) + (lane & 15);
+                    W.tile[idx] = (w == 0 ? 0.0 : W.tile[idx]) + acc[a][j];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// the same sums with plain loops (validation path, and windows with more than 10 free poses)
+__device__ void schur_valu(const BaDev& B, const WgLds& W, int Lg) {
+    for (int idx = threadIdx.x; idx < B.ntile * 256; idx += BA_THREADS) {
+        const int tl = idx / 256, r = (idx % 256) / 16, c = idx % 16;
+        int ti = 0, rem = tl;
+        while (rem >= B.NT - ti) {
+            rem -= B.NT - ti;
+            ++ti;
+        }
+        const int tj = ti + rem, ra = 16 * ti + r, rb = 16 * tj + c;
+        double s = 0;
+        if (ra <= B.n && rb <= B.n)
+            for (int l = 0; l < Lg; ++l)
+                for (int k = 0; k < 3; ++k) s += u_entry(W, B.nfree, B.n, l, ra, k) * u_entry(W, B.nfree, B.n, l, rb, k);
+        W.tile[idx] = s;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
-    extern __shared__ __attribute__((aligned(16))) double S[];  // n x (n+1) reduced system, then scratch
+    extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double sP[BA_MAX_POSES * 8], sPbak[BA_MAX_POSES * 8];  // q[4] t[3] pad
     __shared__ double sR[BA_MAX_POSES * 9], sT[BA_MAX_POSES * 3];
     __shared__ double sHpp[BA_MAX_POSES * 36], sBp[BA_MAX_POSES * 6], sDx[BA_MAX_POSES * 6];
     __shared__ double sPart[BA_WAVES * 49];
     __shared__ double sScr[BA_WAVES];
     __shared__ double sLcol[6 * BA_MAX_POSES], sCol[6 * BA_MAX_POSES];
+    __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ int sFlag[4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = blockIdx.x;
     const int n = B.n, ld = n + 1;
+    const int pt_lo = B.wg_pt_start[g], Lg = B.wg_pt_start[g + 1] - pt_lo;
+    const int e_lo = B.wg_edge_start[g], Eg = B.wg_edge_start[g + 1] - e_lo;
+    unsigned epoch = 0;
 
-    // ---- load poses: T_w_c.inv() -> SE3Quat(R, t)  (g2o_ba.cpp:185-190, 208-215)
-    if (tid < B.F) {
+    // ---- carve the dynamic LDS
+    WgLds W;
+    {
+        double* d = dyn;
+        W.S = d;
+        d += (size_t)n * (n + 1);
+        W.M = d;
+        d += (size_t)B.maxEg * BA_MSTRIDE;
+        W.uv = d;
+        d += (size_t)B.maxEg * 2;
+        W.pts = d;
+        d += (size_t)B.maxLg * 3;
+        W.X = W.Y = W.bak = W.Hll = W.bl = W.Cc = W.cl = W.tile = nullptr;
+        if (!B.fix_points) {
+            W.X = d;
+            d += (size_t)B.maxEg * 6;
+            W.Y = d;
+            d += (size_t)B.maxEg * 6;
+            W.bak = d;
+            d += (size_t)B.maxLg * 3;
+            W.Hll = d;
+            d += (size_t)B.maxLg * 6;
+            W.bl = d;
+            d += (size_t)B.maxLg * 3;
+            W.Cc = d;
+            d += (size_t)B.maxLg * 6;
+            W.cl = d;
+            d += (size_t)B.maxLg * 3;
+            W.tile = d;
+            d += (size_t)B.ntile * 256;
+        }
+        short* s = reinterpret_cast<short*>(d);
+        W.epose = s;
+        s += B.maxEg;
+        W.ept = s;
+        s += B.maxEg;
+        W.dup = s;
+        s += B.maxEg;
+        W.ptl = s;
+        s += B.maxEg;
+        W.pts0 = s;
+        s += B.maxLg + 1;
+        W.eof = s;
+    }
+    // ---- load the workgroup's slice: edges, landmarks, adjacency; every workgroup holds all poses
+    for (int el = tid; el < Eg; el += BA_THREADS) {
+        W.epose[el] = (short)B.e_pose[e_lo + el];
+        W.ept[el] = (short)(B.e_point[e_lo + el] - pt_lo);
+        W.dup[el] = B.dup_next[e_lo + el];
+        W.ptl[el] = (short)(B.pt_edge_list[e_lo + el] - e_lo);
+        W.uv[2 * el] = B.e_uv[2 * (size_t)(e_lo + el)];
+        W.uv[2 * el + 1] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
+    }
+    for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = B.pts_in[3 * (size_t)pt_lo + i];
+    for (int i = tid; i <= Lg; i += BA_THREADS) W.pts0[i] = (short)(B.pt_edge_start[pt_lo + i] - e_lo);
+    for (int i = tid; i < Lg * B.nfree; i += BA_THREADS) W.eof[i] = B.eof[(size_t)pt_lo * B.nfree + i];
+    if (tid < B.F) {  // T_w_c.inv() -> SE3Quat(R, t)  (g2o_ba.cpp:185-190, 208-215)
         double Ri[9], ti[3], q[4];
         invert_Rt(B.poses_in + 16 * tid, Ri, ti);
         quat_from_R(Ri, q);
@@ -257,45 +464,59 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
         for (int i = 0; i < 3; ++i) sP[8 * tid + 4 + i] = ti[i];
         quat_to_R(q, sR + 9 * tid);
         for (int i = 0; i < 3; ++i) sT[3 * tid + i] = ti[i];
+        sSlot[tid] = B.pose_slot[tid];
     }
-    for (int i = tid; i < 3 * B.L; i += BA_THREADS) B.pts[i] = B.pts_in[i];
+    if (tid < B.nfree) sSlotPose[tid] = B.slot_pose[tid];
+    if (tid <= B.F) sPoseStart[tid] = B.wg_pose_start[g * (B.F + 1) + tid] - e_lo;
     __syncthreads();
 
     double lambda = 0, ni = 2;
-    int it = 0, trials = 0, terminated = 0;
-    double currentChi = robust_chi2(B, sR, sT, sScr);
+    int it = 0, trials = 0, terminated = 0, error = 0;
+    // ---- initial robust chi2 (all workgroups)
+    double currentChi;
+    {
+        double c = robust_chi2_local(B, W, Eg, sR, sT, sScr);
+        if (B.G > 1) {
+            if (tid == 0) xstore(B.xSc + 4 * g, c);
+            if (!grid_barrier(B, epoch, sFlag)) error = 1;
+            c = 0;
+            for (int w = 0; w < B.G; ++w) c += xload(B.xSc + 4 * w);
+            if (!grid_barrier(B, epoch, sFlag)) error = 1;  // xSc is reused below
+        }
+        currentChi = c;
+    }
     const double chi0 = currentChi;
     const bool any_free = B.nfree > 0 || !B.fix_points;
+    const bool do_schur = !B.fix_points && n > 0;
 
-    for (it = 0; any_free && it < B.max_it; ++it) {
-        // ================= LIN: per-edge whitened Jacobians (EdgeProjectXYZ2UV::linearizeOplus)
-        for (int e = tid; e < B.E; e += BA_THREADS) {
+    for (it = 0; any_free && !error && it < B.max_it; ++it) {
+        // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus)
+        for (int el = tid; el < Eg; el += BA_THREADS) {
             double Xc[3], ew[2], r0, r1;
-            const double chi = edge_error(B, e, sR, sT, Xc, ew);
+            const double chi = edge_error(B, W, el, sR, sT, Xc, ew);
             huber(chi, B.delta, r0, r1);
             const double sw = sqrt(r1);
-            const int p = B.e_pose[e];
+            const int p = W.epose[el];
             const double x = Xc[0], y = Xc[1], z = Xc[2], z2 = z * z, f = B.f;
-            double* Mr = B.M + 16 * (size_t)e;
-            if (B.pose_slot[p] >= 0) {
+            double* Mr = W.M + BA_MSTRIDE * el;
+            if (sSlot[p] >= 0) {
                 const double J0[6] = {x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f};
                 const double J1[6] = {(1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f};
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     Mr[c] = sw * (B.lc00 * J0[c] + B.lc01 * J1[c]);
-                    Mr[8 + c] = sw * (B.lc11 * J1[c]);
+                    Mr[7 + c] = sw * (B.lc11 * J1[c]);
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) Mr[c] = Mr[8 + c] = 0;
+                for (int c = 0; c < 6; ++c) Mr[c] = Mr[7 + c] = 0;
             }
             Mr[6] = sw * ew[0];
-            Mr[14] = sw * ew[1];
-            Mr[7] = Mr[15] = 0;
+            Mr[13] = sw * ew[1];
             if (!B.fix_points) {
                 const double* R = sR + 9 * p;
                 const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};
-                double* Xr = B.Xt + 6 * (size_t)e;
+                double* Xr = W.X + 6 * el;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);
@@ -306,10 +527,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             }
         }
         __syncthreads();
-        // ================= HPP: [H_pp | -b_p] = M^T M per free pose
+        // ================= HPP: partial [H_pp | -b_p] = M^T M over the own edges of every free pose
         for (int p = 0; p < B.F; ++p) {
-            if (B.pose_slot[p] < 0) continue;
-            const int s = B.pose_edge_start[p], e = B.pose_edge_start[p + 1];
+            if (sSlot[p] < 0) continue;
+            const int s = sPoseStart[p], e = sPoseStart[p + 1];
             if (B.use_mfma) {
                 const int steps = (2 * (e - s) + 3) / 4;
                 v4d acc = {0, 0, 0, 0};
@@ -317,7 +538,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                 for (int st = wave; st < steps; st += BA_WAVES) {
                     const int row = 4 * st + (lane >> 4);
                     const int ed = s + (row >> 1);
-                    double v = (ed < e && col < 8) ? B.M[16 * (size_t)ed + 8 * (row & 1) + col] : 0.0;
+                    double v = (ed < e && col < 7) ? W.M[BA_MSTRIDE * ed + 7 * (row & 1) + col] : 0.0;
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
                 }
 #pragma unroll
@@ -327,34 +548,39 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                 }
                 __syncthreads();
                 if (tid < 49) {
-                    double g = 0;
+                    double gsum = 0;
 #pragma unroll
-                    for (int w = 0; w < BA_WAVES; ++w) g += sPart[w * 49 + tid];
-                    const int i = tid / 7, j = tid % 7;
-                    if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = g;
-                    if (i < 6 && j == 6) sBp[6 * p + i] = -g;
+                    for (int w = 0; w < BA_WAVES; ++w) gsum += sPart[w * 49 + tid];
+                    sPart[tid] = gsum;  // own slot of wave 0: only this thread reads it again
                 }
             } else {
                 if (tid < 49) {
                     const int i = tid / 7, j = tid % 7;
-                    double g = 0;
-                    for (int r = 2 * s; r < 2 * e; ++r) g += B.M[8 * (size_t)r + i] * B.M[8 * (size_t)r + j];
-                    if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = g;
-                    if (i < 6 && j == 6) sBp[6 * p + i] = -g;
+                    double gsum = 0;
+                    for (int r = 2 * s; r < 2 * e; ++r) gsum += W.M[7 * r + i] * W.M[7 * r + j];
+                    sPart[tid] = gsum;
+                }
+            }
+            if (tid < 49) {
+                if (B.G > 1) {
+                    xstore(B.xHpp + ((size_t)g * B.F + p) * 49 + tid, sPart[tid]);
+                } else {
+                    const int i = tid / 7, j = tid % 7;
+                    if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = sPart[tid];
+                    if (i < 6 && j == 6) sBp[6 * p + i] = -sPart[tid];
                 }
             }
             __syncthreads();
         }
-        // ================= PT: 3x3 point blocks H_ll, b_l
+        // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks
         double maxdiag = 0;
         if (!B.fix_points) {
-            for (int l = tid; l < B.L; l += BA_THREADS) {
-                if (!B.pt_free[l]) continue;
+            for (int l = tid; l < Lg; l += BA_THREADS) {
                 double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-                for (int k = B.pt_edge_start[l]; k < B.pt_edge_start[l + 1]; ++k) {
-                    const int e = B.pt_edge_list[k];
-                    const double* X = B.Xt + 6 * (size_t)e;
-                    const double e0 = B.M[16 * (size_t)e + 6], e1 = B.M[16 * (size_t)e + 14];
+                for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
+                    const int el = W.ptl[k];
+                    const double* X = W.X + 6 * el;
+                    const double e0 = W.M[BA_MSTRIDE * el + 6], e1 = W.M[BA_MSTRIDE * el + 13];
                     h[0] += X[0] * X[0] + X[3] * X[3];
                     h[1] += X[0] * X[1] + X[3] * X[4];
                     h[2] += X[0] * X[2] + X[3] * X[5];
@@ -366,16 +592,39 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                     b[2] -= X[2] * e0 + X[5] * e1;
                 }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) B.Hll[6 * (size_t)l + i] = h[i];
+                for (int i = 0; i < 6; ++i) W.Hll[6 * l + i] = h[i];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) B.bl[3 * (size_t)l + i] = b[i];
+                for (int i = 0; i < 3; ++i) W.bl[3 * l + i] = b[i];
                 maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
             }
         }
+        if (it == 0 && B.G > 1) {
+            double m = block_max(maxdiag, sScr);
+            if (tid == 0) xstore(B.xSc + 4 * g + 2, m);
+        }
+        // ---- exchange: pose-block partials (+ the landmark max diagonal at iteration 0)
+        if (B.G > 1) {
+            if (!grid_barrier(B, epoch, sFlag)) error = 1;
+            if (tid < 49 * B.F) {
+                const int p = tid / 49, r = tid % 49;
+                if (sSlot[p] >= 0) {
+                    double gsum = 0;
+                    for (int w = 0; w < B.G; ++w) gsum += xload(B.xHpp + ((size_t)w * B.F + p) * 49 + r);
+                    const int i = r / 7, j = r % 7;
+                    if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = gsum;
+                    if (i < 6 && j == 6) sBp[6 * p + i] = -gsum;
+                }
+            }
+            if (it == 0) {
+                maxdiag = 0;
+                for (int w = 0; w < B.G; ++w) maxdiag = fmax(maxdiag, xload(B.xSc + 4 * w + 2));
+            }
+            __syncthreads();
+        }
         if (it == 0) {  // computeLambdaInit: tau * max |diag H| over the free vertices
-            if (tid < 6 * B.F && B.pose_slot[tid / 6] >= 0)
-                maxdiag = fmax(maxdiag, fabs(sHpp[36 * (tid / 6) + 7 * (tid % 6)]));
-            lambda = 1e-5 * block_max(maxdiag, sScr);
+            double m = maxdiag;
+            if (tid < 6 * B.F && sSlot[tid / 6] >= 0) m = fmax(m, fabs(sHpp[36 * (tid / 6) + 7 * (tid % 6)]));
+            lambda = 1e-5 * block_max(m, sScr);
             ni = 2;
         }
         __syncthreads();
@@ -383,138 +632,89 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
         double rho = 0;
         int qmax = 0;
         do {
-            // ============= T1: D^-1 = (H_ll + lambda I)^-1 = C C^T, UT rows of every free point
+            // ============= T1: (H_ll + lambda I)^-1 = C C^T, C^T b_l; Y = X~ C for the own edges
             if (!B.fix_points) {
-                for (int l = tid; l < B.L; l += BA_THREADS) {
-                    if (!B.pt_free[l]) continue;
-                    const double* h = B.Hll + 6 * (size_t)l;
+                for (int l = tid; l < Lg; l += BA_THREADS) {
+                    const double* h = W.Hll + 6 * l;
                     const double D[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
                     double Di[9];
                     inv3(D, Di);
-                    double* di = B.Dinv + 6 * (size_t)l;
-                    di[0] = Di[0];
-                    di[1] = Di[1];
-                    di[2] = Di[2];
-                    di[3] = Di[4];
-                    di[4] = Di[5];
-                    di[5] = Di[8];
-                    // Cholesky D^-1 = C C^T (lower)
                     const double c00 = sqrt(Di[0]), c10 = Di[3] / c00, c20 = Di[6] / c00;
                     const double c11 = sqrt(Di[4] - c10 * c10), c21 = (Di[7] - c20 * c10) / c11;
                     const double c22 = sqrt(Di[8] - c20 * c20 - c21 * c21);
-                    double* cc = B.Cc + 6 * (size_t)l;
+                    double* cc = W.Cc + 6 * l;
                     cc[0] = c00;
                     cc[1] = c10;
                     cc[2] = c11;
                     cc[3] = c20;
                     cc[4] = c21;
                     cc[5] = c22;
-                    const double* b = B.bl + 3 * (size_t)l;
-                    double* u0 = B.UT + (size_t)(3 * l) * B.W;
-                    double* u1 = u0 + B.W;
-                    double* u2 = u1 + B.W;
-                    // extra column n: C^T b_l
-                    u0[n] = c00 * b[0] + c10 * b[1] + c20 * b[2];
-                    u1[n] = c11 * b[1] + c21 * b[2];
-                    u2[n] = c22 * b[2];
-                    const int k0 = B.pt_edge_start[l], k1 = B.pt_edge_start[l + 1];
-                    for (int k = k0; k < k1; ++k) {
-                        const int sl = B.pose_slot[B.e_pose[B.pt_edge_list[k]]];
-                        if (sl < 0) continue;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) u0[6 * sl + i] = u1[6 * sl + i] = u2[6 * sl + i] = 0;
-                    }
-                    for (int k = k0; k < k1; ++k) {
-                        const int e = B.pt_edge_list[k];
-                        const int sl = B.pose_slot[B.e_pose[e]];
-                        if (sl < 0) continue;
-                        const double* X = B.Xt + 6 * (size_t)e;
-                        const double* A = B.M + 16 * (size_t)e;
-                        // Y = X~ C (2 x 3)
-                        const double y00 = X[0] * c00 + X[1] * c10 + X[2] * c20, y01 = X[1] * c11 + X[2] * c21,
-                                     y02 = X[2] * c22;
-                        const double y10 = X[3] * c00 + X[4] * c10 + X[5] * c20, y11 = X[4] * c11 + X[5] * c21,
-                                     y12 = X[5] * c22;
-#pragma unroll
-                        for (int i = 0; i < 6; ++i) {  // U = A~^T Y (6 x 3), accumulated (duplicate edges add up)
-                            u0[6 * sl + i] += A[i] * y00 + A[8 + i] * y10;
-                            u1[6 * sl + i] += A[i] * y01 + A[8 + i] * y11;
-                            u2[6 * sl + i] += A[i] * y02 + A[8 + i] * y12;
-                        }
-                    }
+                    const double* b = W.bl + 3 * l;
+                    W.cl[3 * l] = c00 * b[0] + c10 * b[1] + c20 * b[2];
+                    W.cl[3 * l + 1] = c11 * b[1] + c21 * b[2];
+                    W.cl[3 * l + 2] = c22 * b[2];
+                }
+                __syncthreads();
+                for (int el = tid; el < Eg; el += BA_THREADS) {
+                    const double* X = W.X + 6 * el;
+                    const double* cc = W.Cc + 6 * W.ept[el];
+                    double* Yr = W.Y + 6 * el;
+                    Yr[0] = X[0] * cc[0] + X[1] * cc[1] + X[2] * cc[3];
+                    Yr[1] = X[1] * cc[2] + X[2] * cc[4];
+                    Yr[2] = X[2] * cc[5];
+                    Yr[3] = X[3] * cc[0] + X[4] * cc[1] + X[5] * cc[3];
+                    Yr[4] = X[4] * cc[2] + X[5] * cc[4];
+                    Yr[5] = X[5] * cc[5];
+                }
+                __syncthreads();
+            }
+            // ============= T2: partial Schur blocks of the own landmarks, published for the other workgroups
+            if (do_schur) {
+                if (B.use_mfma && B.NT <= BA_MFMA_MAX_NT) {
+                    if (B.NT == 1) schur_mfma<1>(B, W, Lg, lane, wave);
+                    else if (B.NT == 2) schur_mfma<2>(B, W, Lg, lane, wave);
+                    else if (B.NT == 3) schur_mfma<3>(B, W, Lg, lane, wave);
+                    else schur_mfma<4>(B, W, Lg, lane, wave);
+                } else {
+                    schur_valu(B, W, Lg);
+                }
+                if (B.G > 1) {
+                    for (int idx = tid; idx < B.ntile * 256; idx += BA_THREADS)
+                        xstore(B.xG + (size_t)g * B.ntile * 256 + idx, W.tile[idx]);
+                    if (!grid_barrier(B, epoch, sFlag)) error = 1;
                 }
             }
-            __syncthreads();
-            // ============= T2: G = UT^T UT (upper tiles) on the matrix cores, K = 3 L split over the waves
-            const int ntile = B.NT * (B.NT + 1) / 2;
-            const int K = 3 * B.L;
-            if (!B.fix_points && n > 0) {
-                if (B.use_mfma) {
-                    const int Kc = ((K + B.KS - 1) / B.KS + 3) & ~3;
-                    for (int item = wave; item < ntile * B.KS; item += BA_WAVES) {
-                        const int tl = item / B.KS, ck = item - tl * B.KS;
-                        int ti = 0, rem = tl;  // tl -> (ti <= tj), row-major over the upper triangle
-                        while (rem >= B.NT - ti) {
-                            rem -= B.NT - ti;
-                            ++ti;
-                        }
-                        const int tj = ti + rem;
-                        v4d acc = {0, 0, 0, 0};
-                        const int kend = min(K, (ck + 1) * Kc);
-                        for (int kk0 = ck * Kc; kk0 < kend; kk0 += 4) {
-                            const int kk = kk0 + (lane >> 4);
-                            double a = 0, b = 0;
-                            if (kk < kend) {
-                                a = B.UT[(size_t)kk * B.W + 16 * ti + (lane & 15)];
-                                b = B.UT[(size_t)kk * B.W + 16 * tj + (lane & 15)];
-                            }
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            B.part[256 * (size_t)item + 16 * ((lane >> 4) + 4 * j) + (lane & 15)] = acc[j];
-                    }
-                }
-            }
-            __syncthreads();
-            // ============= T3: assemble S = H_pp + lambda I - G, g = b_p - G[:, n]; LDL^T by wave 0
+            // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n]; LDL^T by wave 0
             for (int idx = tid; idx < n * ld; idx += BA_THREADS) {
                 const int i = idx / ld, j = idx - i * ld;
-                double g = 0;
-                if (!B.fix_points) {
-                    if (B.use_mfma) {
-                        int a = i, b = j;
-                        if (a / 16 > b / 16) {
-                            a = j;
-                            b = i;
-                        }
-                        const int ti = a / 16, tj = b / 16;
-                        const int tl = ti * B.NT - ti * (ti - 1) / 2 + (tj - ti);
-                        for (int ck = 0; ck < B.KS; ++ck) g += B.part[256 * (size_t)(tl * B.KS + ck) + 16 * (a % 16) + (b % 16)];
-                    } else {
-                        for (int kk = 0; kk < K; ++kk) g += B.UT[(size_t)kk * B.W + i] * B.UT[(size_t)kk * B.W + j];
+                double gsum = 0;
+                if (do_schur) {
+                    int a = i, b = j;
+                    if (a / 16 > b / 16) {
+                        a = j;
+                        b = i;
                     }
+                    const int ti = a / 16, tj = b / 16;
+                    const int tl = ti * B.NT - ti * (ti - 1) / 2 + (tj - ti);
+                    const size_t off = (size_t)tl * 256 + 16 * (a % 16) + (b % 16);
+                    if (B.G > 1)
+                        for (int w = 0; w < B.G; ++w) gsum += xload(B.xG + (size_t)w * B.ntile * 256 + off);
+                    else
+                        gsum = W.tile[off];
                 }
+                const int pi = sSlotPose[i / 6];
                 double v;
-                // slot -> pose lookup through sCol is avoided: free poses keep their order, find pose of slot i/6
-                int pi = -1, pj = -1;
-                {
-                    int si = i / 6, sj = j / 6, c = 0;
-                    for (int p = 0; p < B.F; ++p) {
-                        if (B.pose_slot[p] < 0) continue;
-                        if (c == si) pi = p;
-                        if (c == sj) pj = p;
-                        ++c;
-                    }
+                if (j == n) {
+                    v = sBp[6 * pi + i % 6] - gsum;
+                } else {
+                    const int pj = sSlotPose[j / 6];
+                    v = ((pi == pj) ? sHpp[36 * pi + 6 * (i % 6) + (j % 6)] + (i == j ? lambda : 0.0) : 0.0) - gsum;
                 }
-                if (j == n)
-                    v = sBp[6 * pi + i % 6] - g;
-                else
-                    v = ((pi == pj) ? sHpp[36 * pi + 6 * (i % 6) + (j % 6)] + (i == j ? lambda : 0.0) : 0.0) - g;
-                S[idx] = v;
+                W.S[idx] = v;
             }
             __syncthreads();
             if (wave == 0) {
+                double* S = W.S;
                 int ok = 1;
                 for (int j = 0; j < n; ++j) {
                     const double d = S[j * ld + j];
@@ -551,58 +751,72 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             __syncthreads();
             const int ok2 = sFlag[0];
             if (tid < 6 * B.F) {
-                const int sl = B.pose_slot[tid / 6];
-                sDx[tid] = (ok2 && sl >= 0) ? S[(6 * sl + tid % 6) * ld + n] : 0.0;
+                const int sl = sSlot[tid / 6];
+                sDx[tid] = (ok2 && sl >= 0) ? W.S[(6 * sl + tid % 6) * ld + n] : 0.0;
             }
             __syncthreads();
             ++trials;
-            // ============= T4/T5: back-substitute the points, computeScale, push + apply the update
+            // ============= T4/T5: back-substitute the own landmarks, computeScale, push + apply the update
             double scale = 0;
-            if (tid < 6 * B.F && B.pose_slot[tid / 6] >= 0) scale += sDx[tid] * (lambda * sDx[tid] + sBp[tid]);
+            if (g == 0 && tid < 6 * B.F && sSlot[tid / 6] >= 0) scale += sDx[tid] * (lambda * sDx[tid] + sBp[tid]);
             if (!B.fix_points) {
-                for (int l = tid; l < B.L; l += BA_THREADS) {
-                    if (!B.pt_free[l]) continue;
-                    const double* b = B.bl + 3 * (size_t)l;
-                    double r[3] = {b[0], b[1], b[2]};
-                    for (int k = B.pt_edge_start[l]; k < B.pt_edge_start[l + 1]; ++k) {
-                        const int e = B.pt_edge_list[k];
-                        const int p = B.e_pose[e];
-                        if (B.pose_slot[p] < 0) continue;
-                        const double* A = B.M + 16 * (size_t)e;
-                        const double* X = B.Xt + 6 * (size_t)e;
+                for (int l = tid; l < Lg; l += BA_THREADS) {
+                    double r[3] = {W.cl[3 * l], W.cl[3 * l + 1], W.cl[3 * l + 2]};  // C^T (b_l - sum W^T dx_p)
+                    for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
+                        const int el = W.ptl[k];
+                        const int p = W.epose[el];
+                        if (sSlot[p] < 0) continue;
+                        const double* A = W.M + BA_MSTRIDE * el;
+                        const double* Yr = W.Y + 6 * el;
                         double a0 = 0, a1 = 0;  // A~ dx_p
 #pragma unroll
                         for (int i = 0; i < 6; ++i) {
                             a0 += A[i] * sDx[6 * p + i];
-                            a1 += A[8 + i] * sDx[6 * p + i];
+                            a1 += A[7 + i] * sDx[6 * p + i];
                         }
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) r[c] -= X[c] * a0 + X[3 + c] * a1;  // W^T dx_p
+                        for (int c = 0; c < 3; ++c) r[c] -= Yr[c] * a0 + Yr[3 + c] * a1;
                     }
-                    const double* di = B.Dinv + 6 * (size_t)l;
-                    double d[3] = {di[0] * r[0] + di[1] * r[1] + di[2] * r[2], di[1] * r[0] + di[3] * r[1] + di[4] * r[2],
-                                   di[2] * r[0] + di[4] * r[1] + di[5] * r[2]};
+                    const double* cc = W.Cc + 6 * l;
+                    double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
                     if (!ok2) d[0] = d[1] = d[2] = 0;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        scale += d[c] * (lambda * d[c] + b[c]);
-                        B.pts_bak[3 * (size_t)l + c] = B.pts[3 * (size_t)l + c];
-                        B.pts[3 * (size_t)l + c] += d[c];
+                        scale += d[c] * (lambda * d[c] + W.bl[3 * l + c]);
+                        W.bak[3 * l + c] = W.pts[3 * l + c];
+                        W.pts[3 * l + c] += d[c];
                     }
                 }
             }
             if (tid < B.F) {
                 for (int i = 0; i < 8; ++i) sPbak[8 * tid + i] = sP[8 * tid + i];
-                if (B.pose_slot[tid] >= 0) {
+                if (sSlot[tid] >= 0) {
                     pose_oplus(sP + 8 * tid, sDx + 6 * tid);
                     quat_to_R(sP + 8 * tid, sR + 9 * tid);
                     for (int i = 0; i < 3; ++i) sT[3 * tid + i] = sP[8 * tid + 4 + i];
                 }
             }
-            scale = block_sum(scale, sScr) + 1e-3;
+            scale = block_sum(scale, sScr);
             __syncthreads();
-            // ============= T6/T7: robust chi2 at the trial state, accept / reject
-            double tempChi = robust_chi2(B, sR, sT, sScr);
+            // ============= T6/T7: robust chi2 at the trial state, identical accept / reject decision everywhere
+            double tempChi = robust_chi2_local(B, W, Eg, sR, sT, sScr);
+            if (B.G > 1) {
+                if (tid == 0) {
+                    xstore(B.xSc + 4 * g, tempChi);
+                    xstore(B.xSc + 4 * g + 1, scale);
+                }
+                if (!grid_barrier(B, epoch, sFlag)) error = 1;
+                tempChi = 0;
+                scale = 0;
+                for (int w = 0; w < B.G; ++w) {
+                    tempChi += xload(B.xSc + 4 * w);
+                    scale += xload(B.xSc + 4 * w + 1);
+                }
+                // xSc / xHpp must not be overwritten before everyone has read them: with a Schur phase the next
+                // writes sit behind its barrier; without one (pose-only BA, no free pose) close the phase here
+                if (!do_schur && !grid_barrier(B, epoch, sFlag)) error = 1;
+            }
+            scale += 1e-3;
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = (currentChi - tempChi) / scale;
             if (rho > 0 && isfinite(tempChi)) {
@@ -621,21 +835,21 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                     for (int i = 0; i < 3; ++i) sT[3 * tid + i] = sP[8 * tid + 4 + i];
                 }
                 if (!B.fix_points)
-                    for (int l = tid; l < B.L; l += BA_THREADS)
-                        if (B.pt_free[l])
-                            for (int c = 0; c < 3; ++c) B.pts[3 * (size_t)l + c] = B.pts_bak[3 * (size_t)l + c];
+                    for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = W.bak[i];
             }
             __syncthreads();
             ++qmax;
-        } while (rho < 0 && qmax < 10);
-        if (qmax == 10 || rho == 0) {
+        } while (rho < 0 && qmax < 10 && !error);
+        if (qmax == 10 || rho == 0 || error) {
             terminated = 1;
             ++it;
             break;
         }
+        // a Schur-less window has no barrier between this iteration's xSc reads and the next xHpp/xSc writes
+        // other than the one above; with Schur, the xHpp writes of the next iteration are behind the xSc barrier
     }
-    // ---- write-back (g2o_ba.cpp:298-305): SE3Quat -> (R, t) -> 4x4 -> inverse
-    if (tid < B.F) {
+    // ---- write-back (g2o_ba.cpp:298-316): SE3Quat -> (R, t) -> 4x4 -> inverse; landmarks of the own range
+    if (g == 0 && tid < B.F) {
         double R[9], T[16] = {0}, Ri[9], ti[3];
         quat_to_R(sP + 8 * tid, R);
         for (int r = 0; r < 3; ++r) {
@@ -652,10 +866,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
         o[12] = o[13] = o[14] = 0;
         o[15] = 1;
     }
-    if (tid == 0) {
+    for (int i = tid; i < 3 * Lg; i += BA_THREADS) B.pts_out[3 * (size_t)pt_lo + i] = W.pts[i];
+    if (g == 0 && tid == 0) {
         B.stats->iterations = it;
         B.stats->trials = trials;
         B.stats->terminated = terminated;
+        B.stats->error = error;
         B.stats->chi2_initial = chi0;
         B.stats->chi2_final = currentChi;
         B.stats->lambda_final = lambda;
@@ -674,15 +890,16 @@ struct Carver {
 };
 }  // namespace
 
-int g_ba_use_mfma = 1;  // debug knob (mvo_debug_set)
+int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
+int g_ba_wgs = 0;       // 0 = automatic
 
 // A window whose inputs are resident in HBM: upload once (mvo_ba_prepare), solve any number of times.
 struct mvo_ba_handle {
-    char* dev = nullptr;  // one allocation holding inputs, CSR tables and workspace
+    char* dev = nullptr;  // one allocation holding inputs, adjacency tables and exchange buffers
     size_t bytes = 0;
     BaDev B{};
     int F = 0, L = 0;
-    size_t o_stats = 0, o_pout = 0, o_pts = 0;
+    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0;
     size_t lds = 16;
     bool fix_points = false;
 };
@@ -696,60 +913,116 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     if (!(a > 0) || std::fabs(b - c) > 1e-12 * (std::fabs(a) + std::fabs(d)) || !(a * d - b * b > 0))
         return mvo_set_err(ctx, MVO_ERR_INVALID, "information matrix must be symmetric positive definite", hipSuccess);
     const double lc00 = std::sqrt(a), lc01 = b / lc00, lc11 = std::sqrt(d - lc01 * lc01);
-    // drop edges whose vertices are all fixed (SparseOptimizer::initializeOptimization), sort the rest by pose
-    std::vector<int> pose_slot(F, -1);
-    int nfree = 0;
+    std::vector<int> pose_slot(F, -1), slot_pose;
     for (int i = 0; i < F; ++i)
-        if (!(p->pose_fixed && p->pose_fixed[i])) pose_slot[i] = nfree++;
-    std::vector<int> pstart(F + 1, 0);
+        if (!(p->pose_fixed && p->pose_fixed[i])) {
+            pose_slot[i] = (int)slot_pose.size();
+            slot_pose.push_back(i);
+        }
+    const int nfree = (int)slot_pose.size();
+    // active edges: SparseOptimizer::initializeOptimization drops edges whose vertices are all fixed
+    std::vector<int> act;
+    act.reserve(p->n_edges);
+    std::vector<int> deg(L, 0);
     for (int e = 0; e < p->n_edges; ++e) {
         if (pose_slot[p->edge_pose[e]] < 0 && p->fix_points) continue;
-        pstart[p->edge_pose[e] + 1]++;
+        act.push_back(e);
+        deg[p->edge_point[e]]++;
     }
-    for (int i = 0; i < F; ++i) pstart[i + 1] += pstart[i];
-    const int E = pstart[F];
-    std::vector<int> order(E, 0);
+    const int E = (int)act.size();
+    const int n = 6 * nfree;
+    const int NT = (n + 1 + 15) / 16, ntile = NT * (NT + 1) / 2;
+    // ---- choose G and the landmark ranges (balanced by edge count); the slice of every workgroup must fit in LDS
+    int G = 1;
+    while (G < 32 && E > 160 * G) G *= 2;  // aim at 160-320 edges per workgroup
+    if (g_ba_wgs > 0) G = g_ba_wgs;
+    if (const char* env = std::getenv("MVO_BA_WGS")) G = std::max(1, std::atoi(env));
+    G = std::max(1, std::min(G, BA_MAX_WGS));
+    std::vector<int> wg_pt, wg_edge;
+    int maxEg = 0, maxLg = 0;
+    for (;;) {
+        wg_pt.assign(G + 1, 0);
+        wg_edge.assign(G + 1, 0);
+        int l = 0, eacc = 0;
+        for (int g = 0; g < G; ++g) {
+            wg_pt[g] = l;
+            wg_edge[g] = eacc;
+            const long target = (long)E * (g + 1) / G;
+            while (l < L && (g == G - 1 || eacc < target)) eacc += deg[l++];
+        }
+        wg_pt[G] = L;
+        wg_edge[G] = E;
+        maxEg = maxLg = 0;
+        for (int g = 0; g < G; ++g) {
+            maxEg = std::max(maxEg, wg_edge[g + 1] - wg_edge[g]);
+            maxLg = std::max(maxLg, wg_pt[g + 1] - wg_pt[g]);
+        }
+        if (wg_lds_bytes(n, ntile, nfree, maxEg, maxLg, p->fix_points) <= BA_LDS_BUDGET && maxEg < 32000 && maxLg < 32000)
+            break;
+        if (G >= BA_MAX_WGS)
+            return mvo_set_err(ctx, MVO_ERR_CAPACITY, "BA window too large for the LDS-resident solver", hipSuccess);
+        G = std::min(2 * G, BA_MAX_WGS);
+    }
+    // ---- edges sorted by (owner workgroup, pose); adjacency tables
+    std::vector<int> owner(L, 0);
+    for (int g = 0; g < G; ++g)
+        for (int l = wg_pt[g]; l < wg_pt[g + 1]; ++l) owner[l] = g;
+    std::vector<int> wg_pose((size_t)G * (F + 1), 0);
     {
-        std::vector<int> cur(pstart.begin(), pstart.end() - 1);
-        for (int e = 0; e < p->n_edges; ++e) {
-            if (pose_slot[p->edge_pose[e]] < 0 && p->fix_points) continue;
-            order[cur[p->edge_pose[e]]++] = e;
+        std::vector<int> cnt((size_t)G * std::max(F, 1), 0);
+        for (int e : act) cnt[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
+        int acc = 0;
+        for (int g = 0; g < G; ++g) {
+            for (int q = 0; q < F; ++q) {
+                wg_pose[(size_t)g * (F + 1) + q] = acc;
+                acc += cnt[(size_t)g * F + q];
+            }
+            wg_pose[(size_t)g * (F + 1) + F] = acc;
         }
     }
     std::vector<int> e_pose(E), e_point(E), ptstart(L + 1, 0), ptlist(E);
     std::vector<double> e_uv(2 * (size_t)E);
-    for (int k = 0; k < E; ++k) {
-        e_pose[k] = p->edge_pose[order[k]];
-        e_point[k] = p->edge_point[order[k]];
-        e_uv[2 * k] = p->edge_uv[2 * order[k]];
-        e_uv[2 * k + 1] = p->edge_uv[2 * order[k] + 1];
-        ptstart[e_point[k] + 1]++;
+    {
+        std::vector<int> cur((size_t)G * std::max(F, 1));
+        for (int g = 0; g < G; ++g)
+            for (int q = 0; q < F; ++q) cur[(size_t)g * F + q] = wg_pose[(size_t)g * (F + 1) + q];
+        for (int e : act) {
+            const int k = cur[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
+            e_pose[k] = p->edge_pose[e];
+            e_point[k] = p->edge_point[e];
+            e_uv[2 * (size_t)k] = p->edge_uv[2 * (size_t)e];
+            e_uv[2 * (size_t)k + 1] = p->edge_uv[2 * (size_t)e + 1];
+        }
     }
+    for (int k = 0; k < E; ++k) ptstart[e_point[k] + 1]++;
     for (int i = 0; i < L; ++i) ptstart[i + 1] += ptstart[i];
     {
         std::vector<int> cur(ptstart.begin(), ptstart.end() - 1);
         for (int k = 0; k < E; ++k) ptlist[cur[e_point[k]]++] = k;
     }
-    std::vector<unsigned char> pt_free(L, p->fix_points ? 0 : 1);
+    std::vector<short> eof((size_t)std::max(L, 1) * std::max(nfree, 1), -1), dup(std::max(E, 1), -1);
+    for (int k = E - 1; k >= 0; --k) {  // descending so that the chains run in ascending edge order
+        const int sl = pose_slot[e_pose[k]];
+        if (sl < 0) continue;
+        const int lk = k - wg_edge[owner[e_point[k]]];
+        short& head = eof[(size_t)e_point[k] * nfree + sl];
+        dup[k] = head;
+        head = (short)lk;
+    }
 
-    const int n = 6 * nfree;
-    const int NT = (n + 1 + 15) / 16, W = NT * 16;
-    const int ntile = NT * (NT + 1) / 2;
-    const int KS = std::max(1, BA_WAVES / ntile);
     Carver cv;
     const size_t o_stats = cv.take(sizeof(BaStatsDev));
-    const size_t o_pin = cv.take((size_t)F * 16 * 8), o_pout = cv.take((size_t)F * 16 * 8);
-    const size_t o_ptsin = cv.take((size_t)L * 3 * 8);
-    const size_t o_ep = cv.take((size_t)E * 4), o_el = cv.take((size_t)E * 4), o_uv = cv.take((size_t)E * 16);
-    const size_t o_ps = cv.take((size_t)(F + 1) * 4), o_slot = cv.take((size_t)F * 4 + 4);
-    const size_t o_pts_s = cv.take((size_t)(L + 1) * 4), o_ptl = cv.take((size_t)E * 4 + 4), o_pf = cv.take((size_t)L + 4);
+    const size_t o_pin = cv.take((size_t)F * 128), o_ptsin = cv.take((size_t)L * 24);
+    const size_t o_wpt = cv.take((size_t)(G + 1) * 4), o_wed = cv.take((size_t)(G + 1) * 4);
+    const size_t o_wps = cv.take((size_t)G * (F + 1) * 4);
+    const size_t o_ep = cv.take((size_t)E * 4 + 4), o_el = cv.take((size_t)E * 4 + 4), o_uv = cv.take((size_t)E * 16 + 16);
+    const size_t o_pts_s = cv.take((size_t)(L + 1) * 4), o_ptl = cv.take((size_t)E * 4 + 4);
+    const size_t o_eof = cv.take(eof.size() * 2), o_dup = cv.take(dup.size() * 2);
+    const size_t o_slot = cv.take((size_t)F * 4 + 4), o_sp = cv.take((size_t)nfree * 4 + 4);
     const size_t upload_end = cv.off;
-    const size_t o_pts = cv.take((size_t)L * 3 * 8), o_bak = cv.take((size_t)L * 3 * 8);
-    const size_t o_M = cv.take((size_t)E * 16 * 8 + 256), o_X = cv.take((size_t)E * 6 * 8 + 256);
-    const size_t o_H = cv.take((size_t)L * 6 * 8), o_b = cv.take((size_t)L * 3 * 8), o_D = cv.take((size_t)L * 6 * 8);
-    const size_t o_C = cv.take((size_t)L * 6 * 8), o_dx = cv.take((size_t)L * 3 * 8);
-    const size_t o_part = cv.take((size_t)std::max(BA_WAVES, ntile * KS) * 256 * 8);
-    const size_t o_UT = cv.take(p->fix_points ? 256 : (size_t)3 * L * W * 8 + 256);
+    const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
+    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg = cv.take((size_t)G * ntile * 256 * 8);
+    const size_t o_xs = cv.take((size_t)G * 32), o_bar = cv.take(64);
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();
     hipError_t he = hipMalloc((void**)&H->dev, total);
@@ -766,21 +1039,25 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     }
     uint8_t* h = ctx->h_pin;
     std::memset(h, 0, upload_end);
-    if (F) std::memcpy(h + o_pin, p->pose_T_w_c, (size_t)F * 16 * 8);
-    if (L) std::memcpy(h + o_ptsin, p->points, (size_t)L * 3 * 8);
+    if (F) std::memcpy(h + o_pin, p->pose_T_w_c, (size_t)F * 128);
+    if (L) std::memcpy(h + o_ptsin, p->points, (size_t)L * 24);
+    std::memcpy(h + o_wpt, wg_pt.data(), (size_t)(G + 1) * 4);
+    std::memcpy(h + o_wed, wg_edge.data(), (size_t)(G + 1) * 4);
+    std::memcpy(h + o_wps, wg_pose.data(), wg_pose.size() * 4);
     if (E) {
         std::memcpy(h + o_ep, e_pose.data(), (size_t)E * 4);
         std::memcpy(h + o_el, e_point.data(), (size_t)E * 4);
         std::memcpy(h + o_uv, e_uv.data(), (size_t)E * 16);
         std::memcpy(h + o_ptl, ptlist.data(), (size_t)E * 4);
     }
-    std::memcpy(h + o_ps, pstart.data(), (size_t)(F + 1) * 4);
-    if (F) std::memcpy(h + o_slot, pose_slot.data(), (size_t)F * 4);
     std::memcpy(h + o_pts_s, ptstart.data(), (size_t)(L + 1) * 4);
-    if (L) std::memcpy(h + o_pf, pt_free.data(), (size_t)L);
+    std::memcpy(h + o_eof, eof.data(), eof.size() * 2);
+    std::memcpy(h + o_dup, dup.data(), dup.size() * 2);
+    if (F) std::memcpy(h + o_slot, pose_slot.data(), (size_t)F * 4);
+    if (nfree) std::memcpy(h + o_sp, slot_pose.data(), (size_t)nfree * 4);
     char* D = H->dev;
     hipError_t e1 = hipMemcpyAsync(D, h, upload_end, hipMemcpyHostToDevice, ctx->stream);
-    hipError_t e2 = p->fix_points ? hipSuccess : hipMemsetAsync(D + o_UT, 0, (size_t)3 * L * W * 8, ctx->stream);
+    hipError_t e2 = hipMemsetAsync(D + upload_end, 0, total - upload_end, ctx->stream);
     hipError_t e3 = hipStreamSynchronize(ctx->stream);  // the pinned staging buffer is reused by later calls
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
         (void)hipFree(H->dev);
@@ -791,14 +1068,16 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.F = F;
     B.L = L;
     B.E = E;
+    B.G = G;
     B.nfree = nfree;
     B.n = n;
     B.NT = NT;
-    B.W = W;
-    B.KS = KS;
+    B.ntile = ntile;
     B.fix_points = p->fix_points ? 1 : 0;
     B.max_it = p->max_iterations;
     B.use_mfma = g_ba_use_mfma;
+    B.maxEg = maxEg;
+    B.maxLg = maxLg;
     B.f = p->focal;
     B.cx = p->cx;
     B.cy = p->cy;
@@ -809,33 +1088,32 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.poses_in = (const double*)(D + o_pin);
     B.poses_out = (double*)(D + o_pout);
     B.pts_in = (const double*)(D + o_ptsin);
-    B.pts = (double*)(D + o_pts);
-    B.pts_bak = (double*)(D + o_bak);
+    B.pts_out = (double*)(D + o_pts);
+    B.wg_pt_start = (const int*)(D + o_wpt);
+    B.wg_edge_start = (const int*)(D + o_wed);
+    B.wg_pose_start = (const int*)(D + o_wps);
     B.e_pose = (const int*)(D + o_ep);
     B.e_point = (const int*)(D + o_el);
     B.e_uv = (const double*)(D + o_uv);
-    B.pose_edge_start = (const int*)(D + o_ps);
-    B.pose_slot = (const int*)(D + o_slot);
     B.pt_edge_start = (const int*)(D + o_pts_s);
     B.pt_edge_list = (const int*)(D + o_ptl);
-    B.pt_free = (const unsigned char*)(D + o_pf);
-    B.M = (double*)(D + o_M);
-    B.Xt = (double*)(D + o_X);
-    B.Hll = (double*)(D + o_H);
-    B.bl = (double*)(D + o_b);
-    B.Dinv = (double*)(D + o_D);
-    B.Cc = (double*)(D + o_C);
-    B.dxl = (double*)(D + o_dx);
-    B.UT = (double*)(D + o_UT);
-    B.part = (double*)(D + o_part);
+    B.eof = (const short*)(D + o_eof);
+    B.dup_next = (const short*)(D + o_dup);
+    B.pose_slot = (const int*)(D + o_slot);
+    B.slot_pose = (const int*)(D + o_sp);
+    B.xHpp = (double*)(D + o_xh);
+    B.xG = (double*)(D + o_xg);
+    B.xSc = (double*)(D + o_xs);
+    B.barrier = (unsigned*)(D + o_bar);
     B.stats = (BaStatsDev*)(D + o_stats);
     H->F = F;
     H->L = L;
     H->o_stats = o_stats;
     H->o_pout = o_pout;
     H->o_pts = o_pts;
+    H->o_bar = o_bar;
     H->fix_points = p->fix_points != 0;
-    H->lds = std::max<size_t>((size_t)n * (n + 1) * 8, 16);
+    H->lds = wg_lds_bytes(n, ntile, nfree, maxEg, maxLg, p->fix_points);
     *out = H;
     return MVO_OK;
 }
@@ -844,11 +1122,11 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
 int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
     if (H->F == 0 && (H->L == 0 || H->fix_points)) return MVO_OK;
     H->B.use_mfma = g_ba_use_mfma;
-    if (H->lds > 32768)
-        MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->lds));
+    MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->lds));
+    if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, 64, ctx->stream));
     {
         ProfScope ps(ctx, "k_ba_lm");
-        hipLaunchKernelGGL(k_ba_lm, dim3(1), dim3(BA_THREADS), H->lds, ctx->stream, H->B);
+        hipLaunchKernelGGL(k_ba_lm, dim3(H->B.G), dim3(BA_THREADS), H->lds, ctx->stream, H->B);
     }
     MVO_HIP(hipGetLastError());
     return MVO_OK;
@@ -872,10 +1150,11 @@ int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* point
     }
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     if (!ran) return MVO_OK;
+    const BaStatsDev* s = (const BaStatsDev*)h;
+    if (s->error) return mvo_set_err(ctx, MVO_ERR_HIP, "BA grid barrier timed out (workgroups not co-resident)", hipSuccess);
     if (poses && H->F) std::memcpy(poses, hp, (size_t)H->F * 128);
     if (points && H->L && !H->fix_points) std::memcpy(points, hx, (size_t)H->L * 24);
     if (st) {
-        const BaStatsDev* s = (const BaStatsDev*)h;
         st->iterations = s->iterations;
         st->trials = s->trials;
         st->terminated = s->terminated;

@@ -488,10 +488,14 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 }
 
 // ---------------------------------------------------------------------------------------------- debug hooks
-extern int g_ba_use_mfma;
+extern int g_ba_use_mfma, g_ba_wgs;
 int mvo_debug_set(const char* key, int value) {
     if (key && !std::strcmp(key, "ba_mfma")) {
         g_ba_use_mfma = value;
+        return MVO_OK;
+    }
+    if (key && !std::strcmp(key, "ba_wgs")) {
+        g_ba_wgs = value;
         return MVO_OK;
     }
     return MVO_ERR_INVALID;

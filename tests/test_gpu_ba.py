@@ -79,6 +79,24 @@ def test_full_ba_gauge_anchored(mvo, O, ctx, F, L, seed, mfma):
         mvo.debug_set("ba_mfma", 1)
 
 
+@pytest.mark.parametrize("wgs", [1, 2, 5, 16, 64])
+@pytest.mark.parametrize("fix_points", [True, False])
+def test_workgroup_split_does_not_change_the_result(mvo, O, ctx, wgs, fix_points):
+    """The window is split over G workgroups by landmark; any G must give the oracle's answer."""
+    mvo.debug_set("ba_wgs", wgs)
+    try:
+        pb = mvo.synth.ba_problem(4, 700, 21)
+        kw = dict(fix_points=fix_points, pose_fixed=None if fix_points else _fix(4, 1), max_iterations=3)
+        P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+        Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
+        assert st["trials"] == sto["trials"], (st, sto)
+        assert np.abs(P - Po).max() < 1e-8 and np.abs(X - Xo).max() < 1e-8, (st, sto)
+        pb["poses0"][:2] = pb["poses_gt"][:2]
+        _check(mvo, O, ctx, pb, fix_points=fix_points, pose_fixed=_fix(4, 2))
+    finally:
+        mvo.debug_set("ba_wgs", 0)
+
+
 def _reproj(pb, P, X):
     r = []
     for i in range(len(P)):
