@@ -171,6 +171,9 @@ int mvo_profile_get(mvo_ctx* ctx, mvo_kernel_time* out, int cap);
 /* key "ba_mfma": 1 (default) = matrix-core contractions, 0 = plain VALU loops computing the same sums;
  * key "ba_wgs": workgroups (CUs) one BA window is split over, 0 (default) = automatic. */
 int mvo_debug_set(const char* key, int value);
+/* Shader-clock cycles the last fetched BA solve spent per phase (ids in csrc/ba_kernels.hip), and the number
+ * of workgroups it ran on. */
+int mvo_debug_get_ba_phases(mvo_ctx* ctx, long long* cycles, int n, int* wgs);
 /* Copies cached pyramid level `level` (raw gray or blurred) WITH its 32-px frame: (h+64) rows of `stride`
  * bytes.  out == NULL only queries the geometry. */
 int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int cap, int* w, int* h, int* stride);

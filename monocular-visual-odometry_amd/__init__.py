@@ -315,6 +315,14 @@ class Context:
         n = self.lib.mvo_profile_get(self.h, arr, 64)
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(min(n, 64))}
 
+    def debug_ba_phases(self):
+        arr = (C.c_longlong * 12)()
+        g = C.c_int()
+        self._chk(self.lib.mvo_debug_get_ba_phases(self.h, arr, 12, C.byref(g)))
+        names = ["lin", "hpp", "pt+xchg", "t1", "schur", "publish+bar", "assemble", "ldlt", "backsub", "chi2",
+                 "chi2xchg", "total"]
+        return {"wgs": g.value, **{n: arr[i] for i, n in enumerate(names)}}
+
     def debug_level(self, level, blurred=False):
         w, h, s = C.c_int(), C.c_int(), C.c_int()
         self._chk(self.lib.mvo_debug_get_level(self.h, level, int(blurred), None, 0, C.byref(w), C.byref(h), C.byref(s)))

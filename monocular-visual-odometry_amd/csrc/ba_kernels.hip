@@ -33,13 +33,24 @@ typedef unsigned long long u64;
 #define BA_MAX_POSES 20
 #define BA_MFMA_MAX_NT 4  // matrix-core Schur path up to 64 rows (10 free poses + rhs); beyond: VALU loops
 #define BA_MSTRIDE 14     // doubles per edge in M: two rows [A~(6) | e~]
-#define BA_LDS_BUDGET (150 * 1024)
+#define BA_LDS_BUDGET (140 * 1024)  // dynamic part; ~18 KB of static LDS come on top (160 KB per CU)
 #define BA_MAX_WGS 128
 
+#define BA_NPHASE 12
 struct BaStatsDev {
     int iterations, trials, terminated, error;
     double chi2_initial, chi2_final, lambda_final;
+    long long phase[BA_NPHASE];  // shader-clock cycles per phase as seen by thread 0 of workgroup 0
 };
+// phase ids: 0 LIN, 1 HPP, 2 PT + pose-block exchange, 3 T1, 4 Schur MFMA, 5 publish + barrier, 6 assemble S,
+// 7 LDL^T, 8 back-substitution + update, 9 chi2, 10 chi2 exchange + decision, 11 whole kernel
+#define PH_BEGIN() long long ph_t = (long long)__builtin_amdgcn_s_memtime()
+#define PH_END(id)                                                   \
+    do {                                                             \
+        long long ph_n = (long long)__builtin_amdgcn_s_memtime();    \
+        ph[id] += ph_n - ph_t;                                       \
+        ph_t = ph_n;                                                 \
+    } while (0)
 
 struct BaDev {
     int F, L, E, G, nfree, n, NT, ntile, fix_points, max_it, use_mfma, maxEg, maxLg;
@@ -254,6 +265,44 @@ __device__ __forceinline__ void huber(double e, double delta, double& rho0, doub
     }
 }
 
+
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// Solves the reduced n x n system [S | g] (row stride ld, in LDS) with ONE wave: lane i keeps row i in registers
+// (padded with identity rows up to NR), Gaussian elimination without pivoting = the LDL^T of the SPD system;
+// pivot rows are broadcast with v_readlane.  Returns 0 when a pivot is not positive (g2o: LDLT "not positive"
+// -> the step is rejected).  x (n entries) is written to xout.
+template <int NR>
+__device__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, double* xout) {
+    double a[NR + 1];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) a[k] = (lane < n && k < n) ? S[lane * ld + k] : (k == lane ? 1.0 : 0.0);
+    a[NR] = lane < n ? S[lane * ld + n] : 0.0;
+    int ok = 1;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const double d = readlane_d(a[j], j);
+        ok &= (d > 0) && isfinite(d);
+        const double l = lane > j ? a[j] / d : 0.0;
+#pragma unroll
+        for (int k = j + 1; k <= NR; ++k) a[k] -= l * readlane_d(a[k], j);
+    }
+    double x = 0;
+#pragma unroll
+    for (int j = NR - 1; j >= 0; --j) {
+        const double xj = readlane_d(a[NR], j) / readlane_d(a[j], j);
+        x = lane == j ? xj : x;
+        a[NR] -= a[j] * xj;
+    }
+    if (lane < n) xout[lane] = x;
+    return ok;
+}
+
 // LDS layout of one workgroup, carved from the dynamic segment.
 struct WgLds {
     double* S;     // n x (n+1) reduced system
@@ -388,7 +437,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
     __shared__ double sHpp[BA_MAX_POSES * 36], sBp[BA_MAX_POSES * 6], sDx[BA_MAX_POSES * 6];
     __shared__ double sPart[BA_WAVES * 49];
     __shared__ double sScr[BA_WAVES];
-    __shared__ double sLcol[6 * BA_MAX_POSES], sCol[6 * BA_MAX_POSES];
+    __shared__ double sLcol[6 * BA_MAX_POSES], sCol[6 * BA_MAX_POSES], sSol[6 * BA_MAX_POSES];
+    __shared__ double sX[BA_MAX_WGS * 2];
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ int sFlag[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -472,6 +522,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
 
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, terminated = 0, error = 0;
+    long long ph[BA_NPHASE] = {0};
+    const long long ph_start = (long long)__builtin_amdgcn_s_memtime();
     // ---- initial robust chi2 (all workgroups)
     double currentChi;
     {
@@ -491,6 +543,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
 
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus)
+        PH_BEGIN();
         for (int el = tid; el < Eg; el += BA_THREADS) {
             double Xc[3], ew[2], r0, r1;
             const double chi = edge_error(B, W, el, sR, sT, Xc, ew);
@@ -527,6 +580,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             }
         }
         __syncthreads();
+        PH_END(0);
         // ================= HPP: partial [H_pp | -b_p] = M^T M over the own edges of every free pose
         for (int p = 0; p < B.F; ++p) {
             if (sSlot[p] < 0) continue;
@@ -572,6 +626,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             }
             __syncthreads();
         }
+        PH_END(1);
         // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks
         double maxdiag = 0;
         if (!B.fix_points) {
@@ -609,15 +664,22 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                 const int p = tid / 49, r = tid % 49;
                 if (sSlot[p] >= 0) {
                     double gsum = 0;
-                    for (int w = 0; w < B.G; ++w) gsum += xload(B.xHpp + ((size_t)w * B.F + p) * 49 + r);
+                    const double* src = B.xHpp + (size_t)p * 49 + r;
+                    const size_t stride = (size_t)B.F * 49;
+                    for (int w0 = 0; w0 < B.G; w0 += 16) {
+                        double v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) v[q] = (w0 + q < B.G) ? xload(src + (size_t)(w0 + q) * stride) : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) gsum += v[q];
+                    }
                     const int i = r / 7, j = r % 7;
                     if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = gsum;
                     if (i < 6 && j == 6) sBp[6 * p + i] = -gsum;
                 }
             }
             if (it == 0) {
-                maxdiag = 0;
-                for (int w = 0; w < B.G; ++w) maxdiag = fmax(maxdiag, xload(B.xSc + 4 * w + 2));
+                maxdiag = tid < B.G ? xload(B.xSc + 4 * tid + 2) : 0.0;  // block_max below combines them
             }
             __syncthreads();
         }
@@ -628,6 +690,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             ni = 2;
         }
         __syncthreads();
+        PH_END(2);
 
         double rho = 0;
         int qmax = 0;
@@ -668,6 +731,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                 }
                 __syncthreads();
             }
+            PH_END(3);
             // ============= T2: partial Schur blocks of the own landmarks, published for the other workgroups
             if (do_schur) {
                 if (B.use_mfma && B.NT <= BA_MFMA_MAX_NT) {
@@ -678,12 +742,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                 } else {
                     schur_valu(B, W, Lg);
                 }
+                PH_END(4);
                 if (B.G > 1) {
                     for (int idx = tid; idx < B.ntile * 256; idx += BA_THREADS)
                         xstore(B.xG + (size_t)g * B.ntile * 256 + idx, W.tile[idx]);
                     if (!grid_barrier(B, epoch, sFlag)) error = 1;
                 }
             }
+            PH_END(5);
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n]; LDL^T by wave 0
             for (int idx = tid; idx < n * ld; idx += BA_THREADS) {
                 const int i = idx / ld, j = idx - i * ld;
@@ -697,10 +763,19 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                     const int ti = a / 16, tj = b / 16;
                     const int tl = ti * B.NT - ti * (ti - 1) / 2 + (tj - ti);
                     const size_t off = (size_t)tl * 256 + 16 * (a % 16) + (b % 16);
-                    if (B.G > 1)
-                        for (int w = 0; w < B.G; ++w) gsum += xload(B.xG + (size_t)w * B.ntile * 256 + off);
-                    else
+                    if (B.G > 1) {
+                        const double* src = B.xG + off;
+                        const size_t stride = (size_t)B.ntile * 256;
+                        for (int w0 = 0; w0 < B.G; w0 += 16) {  // 16 independent loads in flight, summed in order
+                            double v[16];
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) v[q] = (w0 + q < B.G) ? xload(src + (size_t)(w0 + q) * stride) : 0.0;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) gsum += v[q];
+                        }
+                    } else {
                         gsum = W.tile[off];
+                    }
                 }
                 const int pi = sSlotPose[i / 6];
                 double v;
@@ -713,37 +788,43 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                 W.S[idx] = v;
             }
             __syncthreads();
+            PH_END(6);
             if (wave == 0) {
-                double* S = W.S;
                 int ok = 1;
-                for (int j = 0; j < n; ++j) {
-                    const double d = S[j * ld + j];
-                    if (!(d > 0) || !isfinite(d)) {
-                        ok = 0;
-                        break;
-                    }
-                    const double gj = S[j * ld + n];
-                    for (int i = j + 1 + lane; i < n; i += 64) {
-                        const double cij = S[i * ld + j];
-                        sCol[i] = cij;
-                        sLcol[i] = cij / d;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    for (int i = j + 1 + lane; i < n; i += 64) {
-                        const double li = sLcol[i];
-                        for (int k = j + 1; k <= i; ++k) S[i * ld + k] -= li * sCol[k];
-                        S[i * ld + n] -= li * gj;
-                        S[i * ld + j] = li;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (ok) {
-                    for (int i = lane; i < n; i += 64) S[i * ld + n] /= S[i * ld + i];
-                    __builtin_amdgcn_wave_barrier();
-                    for (int j = n - 1; j >= 0; --j) {
-                        const double xj = S[j * ld + n];
-                        for (int i = lane; i < j; i += 64) S[i * ld + n] -= S[j * ld + i] * xj;
+                if (n <= 32) {
+                    ok = solve_rows_in_regs<32>(W.S, n, ld, lane, sSol);
+                } else {  // more than 5 free poses: unpivoted LDL^T in LDS
+                    double* S = W.S;
+                    for (int j = 0; j < n; ++j) {
+                        const double d = S[j * ld + j];
+                        if (!(d > 0) || !isfinite(d)) {
+                            ok = 0;
+                            break;
+                        }
+                        const double gj = S[j * ld + n];
+                        for (int i = j + 1 + lane; i < n; i += 64) {
+                            const double cij = S[i * ld + j];
+                            sCol[i] = cij;
+                            sLcol[i] = cij / d;
+                        }
                         __builtin_amdgcn_wave_barrier();
+                        for (int i = j + 1 + lane; i < n; i += 64) {
+                            const double li = sLcol[i];
+                            for (int k = j + 1; k <= i; ++k) S[i * ld + k] -= li * sCol[k];
+                            S[i * ld + n] -= li * gj;
+                            S[i * ld + j] = li;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (ok) {
+                        for (int i = lane; i < n; i += 64) S[i * ld + n] /= S[i * ld + i];
+                        __builtin_amdgcn_wave_barrier();
+                        for (int j = n - 1; j >= 0; --j) {
+                            const double xj = S[j * ld + n];
+                            for (int i = lane; i < j; i += 64) S[i * ld + n] -= S[j * ld + i] * xj;
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        for (int i = lane; i < n; i += 64) sSol[i] = S[i * ld + n];
                     }
                 }
                 if (lane == 0) sFlag[0] = ok;
@@ -752,9 +833,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             const int ok2 = sFlag[0];
             if (tid < 6 * B.F) {
                 const int sl = sSlot[tid / 6];
-                sDx[tid] = (ok2 && sl >= 0) ? W.S[(6 * sl + tid % 6) * ld + n] : 0.0;
+                sDx[tid] = (ok2 && sl >= 0) ? sSol[6 * sl + tid % 6] : 0.0;
             }
             __syncthreads();
+            PH_END(7);
             ++trials;
             // ============= T4/T5: back-substitute the own landmarks, computeScale, push + apply the update
             double scale = 0;
@@ -798,19 +880,26 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             }
             scale = block_sum(scale, sScr);
             __syncthreads();
+            PH_END(8);
             // ============= T6/T7: robust chi2 at the trial state, identical accept / reject decision everywhere
             double tempChi = robust_chi2_local(B, W, Eg, sR, sT, sScr);
+            PH_END(9);
             if (B.G > 1) {
                 if (tid == 0) {
                     xstore(B.xSc + 4 * g, tempChi);
                     xstore(B.xSc + 4 * g + 1, scale);
                 }
                 if (!grid_barrier(B, epoch, sFlag)) error = 1;
+                if (tid < B.G) {
+                    sX[2 * tid] = xload(B.xSc + 4 * tid);
+                    sX[2 * tid + 1] = xload(B.xSc + 4 * tid + 1);
+                }
+                __syncthreads();
                 tempChi = 0;
                 scale = 0;
                 for (int w = 0; w < B.G; ++w) {
-                    tempChi += xload(B.xSc + 4 * w);
-                    scale += xload(B.xSc + 4 * w + 1);
+                    tempChi += sX[2 * w];
+                    scale += sX[2 * w + 1];
                 }
                 // xSc / xHpp must not be overwritten before everyone has read them: with a Schur phase the next
                 // writes sit behind its barrier; without one (pose-only BA, no free pose) close the phase here
@@ -838,6 +927,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                     for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = W.bak[i];
             }
             __syncthreads();
+            PH_END(10);
             ++qmax;
         } while (rho < 0 && qmax < 10 && !error);
         if (qmax == 10 || rho == 0 || error) {
@@ -875,6 +965,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
         B.stats->chi2_initial = chi0;
         B.stats->chi2_final = currentChi;
         B.stats->lambda_final = lambda;
+        ph[11] = (long long)__builtin_amdgcn_s_memtime() - ph_start;
+        for (int i = 0; i < BA_NPHASE; ++i) B.stats->phase[i] = ph[i];
     }
 }
 
@@ -1151,6 +1243,8 @@ int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* point
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     if (!ran) return MVO_OK;
     const BaStatsDev* s = (const BaStatsDev*)h;
+    for (int i = 0; i < BA_NPHASE && i < 16; ++i) ctx->ba_phase[i] = s->phase[i];
+    ctx->ba_wgs = H->B.G;
     if (s->error) return mvo_set_err(ctx, MVO_ERR_HIP, "BA grid barrier timed out (workgroups not co-resident)", hipSuccess);
     if (poses && H->F) std::memcpy(poses, hp, (size_t)H->F * 128);
     if (points && H->L && !H->fix_points) std::memcpy(points, hx, (size_t)H->L * 24);

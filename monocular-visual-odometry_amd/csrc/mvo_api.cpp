@@ -501,6 +501,13 @@ int mvo_debug_set(const char* key, int value) {
     return MVO_ERR_INVALID;
 }
 
+int mvo_debug_get_ba_phases(mvo_ctx* ctx, long long* cycles, int n, int* wgs) {
+    if (!ctx || !cycles) return MVO_ERR_INVALID;
+    for (int i = 0; i < n && i < 16; ++i) cycles[i] = ctx->ba_phase[i];
+    if (wgs) *wgs = ctx->ba_wgs;
+    return MVO_OK;
+}
+
 int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int cap, int* w, int* h, int* stride) {
     if (!ctx || !ctx->pyr_valid || level < 0 || level >= ctx->pyr_levels_built)
         return mvo_set_err(ctx, MVO_ERR_STATE, "no such cached level", hipSuccess);

@@ -102,6 +102,9 @@ struct mvo_ctx {
     float *d_mqxy = nullptr, *d_mtxy = nullptr;
     int32_t* d_mout = nullptr;
     int m_cap_q = 0, m_cap_t = 0;
+    // --- BA diagnostics of the last fetched solve
+    long long ba_phase[16] = {0};
+    int ba_wgs = 0;
     // --- profiling
     bool prof = false;
     std::map<std::string, ProfEntry> prof_acc;
@@ -113,7 +116,10 @@ int mvo_set_err(mvo_ctx* c, int code, const char* what, hipError_t e);
 #define MVO_HIP(call)                                                            \
     do {                                                                         \
         hipError_t e__ = (call);                                                 \
-        if (e__ != hipSuccess) return mvo_set_err(ctx, MVO_ERR_HIP, #call, e__); \
+        if (e__ != hipSuccess) {                                                 \
+            (void)hipGetLastError(); /* clear the sticky error */                \
+            return mvo_set_err(ctx, MVO_ERR_HIP, #call, e__);                    \
+        }                                                                        \
     } while (0)
 
 // profiling brackets
