@@ -985,8 +985,44 @@ struct Carver {
 int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
 
+// Co-residency guard: the workgroups of one BA launch meet at grid barriers, so all of them must be resident
+// (one per CU: the LDS slice is > 80 KB).  Launches from different ctx / host threads draw their workgroups from
+// a per-device budget of CUs and wait (on the host, before launching) while it is exhausted.
+#include <condition_variable>
+#include <mutex>
+namespace {
+struct CuBudget {
+    std::mutex m;
+    std::condition_variable cv;
+    int avail[16];
+    bool init = false;
+} g_budget;
+void budget_acquire(int device, int n) {
+    std::unique_lock<std::mutex> lk(g_budget.m);
+    if (!g_budget.init) {
+        for (int d = 0; d < 16; ++d) {
+            hipDeviceProp_t prop;
+            g_budget.avail[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess) ? prop.multiProcessorCount : 256;
+        }
+        g_budget.init = true;
+    }
+    device &= 15;
+    g_budget.cv.wait(lk, [&] { return g_budget.avail[device] >= n; });
+    g_budget.avail[device] -= n;
+}
+void budget_release(int device, int n) {
+    {
+        std::lock_guard<std::mutex> lk(g_budget.m);
+        g_budget.avail[device & 15] += n;
+    }
+    g_budget.cv.notify_all();
+}
+}  // namespace
+
 // A window whose inputs are resident in HBM: upload once (mvo_ba_prepare), solve any number of times.
 struct mvo_ba_handle {
+    int device = 0;
+    int tokens = 0;  // CUs currently reserved for an in-flight launch of this window
     char* dev = nullptr;  // one allocation holding inputs, adjacency tables and exchange buffers
     size_t bytes = 0;
     BaDev B{};
@@ -1206,6 +1242,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     H->o_bar = o_bar;
     H->fix_points = p->fix_points != 0;
     H->lds = wg_lds_bytes(n, ntile, nfree, maxEg, maxLg, p->fix_points);
+    H->device = ctx->device;
     *out = H;
     return MVO_OK;
 }
@@ -1214,6 +1251,10 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
 int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
     if (H->F == 0 && (H->L == 0 || H->fix_points)) return MVO_OK;
     H->B.use_mfma = g_ba_use_mfma;
+    if (H->B.G > 1 && H->tokens == 0) {
+        budget_acquire(H->device, H->B.G);
+        H->tokens = H->B.G;
+    }
     MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->lds));
     if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, 64, ctx->stream));
     {
@@ -1240,7 +1281,12 @@ int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* point
         if (points && H->L && !H->fix_points)
             MVO_HIP(hipMemcpyAsync(hx, H->dev + H->o_pts, (size_t)H->L * 24, hipMemcpyDeviceToHost, ctx->stream));
     }
-    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    hipError_t sync_err = hipStreamSynchronize(ctx->stream);
+    if (H->tokens) {
+        budget_release(H->device, H->tokens);
+        H->tokens = 0;
+    }
+    MVO_HIP(sync_err);
     if (!ran) return MVO_OK;
     const BaStatsDev* s = (const BaStatsDev*)h;
     for (int i = 0; i < BA_NPHASE && i < 16; ++i) ctx->ba_phase[i] = s->phase[i];
@@ -1261,6 +1307,7 @@ int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* point
 
 void ba_release_device(mvo_ba_handle* H) {
     if (!H) return;
+    if (H->tokens) budget_release(H->device, H->tokens);  // (the caller has synchronised the stream)
     if (H->dev) (void)hipFree(H->dev);
     delete H;
 }

@@ -4,6 +4,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "mvo_internal.h"
@@ -60,6 +61,9 @@ extern "C" {
 int mvo_create(mvo_ctx** out, int device) {
     if (!out) return MVO_ERR_INVALID;
     *out = nullptr;
+    // One ctx = one HIP stream; streams beyond the runtime's hardware-queue limit (default 4) share a queue and
+    // their kernels serialise.  Takes effect only if the HIP runtime has not been initialised yet.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MVO_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return MVO_ERR_NO_DEVICE;
