@@ -17,6 +17,9 @@ import argparse
 import json
 import os
 import sys
+
+# one HIP stream per sequence shard: lift the runtime's default of 4 hardware queues BEFORE HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import threading
 import time
 
