@@ -1000,10 +1000,14 @@ struct CuBudget {
 void budget_acquire(int device, int n) {
     std::unique_lock<std::mutex> lk(g_budget.m);
     if (!g_budget.init) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
         for (int d = 0; d < 16; ++d) {
-            hipDeviceProp_t prop;
-            g_budget.avail[d] = (hipGetDeviceProperties(&prop, d) == hipSuccess) ? prop.multiProcessorCount : 256;
+            int cus = 256;
+            if (d < ndev && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) cus = 256;
+            g_budget.avail[d] = cus;
         }
+        (void)hipGetLastError();
         g_budget.init = true;
     }
     device &= 15;
