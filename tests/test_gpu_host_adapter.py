@@ -1,0 +1,57 @@
+"""The C++ mirror of the reference interface (host/include/my_slam: Frame, calcKeyPoints, matchFeatures,
+bundleAdjustment, g2o-shaped facade) driven like the reference's call sites, results checked against the oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_struct_equal
+
+BIN = os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "tests", "test_dropin")
+
+
+def test_adapter_binary_is_built_and_links_only_the_hip_library():
+    assert os.path.exists(BIN), "run __graft_entry__.build()"
+    ldd = subprocess.run(["ldd", BIN], capture_output=True, text=True).stdout
+    assert "libmvo_hip.so" in ldd and "liboracle" not in ldd and "opencv" not in ldd.lower() and "g2o" not in ldd
+
+
+def _read(f, dtype):
+    n = int(np.frombuffer(f.read(8), "<u8")[0])
+    return np.frombuffer(f.read(n * np.dtype(dtype).itemsize), dtype).copy()
+
+
+@pytest.mark.gpu
+def test_cpp_dropin_matches_oracle(mvo, O, tmp_path):
+    img0 = mvo.synth.small_test_image(31, 480, 360)
+    img1 = np.roll(img0, (2, 5), axis=(0, 1))
+    p0, p1, out = tmp_path / "a.raw", tmp_path / "b.raw", tmp_path / "out.bin"
+    img0.tofile(p0)
+    img1.tofile(p1)
+    r = subprocess.run([BIN, str(p0), str(p1), "480", "360", "3", str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    p = O.default_params(max_keypoints=1000)
+    with open(out, "rb") as f:
+        descs, kps = [], []
+        for img in (img0, img1):
+            k = _read(f, O.KEYPOINT_DTYPE)
+            d = _read(f, np.uint8).reshape(-1, 32)
+            rgb = _read(f, np.uint8).reshape(-1, 3)
+            ko = O.calc_keypoints(img, p)
+            ko, do, rgbo = O.calc_descriptors(img, ko, p, want_rgb=True)
+            assert_struct_equal(k, ko, "Frame::calcKeyPoints/calcDescriptors")
+            assert np.array_equal(d, do) and np.array_equal(rgb, rgbo)
+            descs.append(d)
+            kps.append(k)
+        for method in (1, 2, 3):
+            m = _read(f, O.DMATCH_DTYPE)
+            xy = [np.stack([k["x"], k["y"]], 1) for k in kps]
+            mo = O.match_features(descs[0], descs[1], method, 2.0, 1.0, xy[0], xy[1], 50.0)   # ratios latched as int
+            assert_struct_equal(m, mo, "matchFeatures method %d" % method)
+        P1 = np.stack([_read(f, "<f8").reshape(4, 4) for _ in range(3)])
+        P2 = np.stack([_read(f, "<f8").reshape(4, 4) for _ in range(3)])
+        X2 = _read(f, "<f4").reshape(-1, 3)
+    # pose-only BA pulled the perturbed poses back to the truth (x = 0.05 f, y = z = 0) within the pixel noise
+    assert np.abs(P1[:, :3, 3] - np.array([[0, 0, 0], [0.05, 0, 0], [0.10, 0, 0]])).max() < 2e-3
+    assert np.isfinite(P2).all() and np.isfinite(X2).all() and len(X2) == 150
