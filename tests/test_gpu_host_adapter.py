@@ -51,7 +51,7 @@ def test_cpp_dropin_matches_oracle(mvo, O, tmp_path):
             assert_struct_equal(m, mo, "matchFeatures method %d" % method)
         P1 = np.stack([_read(f, "<f8").reshape(4, 4) for _ in range(3)])
         P2 = np.stack([_read(f, "<f8").reshape(4, 4) for _ in range(3)])
-        X2 = _read(f, "<f4").reshape(-1, 3)
+        X2 = _read(f, np.dtype([("xyz", "<f4", 3)]))["xyz"]        # vector<cv::Point3f>
     # pose-only BA pulled the perturbed poses back to the truth (x = 0.05 f, y = z = 0) within the pixel noise
     assert np.abs(P1[:, :3, 3] - np.array([[0, 0, 0], [0.05, 0, 0], [0.10, 0, 0]])).max() < 2e-3
     assert np.isfinite(P2).all() and np.isfinite(X2).all() and len(X2) == 150
