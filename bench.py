@@ -109,6 +109,33 @@ class Shard:
         self.frame_no += 1
 
 
+def shard_ids(rank, streams):
+    """Sequence shards owned by a rank: disjoint, seeds 1234 + id (no data-path collective needed)."""
+    return [rank * streams + s for s in range(streams)]
+
+
+def max_over_ranks(dist, elapsed, device):
+    """Contract: the timed region is the MAX over ranks."""
+    if dist is None:
+        return elapsed
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_trajectories(dist, traj, device):
+    """The one collective of the path: all_gather of the per-shard trajectories [streams, steps, 12] f64
+    (row format of vo_io.cpp:58-75) -> [world, streams, steps, 12]."""
+    if dist is None:
+        return traj[None]
+    import torch
+    tl = torch.from_numpy(np.ascontiguousarray(traj)).to(device)
+    out = [torch.empty_like(tl) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, tl)
+    return torch.stack(out).cpu().numpy()
+
+
 def run_steps(shards, n):
     """Every shard advances n frames on its own thread (ctypes releases the GIL inside the library)."""
     errs = []
@@ -170,7 +197,7 @@ def main():
     torch.cuda.set_device(local)
     mvo = graft.load_package()
 
-    shards = [Shard(mvo, torch, local, rank * args.streams + s, args) for s in range(args.streams)]
+    shards = [Shard(mvo, torch, local, sid, args) for sid in shard_ids(rank, args.streams)]
     torch.cuda.synchronize()
 
     def barrier():
@@ -186,24 +213,14 @@ def main():
         s.ctx.synchronize()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(dist, t1 - t0, "cuda")
     frames_total = world * args.streams * args.steps
     value = frames_total / elapsed
 
     # ---- the one collective: gather the trajectories (frames x 12 f64 per shard)
     traj = np.stack([np.stack(s.traj[-args.steps:]) for s in shards])           # [streams, steps, 12]
-    if dist is not None:
-        tl = torch.from_numpy(traj).cuda()
-        out = [torch.empty_like(tl) for _ in range(world)]
-        dist.all_gather(out, tl)
-        traj_all = torch.stack(out).cpu().numpy()
-    else:
-        traj_all = traj[None]
-    assert np.isfinite(traj_all).all()
+    traj_all = gather_trajectories(dist, traj, "cuda")
+    assert traj_all.shape == (world, args.streams, args.steps, 12) and np.isfinite(traj_all).all()
 
     result = None
     if rank == 0:
