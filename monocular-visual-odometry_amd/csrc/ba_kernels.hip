@@ -53,7 +53,7 @@ struct BaStatsDev {
     } while (0)
 
 struct BaDev {
-    int F, L, E, G, nfree, n, NT, ntile, fix_points, max_it, use_mfma, maxEg, maxLg;
+    int F, L, E, G, nfree, n, NT, ntile, fix_points, max_it, use_mfma, maxEg, maxLg, has_dups;
     double f, cx, cy, delta;
     double lc00, lc01, lc11;  // upper Cholesky factor of the information matrix: Omega = Lc^T Lc
     const double* poses_in;   // F x 16
@@ -291,6 +291,7 @@ __device__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, doub
         const double l = lane > j ? a[j] / d : 0.0;
 #pragma unroll
         for (int k = j + 1; k <= NR; ++k) a[k] -= l * readlane_d(a[k], j);
+        __builtin_amdgcn_sched_barrier(0);  // no hoisting of the next step's readlanes (SGPR pressure -> spills)
     }
     double x = 0;
 #pragma unroll
@@ -298,6 +299,7 @@ __device__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, doub
         const double xj = readlane_d(a[NR], j) / readlane_d(a[j], j);
         x = lane == j ? xj : x;
         a[NR] -= a[j] * xj;
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (lane < n) xout[lane] = x;
     return ok;
@@ -317,6 +319,7 @@ struct WgLds {
     double* Cc;    // maxLg x 6   Cholesky factor of (H_ll + lambda I)^-1
     double* cl;    // maxLg x 3   C^T b_l
     double* tile;  // ntile x 256
+    double* te;    // maxEg x 3   per-edge back-substitution terms
     short* epose;  // maxEg
     short* ept;    // maxEg  local landmark index
     short* dup;    // maxEg  next local edge with the same (landmark, pose)
@@ -326,7 +329,7 @@ struct WgLds {
 };
 __host__ __device__ inline size_t wg_lds_doubles(int n, int ntile, int maxEg, int maxLg, int fix_points) {
     size_t d = (size_t)n * (n + 1) + (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
-    if (!fix_points) d += (size_t)maxEg * 12 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256;
+    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256;
     return d;
 }
 __host__ __device__ inline size_t wg_lds_bytes(int n, int ntile, int nfree, int maxEg, int maxLg, int fix_points) {
@@ -378,6 +381,14 @@ __device__ __forceinline__ double u_entry(const WgLds& W, int nfree, int n, int 
     return row == n ? W.cl[3 * l + k] : 0.0;
 }
 
+// branch-free variant for windows without duplicate (landmark, pose) observations (the normal case)
+__device__ __forceinline__ double u_entry_nodup(const WgLds& W, int nfree, int n, int l, int row, int sl, int c, int k) {
+    const int el = row < n ? (int)W.eof[l * nfree + sl] : -1;
+    const int e = el < 0 ? 0 : el;
+    const double v = W.M[BA_MSTRIDE * e + c] * W.Y[6 * e + k] + W.M[BA_MSTRIDE * e + 7 + c] * W.Y[6 * e + 3 + k];
+    return el >= 0 ? v : (row == n ? W.cl[3 * l + k] : 0.0);
+}
+
 // partial G = U^T U over the own landmarks: every wave takes every 8th landmark, one MFMA per landmark and
 // tile pair (k-slots 0..2 = columns of U_l, slot 3 = 0); the waves' accumulators are combined in wave order.
 template <int NT>
@@ -387,15 +398,48 @@ __device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int
 #pragma unroll
     for (int a = 0; a < NPAIR; ++a) acc[a] = (v4d){0, 0, 0, 0};
     const int k = lane >> 4, i = lane & 15;
-    for (int l = wave; l < Lg; l += BA_WAVES) {
-        double op[NT];
+    const int kk = k < 3 ? k : 0;
+    if (!B.has_dups) {
+        int sl[NT], cc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) op[t] = k < 3 ? u_entry(W, B.nfree, B.n, l, 16 * t + i, k) : 0.0;
-        int a = 0;
+        for (int t = 0; t < NT; ++t) {
+            const int row = 16 * t + i;
+            sl[t] = row < B.n ? row / 6 : 0;
+            cc[t] = row < B.n ? row - 6 * sl[t] : 0;
+        }
+        // two landmarks per step: their LDS chains are independent and overlap
+        for (int l = wave; l < Lg; l += 2 * BA_WAVES) {
+            const int l2 = l + BA_WAVES;
+            const bool has2 = l2 < Lg;
+            const int l2c = has2 ? l2 : l;
+            double op[NT], oq[NT];
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
+            for (int t = 0; t < NT; ++t) {
+                op[t] = u_entry_nodup(W, B.nfree, B.n, l, 16 * t + i, sl[t], cc[t], kk);
+                oq[t] = u_entry_nodup(W, B.nfree, B.n, l2c, 16 * t + i, sl[t], cc[t], kk);
+                op[t] = k < 3 ? op[t] : 0.0;
+                oq[t] = (k < 3 && has2) ? oq[t] : 0.0;
+            }
+            int a = 0;
 #pragma unroll
-            for (int tj = ti; tj < NT; ++tj, ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[a], 0, 0, 0);
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj, ++a) {
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[a], 0, 0, 0);
+                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(oq[ti], oq[tj], acc[a], 0, 0, 0);
+                }
+        }
+    } else {
+        for (int l = wave; l < Lg; l += BA_WAVES) {
+            double op[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) op[t] = k < 3 ? u_entry(W, B.nfree, B.n, l, 16 * t + i, k) : 0.0;
+            int a = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj, ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[a], 0, 0, 0);
+        }
     }
     for (int w = 0; w < BA_WAVES; ++w) {
         if (wave == w) {
@@ -430,7 +474,8 @@ __device__ void schur_valu(const BaDev& B, const WgLds& W, int Lg) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
+__global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ Bp) {
+    const BaDev& B = *Bp;
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double sP[BA_MAX_POSES * 8], sPbak[BA_MAX_POSES * 8];  // q[4] t[3] pad
     __shared__ double sR[BA_MAX_POSES * 9], sT[BA_MAX_POSES * 3];
@@ -461,7 +506,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
         d += (size_t)B.maxEg * 2;
         W.pts = d;
         d += (size_t)B.maxLg * 3;
-        W.X = W.Y = W.bak = W.Hll = W.bl = W.Cc = W.cl = W.tile = nullptr;
+        W.X = W.Y = W.bak = W.Hll = W.bl = W.Cc = W.cl = W.tile = W.te = nullptr;
         if (!B.fix_points) {
             W.X = d;
             d += (size_t)B.maxEg * 6;
@@ -479,6 +524,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             d += (size_t)B.maxLg * 3;
             W.tile = d;
             d += (size_t)B.ntile * 256;
+            W.te = d;
+            d += (size_t)B.maxEg * 3;
         }
         short* s = reinterpret_cast<short*>(d);
         W.epose = s;
@@ -540,6 +587,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
     const double chi0 = currentChi;
     const bool any_free = B.nfree > 0 || !B.fix_points;
     const bool do_schur = !B.fix_points && n > 0;
+    const int nlow = n * (n + 1) / 2 + n;  // packed lower triangle + rhs column
 
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus)
@@ -751,14 +799,24 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             }
             PH_END(5);
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n]; LDL^T by wave 0
-            for (int idx = tid; idx < n * ld; idx += BA_THREADS) {
-                const int i = idx / ld, j = idx - i * ld;
+            for (int idx = tid; idx < nlow; idx += BA_THREADS) {
+                // element idx of the packed lower triangle (rows i >= j) followed by the rhs column
+                int i, j;
+                if (idx < nlow - n) {
+                    i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+                    while (i * (i + 1) / 2 > idx) --i;
+                    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+                    j = idx - i * (i + 1) / 2;
+                } else {
+                    i = idx - (nlow - n);
+                    j = n;
+                }
                 double gsum = 0;
                 if (do_schur) {
-                    int a = i, b = j;
-                    if (a / 16 > b / 16) {
-                        a = j;
-                        b = i;
+                    int a = j, b = i;  // j <= i (or the rhs column): tile row from the smaller index
+                    if (j == n) {
+                        a = i;
+                        b = n;
                     }
                     const int ti = a / 16, tj = b / 16;
                     const int tl = ti * B.NT - ti * (ti - 1) / 2 + (tj - ti);
@@ -778,14 +836,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
                     }
                 }
                 const int pi = sSlotPose[i / 6];
-                double v;
                 if (j == n) {
-                    v = sBp[6 * pi + i % 6] - gsum;
+                    W.S[i * ld + n] = sBp[6 * pi + i % 6] - gsum;
                 } else {
                     const int pj = sSlotPose[j / 6];
-                    v = ((pi == pj) ? sHpp[36 * pi + 6 * (i % 6) + (j % 6)] + (i == j ? lambda : 0.0) : 0.0) - gsum;
+                    const double v = ((pi == pj) ? sHpp[36 * pi + 6 * (i % 6) + (j % 6)] + (i == j ? lambda : 0.0) : 0.0) - gsum;
+                    W.S[i * ld + j] = v;
+                    W.S[j * ld + i] = v;
                 }
-                W.S[idx] = v;
             }
             __syncthreads();
             PH_END(6);
@@ -842,22 +900,29 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaDev B) {
             double scale = 0;
             if (g == 0 && tid < 6 * B.F && sSlot[tid / 6] >= 0) scale += sDx[tid] * (lambda * sDx[tid] + sBp[tid]);
             if (!B.fix_points) {
+                // per edge (all threads): t_e = Y_e^T (A~_e dx_p), parked in the first 3 slots of X's row? no:
+                // X~ is needed by the next trial -> use the rhs slots of S that the solver no longer needs
+                for (int el = tid; el < Eg; el += BA_THREADS) {
+                    const int p = W.epose[el];
+                    const double* A = W.M + BA_MSTRIDE * el;
+                    const double* Yr = W.Y + 6 * el;
+                    double a0 = 0, a1 = 0;  // A~ dx_p (zero rows for a fixed pose)
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        a0 += A[i] * sDx[6 * p + i];
+                        a1 += A[7 + i] * sDx[6 * p + i];
+                    }
+                    double* te = W.te + 3 * el;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) te[c] = Yr[c] * a0 + Yr[3 + c] * a1;
+                }
+                __syncthreads();
                 for (int l = tid; l < Lg; l += BA_THREADS) {
                     double r[3] = {W.cl[3 * l], W.cl[3 * l + 1], W.cl[3 * l + 2]};  // C^T (b_l - sum W^T dx_p)
                     for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
-                        const int el = W.ptl[k];
-                        const int p = W.epose[el];
-                        if (sSlot[p] < 0) continue;
-                        const double* A = W.M + BA_MSTRIDE * el;
-                        const double* Yr = W.Y + 6 * el;
-                        double a0 = 0, a1 = 0;  // A~ dx_p
+                        const double* te = W.te + 3 * W.ptl[k];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            a0 += A[i] * sDx[6 * p + i];
-                            a1 += A[7 + i] * sDx[6 * p + i];
-                        }
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) r[c] -= Yr[c] * a0 + Yr[3 + c] * a1;
+                        for (int c = 0; c < 3; ++c) r[c] -= te[c];
                     }
                     const double* cc = W.Cc + 6 * l;
                     double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
@@ -1031,7 +1096,7 @@ struct mvo_ba_handle {
     size_t bytes = 0;
     BaDev B{};
     int F = 0, L = 0;
-    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0;
+    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0, o_desc = 0;
     size_t lds = 16;
     bool fix_points = false;
 };
@@ -1133,12 +1198,14 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
         for (int k = 0; k < E; ++k) ptlist[cur[e_point[k]]++] = k;
     }
     std::vector<short> eof((size_t)std::max(L, 1) * std::max(nfree, 1), -1), dup(std::max(E, 1), -1);
+    int has_dups = 0;
     for (int k = E - 1; k >= 0; --k) {  // descending so that the chains run in ascending edge order
         const int sl = pose_slot[e_pose[k]];
         if (sl < 0) continue;
         const int lk = k - wg_edge[owner[e_point[k]]];
         short& head = eof[(size_t)e_point[k] * nfree + sl];
         dup[k] = head;
+        if (head >= 0) has_dups = 1;
         head = (short)lk;
     }
 
@@ -1154,7 +1221,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     const size_t upload_end = cv.off;
     const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
     const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg = cv.take((size_t)G * ntile * 256 * 8);
-    const size_t o_xs = cv.take((size_t)G * 32), o_bar = cv.take(64);
+    const size_t o_xs = cv.take((size_t)G * 32), o_bar = cv.take(64), o_desc = cv.take(sizeof(BaDev));
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();
     hipError_t he = hipMalloc((void**)&H->dev, total);
@@ -1210,6 +1277,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.use_mfma = g_ba_use_mfma;
     B.maxEg = maxEg;
     B.maxLg = maxLg;
+    B.has_dups = has_dups;
     B.f = p->focal;
     B.cx = p->cx;
     B.cy = p->cy;
@@ -1244,6 +1312,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     H->o_pout = o_pout;
     H->o_pts = o_pts;
     H->o_bar = o_bar;
+    H->o_desc = o_desc;
     H->fix_points = p->fix_points != 0;
     H->lds = wg_lds_bytes(n, ntile, nfree, maxEg, maxLg, p->fix_points);
     H->device = ctx->device;
@@ -1261,9 +1330,11 @@ int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
     }
     MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->lds));
     if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, 64, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc, &H->B, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
     {
         ProfScope ps(ctx, "k_ba_lm");
-        hipLaunchKernelGGL(k_ba_lm, dim3(H->B.G), dim3(BA_THREADS), H->lds, ctx->stream, H->B);
+        hipLaunchKernelGGL(k_ba_lm, dim3(H->B.G), dim3(BA_THREADS), H->lds, ctx->stream,
+                           (const BaDev*)(H->dev + H->o_desc));
     }
     MVO_HIP(hipGetLastError());
     return MVO_OK;
