@@ -316,11 +316,11 @@ class Context:
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(min(n, 64))}
 
     def debug_ba_phases(self):
-        arr = (C.c_longlong * 12)()
+        arr = (C.c_longlong * 16)()
         g = C.c_int()
-        self._chk(self.lib.mvo_debug_get_ba_phases(self.h, arr, 12, C.byref(g)))
+        self._chk(self.lib.mvo_debug_get_ba_phases(self.h, arr, 16, C.byref(g)))
         names = ["lin", "hpp", "pt+xchg", "t1", "schur", "publish+bar", "assemble", "ldlt", "backsub", "chi2",
-                 "chi2xchg", "total"]
+                 "chi2xchg", "total", "schur.loop", "schur.wait", "schur.acc", "x15"]
         return {"wgs": g.value, **{n: arr[i] for i, n in enumerate(names)}}
 
     def debug_level(self, level, blurred=False):

@@ -36,7 +36,7 @@ typedef unsigned long long u64;
 #define BA_LDS_BUDGET (140 * 1024)  // dynamic part; ~18 KB of static LDS come on top (160 KB per CU)
 #define BA_MAX_WGS 128
 
-#define BA_NPHASE 12
+#define BA_NPHASE 16
 struct BaStatsDev {
     int iterations, trials, terminated, error;
     double chi2_initial, chi2_final, lambda_final;
@@ -392,7 +392,8 @@ __device__ __forceinline__ double u_entry_nodup(const WgLds& W, int nfree, int n
 // partial G = U^T U over the own landmarks: every wave takes every 8th landmark, one MFMA per landmark and
 // tile pair (k-slots 0..2 = columns of U_l, slot 3 = 0); the waves' accumulators are combined in wave order.
 template <int NT>
-__device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int wave) {
+__device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int wave, long long* ph) {
+    long long ph_t = (long long)__builtin_amdgcn_s_memtime();
     constexpr int NPAIR = NT * (NT + 1) / 2;
     v4d acc[NPAIR];
 #pragma unroll
@@ -441,6 +442,9 @@ __device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int
                 for (int tj = ti; tj < NT; ++tj, ++a) acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[a], 0, 0, 0);
         }
     }
+    PH_END(12);
+    __syncthreads();
+    PH_END(13);
     for (int w = 0; w < BA_WAVES; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -453,6 +457,7 @@ __device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int
         }
         __syncthreads();
     }
+    PH_END(14);
 }
 
 // the same sums with plain loops (validation path, and windows with more than 10 free poses)
@@ -783,10 +788,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             // ============= T2: partial Schur blocks of the own landmarks, published for the other workgroups
             if (do_schur) {
                 if (B.use_mfma && B.NT <= BA_MFMA_MAX_NT) {
-                    if (B.NT == 1) schur_mfma<1>(B, W, Lg, lane, wave);
-                    else if (B.NT == 2) schur_mfma<2>(B, W, Lg, lane, wave);
-                    else if (B.NT == 3) schur_mfma<3>(B, W, Lg, lane, wave);
-                    else schur_mfma<4>(B, W, Lg, lane, wave);
+                    if (B.NT == 1) schur_mfma<1>(B, W, Lg, lane, wave, ph);
+                    else if (B.NT == 2) schur_mfma<2>(B, W, Lg, lane, wave, ph);
+                    else if (B.NT == 3) schur_mfma<3>(B, W, Lg, lane, wave, ph);
+                    else schur_mfma<4>(B, W, Lg, lane, wave, ph);
                 } else {
                     schur_valu(B, W, Lg);
                 }

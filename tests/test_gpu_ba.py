@@ -199,3 +199,20 @@ def test_resident_window_can_be_resolved_repeatedly(mvo, O, ctx):
     for P, X, st in res:
         assert np.array_equal(P, res[0][0]) and np.array_equal(X, res[0][1])      # deterministic re-solve
         assert _rel(P[:, :3, 3], Po[:, :3, 3]) < TOL and _rel(X, Xo) < TOL
+
+
+def test_config4_ba10_window(mvo, O, ctx):
+    """BASELINE configs[3]: 10-keyframe BA, 4000 landmarks, ~40k edges (KITTI-shaped): exercises G = 128 workgroups,
+    the 4-tile matrix-core Schur path and the LDS LDL^T (n = 60 > 32)."""
+    pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)
+    assert len(pb["edge_pose"]) > 30000
+    kw = dict(fix_points=False, max_iterations=3)
+    P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
+    assert st["trials"] == sto["trials"], (st, sto)
+    assert np.abs(P - Po).max() < 1e-8 and np.abs(X - Xo).max() < 1e-7, (st, sto)
+    pb["poses0"][:2] = pb["poses_gt"][:2]
+    P, X, st = ctx.bundle_adjustment(*_args(pb), fix_points=False, pose_fixed=_fix(10, 2))
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), fix_points=False, pose_fixed=_fix(10, 2))
+    assert _rel(P[:, :3, 3], Po[:, :3, 3]) < TOL and np.abs(P[:, :3, :3] - Po[:, :3, :3]).max() < TOL, (st, sto)
+    assert ctx.debug_ba_phases()["wgs"] >= 64

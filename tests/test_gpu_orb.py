@@ -103,6 +103,22 @@ def test_grid_latching_and_degenerate_images(mvo, O, ctx):
         assert 1500 < len(k) <= 2001
 
 
+def test_config4_kitti_shape_4000_keypoints(mvo, O, ctx):
+    """BASELINE configs[3]: 1242x375, 4000 keypoints."""
+    seq = mvo.synth.Sequence(1242, 375, 2, seed=99, tex_size=2048)
+    p = _cfg(mvo, O, ctx, max_keypoints=4000)
+    img = seq.frame(1)
+    k = ctx.calc_keypoints(img, cap=8192)
+    ko = O.calc_keypoints(img, p)
+    assert_struct_equal(k, ko.astype(k.dtype), "S1242")
+    k, d = ctx.calc_descriptors(img, k, reuse_pyramid=True)
+    ko, do = O.calc_descriptors(img, ko, p)
+    assert np.array_equal(d, do) and len(k) > 3000
+    idx, dist = ctx.match_knn2(d, d[::-1].copy())
+    io, do_ = O.match_knn2(d, d[::-1].copy())
+    assert np.array_equal(idx, io) and np.array_equal(dist, do_)
+
+
 def test_device_resident_image_and_descriptors(mvo, O, ctx):
     import torch
     p = _cfg(mvo, O, ctx, max_keypoints=1000)
