@@ -1,0 +1,51 @@
+"""Regenerates tests/golden/*.npz from the CPU ORACLE (run in the authoring container: `python tests/golden/make_golden.py`).
+
+The reference is C++ on OpenCV/g2o (not importable, not buildable here), so these fixtures are NOT outputs of the
+reference: they freeze the oracle's canonical arithmetic (parity unpinned) so that neither the
+oracle nor the HIP path can drift silently.  Inputs are stored with the outputs; sizes are kept tiny."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    O = graft.load_oracle()
+    S = graft.load_package().synth
+    # ---- ORB: one 176x144 BGR image, 3 levels
+    img = S.small_test_image(2024, 176, 144)
+    p = O.default_params(nlevels=3, max_keypoints=300)
+    cand = O.candidates(img, p)
+    k = O.calc_keypoints(img, p)
+    k2, d, rgb = O.calc_descriptors(img, k, p, want_rgb=True)
+    np.savez_compressed(os.path.join(HERE, "orb_176x144.npz"), image=img, candidates=cand, keypoints=k2, descriptors=d,
+                        rgb=rgb, level2_blurred=O.pyramid_level(img, p, 2, True))
+    # ---- matching: 150 x 170 descriptors with ties
+    q, t = S.match_inputs("ties", 150, 170, seed=5)
+    q2, t2 = S.match_inputs("perturbed", 150, 170, seed=6)
+    idx, dist = O.match_knn2(q, t)
+    out = dict(q=q, t=t, idx=idx, dist=dist, q2=q2, t2=t2)
+    for m in (1, 2):
+        out["m%d" % m] = O.match_features(q2, t2, m, 2.0, 1.0)
+    np.savez_compressed(os.path.join(HERE, "match_150x170.npz"), **out)
+    # ---- BA: 3 poses / 40 landmarks, pose-only (50 it) and full (3 it)
+    pb = S.ba_problem(3, 40, seed=77)
+    args = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+    P1, _, st1 = O.bundle_adjustment(*args, fix_points=True)
+    P2, X2, st2 = O.bundle_adjustment(*args, fix_points=False, max_iterations=3)
+    np.savez_compressed(os.path.join(HERE, "ba_3x40.npz"), poses0=pb["poses0"], points0=pb["points0"],
+                        edge_pose=pb["edge_pose"], edge_point=pb["edge_point"], edge_uv=pb["edge_uv"],
+                        intr=np.array([pb["focal"], pb["cx"], pb["cy"]]), pose_only_poses=P1,
+                        pose_only_chi2=np.array([st1["chi2_initial"], st1["chi2_final"]]), full3_poses=P2,
+                        full3_points=X2, full3_chi2=np.array([st2["chi2_initial"], st2["chi2_final"]]))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
