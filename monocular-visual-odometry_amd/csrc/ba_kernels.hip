@@ -284,21 +284,25 @@ __device__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, doub
     for (int k = 0; k < NR; ++k) a[k] = (lane < n && k < n) ? S[lane * ld + k] : (k == lane ? 1.0 : 0.0);
     a[NR] = lane < n ? S[lane * ld + n] : 0.0;
     int ok = 1;
+    double rinv = 0;  // lane j keeps 1 / pivot_j for the back-substitution
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const double d = readlane_d(a[j], j);
         ok &= (d > 0) && isfinite(d);
-        const double l = lane > j ? a[j] / d : 0.0;
+        const double r = 1.0 / d;  // uniform
+        rinv = lane == j ? r : rinv;
+        const double l = lane > j ? a[j] * r : 0.0;
 #pragma unroll
         for (int k = j + 1; k <= NR; ++k) a[k] -= l * readlane_d(a[k], j);
         __builtin_amdgcn_sched_barrier(0);  // no hoisting of the next step's readlanes (SGPR pressure -> spills)
     }
     double x = 0;
+    a[NR] *= rinv;  // z = D^-1 y
 #pragma unroll
     for (int j = NR - 1; j >= 0; --j) {
-        const double xj = readlane_d(a[NR], j) / readlane_d(a[j], j);
+        const double xj = readlane_d(a[NR], j);
         x = lane == j ? xj : x;
-        a[NR] -= a[j] * xj;
+        a[NR] -= (a[j] * rinv) * xj;  // rows i < j: U[i][j] / d_i; rows >= j are not read again
         __builtin_amdgcn_sched_barrier(0);
     }
     if (lane < n) xout[lane] = x;
