@@ -177,7 +177,8 @@ def algorithmic_work(args, shard):
         "k_harris_angle": ("hbm", (81 + 749) * 8000),
         "k_blur": ("hbm", 2 * P),
         "k_brief": ("hbm", (961 + 32 + 16) * K),
-        "k_knn2": ("valu", 16.0 * K * K),
+        "k_knn2_partial": ("valu", 16.0 * K * K),
+        "k_knn2_merge": ("hbm", 32 * 16.0 * K),
         "k_ba_lm": ("fp64", ba_trial),                               # x trials, filled in by the caller
     }, mvo
 
@@ -256,7 +257,7 @@ def main():
         default_workload = (args.width, args.height, args.max_kp, args.ba_poses, args.ba_points, args.ba) == \
             (640, 480, 2000, 5, 2000, "full")
         pmc_kb = {"k_ba_lm": 79711.3 + 25486.5, "k_fast_nms": 2 * 1526.0 + 818.7, "k_blur": 2 * 2217.1 + 1012.1,
-                  "k_knn2": 2 * 568.9 + 32.3}
+                  "k_knn2_partial": 2 * 568.9 + 32.3}
         roof["traffic"] = pmc_kb[dom] * 1024 if (default_workload and dom in pmc_kb) else None
         roof["traffic_source"] = "profiles/r01_pmc_fetch_write_size_per_kernel.csv" if roof["traffic"] else None
         roof["kernel"] = dom

@@ -5,10 +5,11 @@
 //   k_radius_l1 geometry::matchByRadiusAndBruteForce (feature_match.cpp:86-124).
 // Work decomposition (wave64): one LANE per query, the query's 256 bits live in 4 x u64 VGPRs; the train
 // descriptor of the current step is wave-uniform, so it is fetched with scalar loads (s_load_dwordx8) and
-// broadcast for free; distance = 4 x (v_xor + v_bcnt64).  A workgroup = 16 waves x the same 64 queries, each
-// wave scanning one contiguous slice of the train set in index order; the 16 partial (best, second) pairs are
-// merged through LDS in slice order with strict '<', which reproduces cv::batchDistance's tie rule exactly
-// (equal distances keep the lower train index).  Everything is integer: results are bit-exact.
+// broadcast for free; distance = 8 x (v_xor + v_bcnt_u32).  k_knn2_partial: one wave per (64 queries, train slice)
+// pair, 32 slices -> 1024 single-wave workgroups for 2000 x 2000, each scanning its slice in index order;
+// k_knn2_merge folds the 32 partial (best, second) pairs of a query in slice order with strict '<', which
+// reproduces cv::batchDistance's tie rule exactly (equal distances keep the lower train index).  k_radius_l1
+// keeps the single-kernel form (16 waves x 64 queries, LDS merge).  Everything is integer: results are bit-exact.
 // The whole working set (<= 2 x 128 KB) is L2-resident: the bound is VALU integer throughput, not HBM.
 #include "mvo_internal.h"
 
@@ -33,40 +34,44 @@ __device__ __forceinline__ void top2_insert(Top2& t, int d, int j) {
     t.i1 = ni1;
 }
 
-__global__ __launch_bounds__(1024) void k_knn2(const u64* __restrict__ q, int nq, const u64* __restrict__ t,
-                                               int nt, int32_t* __restrict__ out_idx,
-                                               int32_t* __restrict__ out_dist) {
-    __shared__ Top2 part[MK_WAVES][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// Stage 1: grid = (query groups of 64) x MK_SLICES train slices, ONE wave per workgroup -> >= 1024 waves for a
+// 2000 x 2000 call, so every SIMD of the chip gets work; each wave scans its slice in index order.
+#define MK_SLICES 32
+__global__ __launch_bounds__(64) void k_knn2_partial(const u64* __restrict__ q, int nq, const u64* __restrict__ t,
+                                                     int nt, int4* __restrict__ part) {
+    const int lane = threadIdx.x;
     const int qi = blockIdx.x * 64 + lane;
     const int qc = min(qi, nq - 1);
     const u64 q0 = q[4 * (size_t)qc], q1 = q[4 * (size_t)qc + 1], q2 = q[4 * (size_t)qc + 2],
               q3 = q[4 * (size_t)qc + 3];
-    const int slice = (nt + MK_WAVES - 1) / MK_WAVES;
-    const int j0 = wave * slice, j1 = min(nt, j0 + slice);
+    const int slice = (nt + MK_SLICES - 1) / MK_SLICES;
+    const int j0 = blockIdx.y * slice, j1 = min(nt, j0 + slice);
     Top2 b = {INT_MAX, -1, INT_MAX, -1};
-#pragma unroll 4
+#pragma unroll 8
     for (int j = j0; j < j1; ++j) {
         const u64* tj = t + 4 * (size_t)j;  // wave-uniform address -> scalar loads
         int d = __popcll(q0 ^ tj[0]) + __popcll(q1 ^ tj[1]) + __popcll(q2 ^ tj[2]) + __popcll(q3 ^ tj[3]);
         top2_insert(b, d, j);
     }
-    part[wave][lane] = b;
-    __syncthreads();
-    if (wave == 0 && qi < nq) {
-        Top2 r = part[0][lane];
-#pragma unroll
-        for (int w = 1; w < MK_WAVES; ++w) {
-            Top2 p = part[w][lane];
-            if (p.i0 >= 0) top2_insert(r, p.d0, p.i0);
-            if (p.i1 >= 0) top2_insert(r, p.d1, p.i1);
-        }
-        out_idx[2 * qi] = r.i0;
-        out_idx[2 * qi + 1] = r.i1;
-        out_dist[2 * qi] = r.d0;
-        out_dist[2 * qi + 1] = r.d1;
+    if (qi < nq) part[(size_t)blockIdx.y * nq + qi] = make_int4(b.d0, b.i0, b.d1, b.i1);
+}
+// Stage 2: merge the MK_SLICES partial (best, second) pairs of a query in slice order with strict '<'.
+__global__ __launch_bounds__(256) void k_knn2_merge(const int4* __restrict__ part, int nq, int32_t* __restrict__ out_idx,
+                                                    int32_t* __restrict__ out_dist) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    int4 p0 = part[qi];
+    Top2 r = {p0.x, p0.y, p0.z, p0.w};
+#pragma unroll 8
+    for (int s = 1; s < MK_SLICES; ++s) {
+        const int4 p = part[(size_t)s * nq + qi];
+        if (p.y >= 0) top2_insert(r, p.x, p.y);
+        if (p.w >= 0) top2_insert(r, p.z, p.w);
     }
+    out_idx[2 * qi] = r.i0;
+    out_idx[2 * qi + 1] = r.i1;
+    out_dist[2 * qi] = r.d0;
+    out_dist[2 * qi + 1] = r.d1;
 }
 
 __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__ q, const float2* __restrict__ qxy,
@@ -116,9 +121,18 @@ __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__
 
 int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out) {
     if (nq <= 0) return MVO_OK;
-    ProfScope ps(ctx, "k_knn2");
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64), dim3(1024), 0, ctx->stream, (const u64*)d_q, nq,
-                       (const u64*)d_t, nt, d_out, d_out + 2 * (size_t)nq);
+    // d_part: MK_SLICES x nq int4 partials live behind the nq x 4 int32 result block
+    int4* d_part = reinterpret_cast<int4*>(d_out + 4 * (size_t)nq);
+    {
+        ProfScope ps(ctx, "k_knn2_partial");
+        hipLaunchKernelGGL(k_knn2_partial, dim3((nq + 63) / 64, MK_SLICES), dim3(64), 0, ctx->stream, (const u64*)d_q, nq,
+                           (const u64*)d_t, nt, d_part);
+    }
+    {
+        ProfScope ps(ctx, "k_knn2_merge");
+        hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, d_part, nq, d_out,
+                           d_out + 2 * (size_t)nq);
+    }
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

@@ -268,7 +268,7 @@ static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
         int cap = std::max(4096, nq + nq / 2);
         MVO_HIP(hipMalloc((void**)&ctx->d_mq, (size_t)cap * 32));
         MVO_HIP(hipMalloc((void**)&ctx->d_mqxy, (size_t)cap * 8));
-        MVO_HIP(hipMalloc((void**)&ctx->d_mout, (size_t)cap * 16));
+        MVO_HIP(hipMalloc((void**)&ctx->d_mout, (size_t)cap * (16 + 32 * 16)));  // results + 32 slices of partials
         ctx->m_cap_q = cap;
     }
     if (nt > ctx->m_cap_t) {
