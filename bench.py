@@ -173,7 +173,8 @@ def algorithmic_work(args, shard):
         "k_gray_border": ("hbm", w * h * 3 + w * h),
         "k_resize_border": ("hbm", 2 * (P - w * h) / 3.0),            # per launch (3 launches / frame)
         "k_fast_nms": ("hbm", P),
-        "k_scan_emit": ("hbm", 12 * 12000),
+        "k_scan_cells": ("hbm", 8 * 12400),
+        "k_emit_cells": ("hbm", 12 * 12400 + 16 * 8000),
         "k_harris_angle": ("hbm", (81 + 749) * 8000),
         "k_blur": ("hbm", 2 * P),
         "k_brief": ("hbm", (961 + 32 + 16) * K),

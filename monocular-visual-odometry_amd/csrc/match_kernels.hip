@@ -34,44 +34,68 @@ __device__ __forceinline__ void top2_insert(Top2& t, int d, int j) {
     t.i1 = ni1;
 }
 
-// Stage 1: grid = (query groups of 64) x MK_SLICES train slices, ONE wave per workgroup -> >= 1024 waves for a
-// 2000 x 2000 call, so every SIMD of the chip gets work; each wave scans its slice in index order.
+// Stage 1: grid = (query groups of 64) x MK_SLICES train slices, ONE wave per workgroup -> 1024 waves for a
+// 2000 x 2000 call (every SIMD of the chip gets one).  The wave first parks its slice in registers -- lane j holds
+// train descriptor j of the current 64-train chunk (one coalesced 2 KB read) -- and then broadcasts descriptor j
+// to all lanes with v_readlane: no memory access and no LDS in the pair loop.
 #define MK_SLICES 32
-__global__ __launch_bounds__(64) void k_knn2_partial(const u64* __restrict__ q, int nq, const u64* __restrict__ t,
+__device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__global__ __launch_bounds__(64) void k_knn2_partial(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t,
                                                      int nt, int4* __restrict__ part) {
     const int lane = threadIdx.x;
     const int qi = blockIdx.x * 64 + lane;
     const int qc = min(qi, nq - 1);
-    const u64 q0 = q[4 * (size_t)qc], q1 = q[4 * (size_t)qc + 1], q2 = q[4 * (size_t)qc + 2],
-              q3 = q[4 * (size_t)qc + 3];
+    const uint4 qa = q[2 * (size_t)qc], qb = q[2 * (size_t)qc + 1];
     const int slice = (nt + MK_SLICES - 1) / MK_SLICES;
     const int j0 = blockIdx.y * slice, j1 = min(nt, j0 + slice);
     Top2 b = {INT_MAX, -1, INT_MAX, -1};
-#pragma unroll 8
-    for (int j = j0; j < j1; ++j) {
-        const u64* tj = t + 4 * (size_t)j;  // wave-uniform address -> scalar loads
-        int d = __popcll(q0 ^ tj[0]) + __popcll(q1 ^ tj[1]) + __popcll(q2 ^ tj[2]) + __popcll(q3 ^ tj[3]);
-        top2_insert(b, d, j);
+    for (int c0 = j0; c0 < j1; c0 += 64) {
+        const int cn = min(64, j1 - c0);  // wave-uniform
+        const int tl = min(c0 + lane, nt - 1);
+        const uint4 ta = t[2 * (size_t)tl], tb = t[2 * (size_t)tl + 1];
+#pragma unroll 4
+        for (int j = 0; j < cn; ++j) {
+            int d = __popc(qa.x ^ rl(ta.x, j)) + __popc(qa.y ^ rl(ta.y, j)) + __popc(qa.z ^ rl(ta.z, j)) +
+                    __popc(qa.w ^ rl(ta.w, j)) + __popc(qb.x ^ rl(tb.x, j)) + __popc(qb.y ^ rl(tb.y, j)) +
+                    __popc(qb.z ^ rl(tb.z, j)) + __popc(qb.w ^ rl(tb.w, j));
+            top2_insert(b, d, c0 + j);
+        }
     }
     if (qi < nq) part[(size_t)blockIdx.y * nq + qi] = make_int4(b.d0, b.i0, b.d1, b.i1);
 }
-// Stage 2: merge the MK_SLICES partial (best, second) pairs of a query in slice order with strict '<'.
+// Stage 2: one lane per (query, slice); the 32 partial pairs of a query are folded by a shuffle butterfly.  The
+// fold keeps the two lexicographically smallest (distance, train index) pairs, which is exactly the strict-'<'
+// in-order scan (indices are unique), so the order of the fold does not matter.
+__device__ __forceinline__ bool pair_less(int d, int i, int e, int j) {  // (d,i) < (e,j); index -1 = empty = +inf
+    return j < 0 ? i >= 0 : (i >= 0 && (d < e || (d == e && i < j)));
+}
 __global__ __launch_bounds__(256) void k_knn2_merge(const int4* __restrict__ part, int nq, int32_t* __restrict__ out_idx,
                                                     int32_t* __restrict__ out_dist) {
-    const int qi = blockIdx.x * 256 + threadIdx.x;
-    if (qi >= nq) return;
-    int4 p0 = part[qi];
-    Top2 r = {p0.x, p0.y, p0.z, p0.w};
-#pragma unroll 8
-    for (int s = 1; s < MK_SLICES; ++s) {
-        const int4 p = part[(size_t)s * nq + qi];
-        if (p.y >= 0) top2_insert(r, p.x, p.y);
-        if (p.w >= 0) top2_insert(r, p.z, p.w);
+    const int s = threadIdx.x & 31;
+    const int qi = blockIdx.x * 8 + (threadIdx.x >> 5);
+    int4 p = make_int4(INT_MAX, -1, INT_MAX, -1);
+    if (qi < nq) p = part[(size_t)s * nq + qi];
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        int4 r;
+        r.x = __shfl_xor(p.x, o);
+        r.y = __shfl_xor(p.y, o);
+        r.z = __shfl_xor(p.z, o);
+        r.w = __shfl_xor(p.w, o);
+        // merge two sorted pairs (p.x,p.y)<=(p.z,p.w) and (r.x,r.y)<=(r.z,r.w)
+        const bool pf = pair_less(p.x, p.y, r.x, r.y);
+        const int b0d = pf ? p.x : r.x, b0i = pf ? p.y : r.y;          // overall best
+        const int cd = pf ? r.x : p.x, ci = pf ? r.y : p.y;            // loser of the heads
+        const int nd = pf ? p.z : r.z, ni = pf ? p.w : r.w;            // second of the winner's list
+        const bool sf = pair_less(cd, ci, nd, ni);
+        p = make_int4(b0d, b0i, sf ? cd : nd, sf ? ci : ni);
     }
-    out_idx[2 * qi] = r.i0;
-    out_idx[2 * qi + 1] = r.i1;
-    out_dist[2 * qi] = r.d0;
-    out_dist[2 * qi + 1] = r.d1;
+    if (s == 0 && qi < nq) {
+        out_idx[2 * qi] = p.y;
+        out_idx[2 * qi + 1] = p.w;
+        out_dist[2 * qi] = p.y >= 0 ? p.x : INT_MAX;
+        out_dist[2 * qi + 1] = p.w >= 0 ? p.z : INT_MAX;
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__ q, const float2* __restrict__ qxy,
@@ -125,12 +149,12 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
     int4* d_part = reinterpret_cast<int4*>(d_out + 4 * (size_t)nq);
     {
         ProfScope ps(ctx, "k_knn2_partial");
-        hipLaunchKernelGGL(k_knn2_partial, dim3((nq + 63) / 64, MK_SLICES), dim3(64), 0, ctx->stream, (const u64*)d_q, nq,
-                           (const u64*)d_t, nt, d_part);
+        hipLaunchKernelGGL(k_knn2_partial, dim3((nq + 63) / 64, MK_SLICES), dim3(64), 0, ctx->stream, (const uint4*)d_q,
+                           nq, (const uint4*)d_t, nt, d_part);
     }
     {
         ProfScope ps(ctx, "k_knn2_merge");
-        hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, d_part, nq, d_out,
+        hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 7) / 8), dim3(256), 0, ctx->stream, d_part, nq, d_out,
                            d_out + 2 * (size_t)nq);
     }
     MVO_HIP(hipGetLastError());

@@ -85,6 +85,7 @@ struct mvo_ctx {
     ResizeEntry* d_tabs = nullptr;
     unsigned long long* d_cell_mask = nullptr;
     int32_t* d_cell_cnt = nullptr;
+    int32_t* d_cell_off = nullptr;
     CandHeader* d_hdr = nullptr;
     DevCandidate* d_cand = nullptr;
     int cand_cap = 0;

@@ -132,6 +132,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     free_dev(ctx->d_tabs);
     free_dev(ctx->d_cell_mask);
     free_dev(ctx->d_cell_cnt);
+    free_dev(ctx->d_cell_off);
     MVO_HIP(hipMalloc((void**)&ctx->d_raw, bytes));
     MVO_HIP(hipMalloc((void**)&ctx->d_blur, bytes));
     MVO_HIP(hipMalloc((void**)&ctx->d_score, bytes));
@@ -140,7 +141,8 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     MVO_HIP(hipMemsetAsync(ctx->d_score, 0, bytes, ctx->stream));
     MVO_HIP(hipMalloc((void**)&ctx->d_tabs, tab * sizeof(ResizeEntry)));
     MVO_HIP(hipMalloc((void**)&ctx->d_cell_mask, (size_t)cells * 8));
-    MVO_HIP(hipMalloc((void**)&ctx->d_cell_cnt, (size_t)cells * 4));
+    MVO_HIP(hipMalloc((void**)&ctx->d_cell_cnt, (size_t)cells * 4 + 64));
+    MVO_HIP(hipMalloc((void**)&ctx->d_cell_off, (size_t)cells * 4 + 64));
     std::vector<ResizeEntry> tabs(tab);
     for (int l = 1; l < p.nlevels; ++l) {
         fill_resize_tab(&tabs[P.lv[l].tab_off], P.lv[l - 1].w, P.lv[l].w);

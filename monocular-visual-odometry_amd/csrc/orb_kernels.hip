@@ -9,7 +9,8 @@
 //   k_resize_border level l from level l-1 (fixed-point bilinear) + frame
 //   k_fast_nms      FAST-9/16 score + 3x3 NMS + 31-px border; one 64x16 tile per workgroup; emits one 64-bit
 //                   survivor mask per (row, 64-px column) cell via wave ballot
-//   k_scan_emit     exclusive scan of the cell counts -> canonical (level,row,col) candidate list
+//   k_scan_cells    exclusive scan of the cell counts (one workgroup) -> per-cell offsets + per-level starts
+//   k_emit_cells    one thread per cell expands its mask into the canonical (level,row,col) candidate list
 //   k_harris_angle  one WAVE per candidate: 7x7 Harris (49 lanes) + IC angle over the 749-px disc, wave
 //                   shuffle reductions
 //   k_blur          separable 7x7 fixed-point Gaussian through LDS, frame copied unblurred
@@ -205,19 +206,24 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ ra
 }
 
 // ------------------------------------------------------------------------------------------------ scan + emit
-__global__ __launch_bounds__(1024) void k_scan_emit(const u64* __restrict__ cell_mask,
-                                                    const int32_t* __restrict__ cell_cnt,
-                                                    const uint8_t* __restrict__ score,
-                                                    DevCandidate* __restrict__ cand, CandHeader* __restrict__ hdr,
-                                                    PyrInfo P, int cand_cap) {
+// k_scan_cells: ONE workgroup turns the per-cell survivor counts into exclusive offsets (canonical order = level,
+// row, 64-px column) and fills the header; k_emit_cells: one thread per cell expands its ballot mask.
+__global__ __launch_bounds__(1024) void k_scan_cells(const int32_t* __restrict__ cell_cnt, int32_t* __restrict__ cell_off,
+                                                     CandHeader* __restrict__ hdr, PyrInfo P) {
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n_cells;
-    const int chunk = (n + 1023) / 1024;
+    const int chunk = ((n + 1023) / 1024 + 3) & ~3;  // multiple of 4: int4 loads
     const int c0 = tid * chunk, c1 = min(n, c0 + chunk);
     int local = 0;
-    for (int c = c0; c < c1; ++c) local += cell_cnt[c];
-    // inclusive scan inside the wave
+    for (int c = c0; c < c1; c += 4) {
+        if (c + 4 <= c1) {
+            const int4 v = *reinterpret_cast<const int4*>(cell_cnt + c);
+            local += v.x + v.y + v.z + v.w;
+        } else {
+            for (int k = c; k < c1; ++k) local += cell_cnt[k];
+        }
+    }
     int incl = local;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -229,9 +235,9 @@ __global__ __launch_bounds__(1024) void k_scan_emit(const u64* __restrict__ cell
     int wbase = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        int s = wsum[w];
-        if (w < wave) wbase += s;
-        total += s;
+        int sv = wsum[w];
+        if (w < wave) wbase += sv;
+        total += sv;
     }
     int off = wbase + incl - local;
     if (tid == 0) {
@@ -239,27 +245,40 @@ __global__ __launch_bounds__(1024) void k_scan_emit(const u64* __restrict__ cell
         hdr->level_start[P.nlevels] = total;
     }
     for (int c = c0; c < c1; ++c) {
-        const int lvl = find_level_by(P, c, 1);
-        const LevelInfo L = P.lv[lvl];
-        if (c == L.cell_off) hdr->level_start[lvl] = off;
-        const int rc = c - L.cell_off;
-        const int y = rc / L.tiles_x, tx = rc - y * L.tiles_x;
-        u64 m = cell_mask[c];
-        while (m) {
-            int b = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            int x = tx * FT_W + b;
-            if (off < cand_cap) {
-                DevCandidate cd;
-                cd.x = (int16_t)x;
-                cd.y = (int16_t)y;
-                cd.level_score = (lvl << 16) | score[L.off + (size_t)(y + MVO_BORDER) * L.stride + MVO_BORDER + x];
-                cd.harris = 0.f;
-                cd.angle = 0.f;
-                cand[off] = cd;
-            }
-            ++off;
+#pragma unroll
+        for (int l = 0; l < MVO_MAX_LEVELS; ++l)
+            if (l < P.nlevels && c == P.lv[l].cell_off) hdr->level_start[l] = off;
+        cell_off[c] = off;
+        off += cell_cnt[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_emit_cells(const u64* __restrict__ cell_mask, const int32_t* __restrict__ cell_off,
+                                                    const uint8_t* __restrict__ score, DevCandidate* __restrict__ cand,
+                                                    PyrInfo P, int cand_cap) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= P.n_cells) return;
+    u64 m = cell_mask[c];
+    if (!m) return;
+    int off = cell_off[c];
+    const int lvl = find_level_by(P, c, 1);
+    const LevelInfo L = P.lv[lvl];
+    const int rc = c - L.cell_off;
+    const int y = rc / L.tiles_x, tx = rc - y * L.tiles_x;
+    while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int x = tx * FT_W + b;
+        if (off < cand_cap) {
+            DevCandidate cd;
+            cd.x = (int16_t)x;
+            cd.y = (int16_t)y;
+            cd.level_score = (lvl << 16) | score[L.off + (size_t)(y + MVO_BORDER) * L.stride + MVO_BORDER + x];
+            cd.harris = 0.f;
+            cd.angle = 0.f;
+            cand[off] = cd;
         }
+        ++off;
     }
 }
 
@@ -492,9 +511,13 @@ int orb_launch_detect(mvo_ctx* ctx) {
                            ctx->d_cell_mask, ctx->d_cell_cnt, P, ctx->orb.fast_threshold);
     }
     {
-        ProfScope ps(ctx, "k_scan_emit");
-        hipLaunchKernelGGL(k_scan_emit, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cell_mask, ctx->d_cell_cnt,
-                           ctx->d_score, ctx->d_cand, ctx->d_hdr, P, ctx->cand_cap);
+        ProfScope ps(ctx, "k_scan_cells");
+        hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cell_cnt, ctx->d_cell_off, ctx->d_hdr, P);
+    }
+    {
+        ProfScope ps(ctx, "k_emit_cells");
+        hipLaunchKernelGGL(k_emit_cells, dim3((P.n_cells + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cell_mask,
+                           ctx->d_cell_off, ctx->d_score, ctx->d_cand, P, ctx->cand_cap);
     }
     {
         ProfScope ps(ctx, "k_harris_angle");
