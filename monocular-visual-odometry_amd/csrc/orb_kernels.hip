@@ -213,43 +213,65 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int32_t* __restrict__
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = P.n_cells;
-    const int chunk = ((n + 1023) / 1024 + 3) & ~3;  // multiple of 4: int4 loads
-    const int c0 = tid * chunk, c1 = min(n, c0 + chunk);
-    int local = 0;
-    for (int c = c0; c < c1; c += 4) {
-        if (c + 4 <= c1) {
-            const int4 v = *reinterpret_cast<const int4*>(cell_cnt + c);
-            local += v.x + v.y + v.z + v.w;
-        } else {
-            for (int k = c; k < c1; ++k) local += cell_cnt[k];
+    // every thread owns CH consecutive cells, held in registers (int4 loads / stores); CH*1024 >= n is guaranteed
+    // by the launcher (it picks the instantiation)
+    constexpr int CH = 16;
+    const int passes = (n + CH * 1024 - 1) / (CH * 1024);
+    int carry = 0;
+    for (int ps = 0; ps < passes; ++ps) {
+        const int c0 = (ps * 1024 + tid) * CH;
+        int cnt[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k += 4) {
+            int4 v = make_int4(0, 0, 0, 0);
+            if (c0 + k + 4 <= n) {
+                v = *reinterpret_cast<const int4*>(cell_cnt + c0 + k);
+            } else {
+                if (c0 + k < n) v.x = cell_cnt[c0 + k];
+                if (c0 + k + 1 < n) v.y = cell_cnt[c0 + k + 1];
+                if (c0 + k + 2 < n) v.z = cell_cnt[c0 + k + 2];
+            }
+            cnt[k] = v.x;
+            cnt[k + 1] = v.y;
+            cnt[k + 2] = v.z;
+            cnt[k + 3] = v.w;
         }
-    }
-    int incl = local;
+        int local = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
+        for (int k = 0; k < CH; ++k) local += cnt[k];
+        int incl = local;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
-        int sv = wsum[w];
-        if (w < wave) wbase += sv;
-        total += sv;
+        for (int o = 1; o < 64; o <<= 1) {
+            int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            int sv = wsum[w];
+            if (w < wave) wbase += sv;
+            total += sv;
+        }
+        int off = carry + wbase + incl - local;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = c0 + k;
+            if (c < n) {
+#pragma unroll
+                for (int l = 0; l < MVO_MAX_LEVELS; ++l)
+                    if (l < P.nlevels && c == P.lv[l].cell_off) hdr->level_start[l] = off;
+                cell_off[c] = off;
+            }
+            off += cnt[k];
+        }
+        carry += total;
     }
-    int off = wbase + incl - local;
     if (tid == 0) {
-        hdr->n_total = total;
-        hdr->level_start[P.nlevels] = total;
-    }
-    for (int c = c0; c < c1; ++c) {
-#pragma unroll
-        for (int l = 0; l < MVO_MAX_LEVELS; ++l)
-            if (l < P.nlevels && c == P.lv[l].cell_off) hdr->level_start[l] = off;
-        cell_off[c] = off;
-        off += cell_cnt[c];
+        hdr->n_total = carry;
+        hdr->level_start[P.nlevels] = carry;
     }
 }
 
