@@ -45,7 +45,7 @@ def parse():
                     help="full = points + poses free (reference is_fix_map_pts=false branch, no vertex fixed)")
     ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=150)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--max-kp", type=int, default=2000)
