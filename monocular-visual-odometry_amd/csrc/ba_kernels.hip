@@ -322,7 +322,7 @@ struct WgLds {
     double* bl;    // maxLg x 3
     double* Cc;    // maxLg x 6   Cholesky factor of (H_ll + lambda I)^-1
     double* cl;    // maxLg x 3   C^T b_l
-    double* tile;  // ntile x 256
+    double* tile;  // 4 x ntile x 256 (slot 0 = result)
     double* te;    // maxEg x 3   per-edge back-substitution terms
     short* epose;  // maxEg
     short* ept;    // maxEg  local landmark index
@@ -333,7 +333,7 @@ struct WgLds {
 };
 __host__ __device__ inline size_t wg_lds_doubles(int n, int ntile, int maxEg, int maxLg, int fix_points) {
     size_t d = (size_t)n * (n + 1) + (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
-    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256;
+    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256 * 4;
     return d;
 }
 __host__ __device__ inline size_t wg_lds_bytes(int n, int ntile, int nfree, int maxEg, int maxLg, int fix_points) {
@@ -449,18 +449,34 @@ __device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int
     PH_END(12);
     __syncthreads();
     PH_END(13);
-    for (int w = 0; w < BA_WAVES; ++w) {
-        if (wave == w) {
+    // fixed reduction tree over the 8 waves through NPAIR*256-double slots: (0..3) += (4..7), (0,1) += (2,3), 0 += 1
+    const int base = 16 * (lane >> 4) + (lane & 15);
+#pragma unroll
+    for (int half = BA_WAVES / 2; half >= 1; half >>= 1) {
+        if (wave >= half && wave < 2 * half) {
+            double* slot = W.tile + (size_t)(wave - half) * NPAIR * 256;
 #pragma unroll
             for (int a = 0; a < NPAIR; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = a * 256 + 16 * ((lane >> 4) + 4 * j) + (lane & 15);
-                    W.tile[idx] = (w == 0 ? 0.0 : W.tile[idx]) + acc[a][j];
-                }
+                for (int j = 0; j < 4; ++j) slot[a * 256 + base + 64 * j] = acc[a][j];
+        }
+        __syncthreads();
+        if (wave < half) {
+            const double* slot = W.tile + (size_t)wave * NPAIR * 256;
+#pragma unroll
+            for (int a = 0; a < NPAIR; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][j] += slot[a * 256 + base + 64 * j];
         }
         __syncthreads();
     }
+    if (wave == 0) {
+#pragma unroll
+        for (int a = 0; a < NPAIR; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) W.tile[a * 256 + base + 64 * j] = acc[a][j];
+    }
+    __syncthreads();
     PH_END(14);
 }
 
@@ -489,7 +505,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
     __shared__ double sP[BA_MAX_POSES * 8], sPbak[BA_MAX_POSES * 8];  // q[4] t[3] pad
     __shared__ double sR[BA_MAX_POSES * 9], sT[BA_MAX_POSES * 3];
     __shared__ double sHpp[BA_MAX_POSES * 36], sBp[BA_MAX_POSES * 6], sDx[BA_MAX_POSES * 6];
-    __shared__ double sPart[BA_WAVES * 49];
     __shared__ double sScr[BA_WAVES];
     __shared__ double sLcol[6 * BA_MAX_POSES], sCol[6 * BA_MAX_POSES], sSol[6 * BA_MAX_POSES];
     __shared__ double sX[BA_MAX_WGS * 2];
@@ -532,7 +547,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             W.cl = d;
             d += (size_t)B.maxLg * 3;
             W.tile = d;
-            d += (size_t)B.ntile * 256;
+            d += (size_t)B.ntile * 256 * 4;  // 4 slots for the wave reduction tree; slot 0 holds the result
             W.te = d;
             d += (size_t)B.maxEg * 3;
         }
@@ -638,51 +653,56 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
         }
         __syncthreads();
         PH_END(0);
-        // ================= HPP: partial [H_pp | -b_p] = M^T M over the own edges of every free pose
-        for (int p = 0; p < B.F; ++p) {
-            if (sSlot[p] < 0) continue;
-            const int s = sPoseStart[p], e = sPoseStart[p + 1];
-            if (B.use_mfma) {
+        // ================= HPP: partial [H_pp | -b_p] = M^T M over the own edges of every free pose.
+        // Matrix-core path: wave w owns the poses p = w, w + 8, ... and accumulates each of them alone (no
+        // cross-wave reduction, one barrier for the whole phase).
+        if (B.use_mfma) {
+            const int col = lane & 15;
+            for (int p = wave; p < B.F; p += BA_WAVES) {
+                if (sSlot[p] < 0) continue;
+                const int s = sPoseStart[p], e = sPoseStart[p + 1];
                 const int steps = (2 * (e - s) + 3) / 4;
-                v4d acc = {0, 0, 0, 0};
-                const int col = lane & 15;
-                for (int st = wave; st < steps; st += BA_WAVES) {
-                    const int row = 4 * st + (lane >> 4);
-                    const int ed = s + (row >> 1);
-                    double v = (ed < e && col < 7) ? W.M[BA_MSTRIDE * ed + 7 * (row & 1) + col] : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+                v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};  // two chains hide the MFMA latency
+                for (int st = 0; st < steps; st += 2) {
+                    const int row0 = 4 * st + (lane >> 4), row1 = row0 + 4;
+                    const int ed0 = s + (row0 >> 1), ed1 = s + (row1 >> 1);
+                    const double v0 = (ed0 < e && col < 7) ? W.M[BA_MSTRIDE * ed0 + 7 * (row0 & 1) + col] : 0.0;
+                    const double v1 = (ed1 < e && col < 7) ? W.M[BA_MSTRIDE * ed1 + 7 * (row1 & 1) + col] : 0.0;
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int rg = (lane >> 4) + 4 * j;
-                    if (rg < 7 && col < 7) sPart[wave * 49 + rg * 7 + col] = acc[j];
+                    if (rg < 7 && col < 7) {
+                        const double gsum = acc0[j] + acc1[j];
+                        if (B.G > 1) {
+                            xstore(B.xHpp + ((size_t)g * B.F + p) * 49 + rg * 7 + col, gsum);
+                        } else {
+                            if (rg < 6 && col < 6) sHpp[36 * p + 6 * rg + col] = gsum;
+                            if (rg < 6 && col == 6) sBp[6 * p + rg] = -gsum;
+                        }
+                    }
                 }
-                __syncthreads();
-                if (tid < 49) {
-                    double gsum = 0;
-#pragma unroll
-                    for (int w = 0; w < BA_WAVES; ++w) gsum += sPart[w * 49 + tid];
-                    sPart[tid] = gsum;  // own slot of wave 0: only this thread reads it again
-                }
-            } else {
+            }
+        } else {
+            for (int p = 0; p < B.F; ++p) {
+                if (sSlot[p] < 0) continue;
+                const int s = sPoseStart[p], e = sPoseStart[p + 1];
                 if (tid < 49) {
                     const int i = tid / 7, j = tid % 7;
                     double gsum = 0;
                     for (int r = 2 * s; r < 2 * e; ++r) gsum += W.M[7 * r + i] * W.M[7 * r + j];
-                    sPart[tid] = gsum;
+                    if (B.G > 1) {
+                        xstore(B.xHpp + ((size_t)g * B.F + p) * 49 + tid, gsum);
+                    } else {
+                        if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = gsum;
+                        if (i < 6 && j == 6) sBp[6 * p + i] = -gsum;
+                    }
                 }
             }
-            if (tid < 49) {
-                if (B.G > 1) {
-                    xstore(B.xHpp + ((size_t)g * B.F + p) * 49 + tid, sPart[tid]);
-                } else {
-                    const int i = tid / 7, j = tid % 7;
-                    if (i < 6 && j < 6) sHpp[36 * p + 6 * i + j] = sPart[tid];
-                    if (i < 6 && j == 6) sBp[6 * p + i] = -sPart[tid];
-                }
-            }
-            __syncthreads();
         }
+        __syncthreads();
         PH_END(1);
         // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks
         double maxdiag = 0;
@@ -833,12 +853,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                     if (B.G > 1) {
                         const double* src = B.xG + off;
                         const size_t stride = (size_t)B.ntile * 256;
-                        for (int w0 = 0; w0 < B.G; w0 += 16) {  // 16 independent loads in flight, summed in order
-                            double v[16];
+                        for (int w0 = 0; w0 < B.G; w0 += 32) {  // 32 independent loads in flight, summed in order
+                            double v[32];
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) v[q] = (w0 + q < B.G) ? xload(src + (size_t)(w0 + q) * stride) : 0.0;
+                            for (int q = 0; q < 32; ++q) v[q] = (w0 + q < B.G) ? xload(src + (size_t)(w0 + q) * stride) : 0.0;
 #pragma unroll
-                            for (int q = 0; q < 16; ++q) gsum += v[q];
+                            for (int q = 0; q < 32; ++q) gsum += v[q];
                         }
                     } else {
                         gsum = W.tile[off];
