@@ -35,6 +35,7 @@ typedef unsigned long long u64;
 #define BA_MSTRIDE 14     // doubles per edge in M: two rows [A~(6) | e~]
 #define BA_LDS_BUDGET (140 * 1024)  // dynamic part; ~18 KB of static LDS come on top (160 KB per CU)
 #define BA_MAX_WGS 128
+#define BA_TILE_SLOTS(ntile) ((ntile) <= 3 ? 4 : 1)  // LDS slots for the wave reduction tree (big systems: 1, sequential)
 
 #define BA_NPHASE 16
 struct BaStatsDev {
@@ -333,7 +334,7 @@ struct WgLds {
 };
 __host__ __device__ inline size_t wg_lds_doubles(int n, int ntile, int maxEg, int maxLg, int fix_points) {
     size_t d = (size_t)n * (n + 1) + (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
-    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256 * 4;
+    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256 * BA_TILE_SLOTS(ntile);
     return d;
 }
 __host__ __device__ inline size_t wg_lds_bytes(int n, int ntile, int nfree, int maxEg, int maxLg, int fix_points) {
@@ -449,34 +450,49 @@ __device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int
     PH_END(12);
     __syncthreads();
     PH_END(13);
-    // fixed reduction tree over the 8 waves through NPAIR*256-double slots: (0..3) += (4..7), (0,1) += (2,3), 0 += 1
     const int base = 16 * (lane >> 4) + (lane & 15);
+    if (BA_TILE_SLOTS(NPAIR) == 4) {
+        // fixed reduction tree over the 8 waves through NPAIR*256-double slots: (0..3) += (4..7), (0,1) += (2,3), 0 += 1
 #pragma unroll
-    for (int half = BA_WAVES / 2; half >= 1; half >>= 1) {
-        if (wave >= half && wave < 2 * half) {
-            double* slot = W.tile + (size_t)(wave - half) * NPAIR * 256;
+        for (int half = BA_WAVES / 2; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+                double* slot = W.tile + (size_t)(wave - half) * NPAIR * 256;
+#pragma unroll
+                for (int a = 0; a < NPAIR; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) slot[a * 256 + base + 64 * j] = acc[a][j];
+            }
+            __syncthreads();
+            if (wave < half) {
+                const double* slot = W.tile + (size_t)wave * NPAIR * 256;
+#pragma unroll
+                for (int a = 0; a < NPAIR; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a][j] += slot[a * 256 + base + 64 * j];
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
 #pragma unroll
             for (int a = 0; a < NPAIR; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) slot[a * 256 + base + 64 * j] = acc[a][j];
+                for (int j = 0; j < 4; ++j) W.tile[a * 256 + base + 64 * j] = acc[a][j];
         }
         __syncthreads();
-        if (wave < half) {
-            const double* slot = W.tile + (size_t)wave * NPAIR * 256;
+    } else {  // one slot: the waves add their accumulators one after the other (wave order)
+        for (int w = 0; w < BA_WAVES; ++w) {
+            if (wave == w) {
 #pragma unroll
-            for (int a = 0; a < NPAIR; ++a)
+                for (int a = 0; a < NPAIR; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[a][j] += slot[a * 256 + base + 64 * j];
+                    for (int j = 0; j < 4; ++j) {
+                        const int idx = a * 256 + base + 64 * j;
+                        W.tile[idx] = (w == 0 ? 0.0 : W.tile[idx]) + acc[a][j];
+                    }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (wave == 0) {
-#pragma unroll
-        for (int a = 0; a < NPAIR; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) W.tile[a * 256 + base + 64 * j] = acc[a][j];
-    }
-    __syncthreads();
     PH_END(14);
 }
 
@@ -547,7 +563,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             W.cl = d;
             d += (size_t)B.maxLg * 3;
             W.tile = d;
-            d += (size_t)B.ntile * 256 * 4;  // 4 slots for the wave reduction tree; slot 0 holds the result
+            d += (size_t)B.ntile * 256 * BA_TILE_SLOTS(B.ntile);  // slot 0 holds the result
             W.te = d;
             d += (size_t)B.maxEg * 3;
         }
