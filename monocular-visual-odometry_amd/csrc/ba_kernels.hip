@@ -75,7 +75,8 @@ struct BaDev {
     const int* slot_pose;     // nfree
     // cross-workgroup exchange (agent-scope atomics only)
     double* xHpp;             // G x F x 49
-    double* xG;               // G x ntile x 256
+    double* xG;               // G x npk: packed Schur partials (lower triangle + rhs)
+    double* xR;               // npk: the same entries summed over the workgroups
     double* xSc;              // G x 4: chi2, scale, maxdiag
     unsigned* barrier;        // monotonically increasing arrival counter (zeroed before every launch)
     BaStatsDev* stats;
@@ -310,6 +311,31 @@ __device__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, doub
     return ok;
 }
 
+
+// element `idx` of the packed order "lower triangle row by row (i >= j), then the rhs column" -> (i, j)
+__device__ __forceinline__ void packed_ij(int idx, int n, int nlow, int& i, int& j) {
+    if (idx < nlow - n) {
+        i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+        while (i * (i + 1) / 2 > idx) --i;
+        while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+        j = idx - i * (i + 1) / 2;
+    } else {
+        i = idx - (nlow - n);
+        j = n;
+    }
+}
+// where G[i][j] (j <= i, or j == n) lives inside the upper-triangle tile set
+__device__ __forceinline__ int tile_offset(int i, int j, int n, int NT) {
+    int a = j, b = i;
+    if (j == n) {
+        a = i;
+        b = n;
+    }
+    const int ti = a / 16, tj = b / 16;
+    const int tl = ti * NT - ti * (ti - 1) / 2 + (tj - ti);
+    return tl * 256 + 16 * (a % 16) + (b % 16);
+}
+
 // LDS layout of one workgroup, carved from the dynamic segment.
 struct WgLds {
     double* S;     // n x (n+1) reduced system
@@ -332,9 +358,14 @@ struct WgLds {
     short* pts0;   // maxLg + 1 offsets into ptl
     short* eof;    // maxLg x nfree
 };
+// tile area: reduction-tree slots, reused as the stage-1 staging buffer (<= nlow + BA_MAX_WGS doubles)
+__host__ __device__ inline size_t ba_tile_doubles(int n, int ntile) {
+    size_t a = (size_t)ntile * 256 * BA_TILE_SLOTS(ntile), b = (size_t)n * (n + 1) / 2 + n + BA_MAX_WGS;
+    return a > b ? a : b;
+}
 __host__ __device__ inline size_t wg_lds_doubles(int n, int ntile, int maxEg, int maxLg, int fix_points) {
     size_t d = (size_t)n * (n + 1) + (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
-    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + (size_t)ntile * 256 * BA_TILE_SLOTS(ntile);
+    if (!fix_points) d += (size_t)maxEg * 15 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3) + ba_tile_doubles(n, ntile);
     return d;
 }
 __host__ __device__ inline size_t wg_lds_bytes(int n, int ntile, int nfree, int maxEg, int maxLg, int fix_points) {
@@ -563,7 +594,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             W.cl = d;
             d += (size_t)B.maxLg * 3;
             W.tile = d;
-            d += (size_t)B.ntile * 256 * BA_TILE_SLOTS(B.ntile);  // slot 0 holds the result
+            d += ba_tile_doubles(n, B.ntile);  // slot 0 holds the result
             W.te = d;
             d += (size_t)B.maxEg * 3;
         }
@@ -628,6 +659,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
     const bool any_free = B.nfree > 0 || !B.fix_points;
     const bool do_schur = !B.fix_points && n > 0;
     const int nlow = n * (n + 1) / 2 + n;  // packed lower triangle + rhs column
+    const int npk = (nlow + 15) & ~15;     // row pitch of the packed partials
+    const int slice = (nlow + B.G - 1) / B.G;  // entries each workgroup reduces in stage 1
 
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus)
@@ -837,49 +870,37 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                 }
                 PH_END(4);
                 if (B.G > 1) {
-                    for (int idx = tid; idx < B.ntile * 256; idx += BA_THREADS)
-                        xstore(B.xG + (size_t)g * B.ntile * 256 + idx, W.tile[idx]);
+                    // publish the needed entries (lower triangle + rhs) in packed order
+                    for (int idx = tid; idx < nlow; idx += BA_THREADS) {
+                        int i, j;
+                        packed_ij(idx, n, nlow, i, j);
+                        xstore(B.xG + (size_t)g * npk + idx, W.tile[tile_offset(i, j, n, B.NT)]);
+                    }
+                    if (!grid_barrier(B, epoch, sFlag)) error = 1;
+                    // stage 1 of the cross-workgroup sum: this workgroup reduces its SLICE of the packed entries
+                    // over all G partials (one load per thread), in workgroup order, and republishes the slice
+                    const int sl0 = g * slice, sln = max(0, min(slice, nlow - sl0));
+                    double* red = W.tile;  // the published tile is no longer needed
+                    for (int q = tid; q < sln * B.G; q += BA_THREADS) {
+                        const int w = q / sln, el = q - w * sln;
+                        red[q] = xload(B.xG + (size_t)w * npk + sl0 + el);
+                    }
+                    __syncthreads();
+                    for (int el = tid; el < sln; el += BA_THREADS) {
+                        double sum = 0;
+                        for (int w = 0; w < B.G; ++w) sum += red[w * sln + el];
+                        xstore(B.xR + sl0 + el, sum);
+                    }
                     if (!grid_barrier(B, epoch, sFlag)) error = 1;
                 }
             }
             PH_END(5);
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n]; LDL^T by wave 0
             for (int idx = tid; idx < nlow; idx += BA_THREADS) {
-                // element idx of the packed lower triangle (rows i >= j) followed by the rhs column
                 int i, j;
-                if (idx < nlow - n) {
-                    i = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-                    while (i * (i + 1) / 2 > idx) --i;
-                    while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-                    j = idx - i * (i + 1) / 2;
-                } else {
-                    i = idx - (nlow - n);
-                    j = n;
-                }
+                packed_ij(idx, n, nlow, i, j);
                 double gsum = 0;
-                if (do_schur) {
-                    int a = j, b = i;  // j <= i (or the rhs column): tile row from the smaller index
-                    if (j == n) {
-                        a = i;
-                        b = n;
-                    }
-                    const int ti = a / 16, tj = b / 16;
-                    const int tl = ti * B.NT - ti * (ti - 1) / 2 + (tj - ti);
-                    const size_t off = (size_t)tl * 256 + 16 * (a % 16) + (b % 16);
-                    if (B.G > 1) {
-                        const double* src = B.xG + off;
-                        const size_t stride = (size_t)B.ntile * 256;
-                        for (int w0 = 0; w0 < B.G; w0 += 32) {  // 32 independent loads in flight, summed in order
-                            double v[32];
-#pragma unroll
-                            for (int q = 0; q < 32; ++q) v[q] = (w0 + q < B.G) ? xload(src + (size_t)(w0 + q) * stride) : 0.0;
-#pragma unroll
-                            for (int q = 0; q < 32; ++q) gsum += v[q];
-                        }
-                    } else {
-                        gsum = W.tile[off];
-                    }
-                }
+                if (do_schur) gsum = B.G > 1 ? xload(B.xR + idx) : W.tile[tile_offset(i, j, n, B.NT)];
                 const int pi = sSlotPose[i / 6];
                 if (j == n) {
                     W.S[i * ld + n] = sBp[6 * pi + i % 6] - gsum;
@@ -1265,7 +1286,8 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     const size_t o_slot = cv.take((size_t)F * 4 + 4), o_sp = cv.take((size_t)nfree * 4 + 4);
     const size_t upload_end = cv.off;
     const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
-    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg = cv.take((size_t)G * ntile * 256 * 8);
+    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg = cv.take((size_t)G * (((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15) * 8 + 256);
+    const size_t o_xr = cv.take(((size_t)n * (n + 1) / 2 + n + 16) * 8);
     const size_t o_xs = cv.take((size_t)G * 32), o_bar = cv.take(64), o_desc = cv.take(sizeof(BaDev));
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();
@@ -1348,6 +1370,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.slot_pose = (const int*)(D + o_sp);
     B.xHpp = (double*)(D + o_xh);
     B.xG = (double*)(D + o_xg);
+    B.xR = (double*)(D + o_xr);
     B.xSc = (double*)(D + o_xs);
     B.barrier = (unsigned*)(D + o_bar);
     B.stats = (BaStatsDev*)(D + o_stats);
