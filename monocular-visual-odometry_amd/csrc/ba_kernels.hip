@@ -417,12 +417,18 @@ __device__ __forceinline__ double u_entry(const WgLds& W, int nfree, int n, int 
     return row == n ? W.cl[3 * l + k] : 0.0;
 }
 
-// branch-free variant for windows without duplicate (landmark, pose) observations (the normal case)
-__device__ __forceinline__ double u_entry_nodup(const WgLds& W, int nfree, int n, int l, int row, int sl, int c, int k) {
-    const int el = row < n ? (int)W.eof[l * nfree + sl] : -1;
+// branch-free variant for windows without duplicate (landmark, pose) observations (the normal case): every load
+// is unconditional (clamped index), the selection happens on values
+__device__ __forceinline__ double u_entry_nodup(const WgLds& W, int nfree, int l, bool valid, bool is_rhs, int sl, int c,
+                                                int k) {
+    const int el = W.eof[l * nfree + sl];
     const int e = el < 0 ? 0 : el;
-    const double v = W.M[BA_MSTRIDE * e + c] * W.Y[6 * e + k] + W.M[BA_MSTRIDE * e + 7 + c] * W.Y[6 * e + 3 + k];
-    return el >= 0 ? v : (row == n ? W.cl[3 * l + k] : 0.0);
+    const double m0 = W.M[BA_MSTRIDE * e + c], m1 = W.M[BA_MSTRIDE * e + 7 + c];
+    const double y0 = W.Y[6 * e + k], y1 = W.Y[6 * e + 3 + k];
+    const double clv = W.cl[3 * l + k];
+    double v = m0 * y0 + m1 * y1;
+    v = (valid && el >= 0) ? v : 0.0;
+    return is_rhs ? clv : v;
 }
 
 // partial G = U^T U over the own landmarks: every wave takes every 8th landmark, one MFMA per landmark and
@@ -438,33 +444,37 @@ __device__ void schur_mfma(const BaDev& B, const WgLds& W, int Lg, int lane, int
     const int kk = k < 3 ? k : 0;
     if (!B.has_dups) {
         int sl[NT], cc[NT];
+        bool valid[NT], rhs[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int row = 16 * t + i;
+            valid[t] = row < B.n && k < 3;
+            rhs[t] = row == B.n && k < 3;
             sl[t] = row < B.n ? row / 6 : 0;
             cc[t] = row < B.n ? row - 6 * sl[t] : 0;
         }
-        // two landmarks per step: their LDS chains are independent and overlap
-        for (int l = wave; l < Lg; l += 2 * BA_WAVES) {
-            const int l2 = l + BA_WAVES;
-            const bool has2 = l2 < Lg;
-            const int l2c = has2 ? l2 : l;
-            double op[NT], oq[NT];
+        // four landmarks per step: their LDS chains are independent and overlap
+        constexpr int UL = 4;
+        for (int l0 = wave; l0 < Lg; l0 += UL * BA_WAVES) {
+            double op[UL][NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                op[t] = u_entry_nodup(W, B.nfree, B.n, l, 16 * t + i, sl[t], cc[t], kk);
-                oq[t] = u_entry_nodup(W, B.nfree, B.n, l2c, 16 * t + i, sl[t], cc[t], kk);
-                op[t] = k < 3 ? op[t] : 0.0;
-                oq[t] = (k < 3 && has2) ? oq[t] : 0.0;
+            for (int u = 0; u < UL; ++u) {
+                const int l = l0 + u * BA_WAVES;
+                const bool has = l < Lg;
+                const int lc = has ? l : l0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    op[u][t] = u_entry_nodup(W, B.nfree, lc, valid[t] && has, rhs[t] && has, sl[t], cc[t], kk);
             }
-            int a = 0;
 #pragma unroll
-            for (int ti = 0; ti < NT; ++ti)
+            for (int u = 0; u < UL; ++u) {
+                int a = 0;
 #pragma unroll
-                for (int tj = ti; tj < NT; ++tj, ++a) {
-                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ti], op[tj], acc[a], 0, 0, 0);
-                    acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(oq[ti], oq[tj], acc[a], 0, 0, 0);
-                }
+                for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                    for (int tj = ti; tj < NT; ++tj, ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[u][ti], op[u][tj], acc[a], 0, 0, 0);
+            }
         }
     } else {
         for (int l = wave; l < Lg; l += BA_WAVES) {
