@@ -280,7 +280,7 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // pivot rows are broadcast with v_readlane.  Returns 0 when a pivot is not positive (g2o: LDLT "not positive"
 // -> the step is rejected).  x (n entries) is written to xout.
 template <int NR>
-__device__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, double* xout) {
+__device__ __forceinline__ int solve_rows_in_regs(const double* S, int n, int ld, int lane, double* xout) {
     double a[NR + 1];
 #pragma unroll
     for (int k = 0; k < NR; ++k) a[k] = (lane < n && k < n) ? S[lane * ld + k] : (k == lane ? 1.0 : 0.0);
@@ -334,6 +334,12 @@ __device__ __forceinline__ int tile_offset(int i, int j, int n, int NT) {
     const int ti = a / 16, tj = b / 16;
     const int tl = ti * NT - ti * (ti - 1) / 2 + (tj - ti);
     return tl * 256 + 16 * (a % 16) + (b % 16);
+}
+
+// the 64-row instantiation needs ~130 VGPRs of its own: kept out of line so that it does not inflate the register
+// pressure of the common (<= 5 free poses) path
+__device__ __noinline__ int solve_rows_64(const double* S, int n, int ld, int lane, double* xout) {
+    return solve_rows_in_regs<64>(S, n, ld, lane, xout);
 }
 
 // LDS layout of one workgroup, carved from the dynamic segment.
@@ -927,7 +933,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                 int ok = 1;
                 if (n <= 32) {
                     ok = solve_rows_in_regs<32>(W.S, n, ld, lane, sSol);
-                } else {  // more than 5 free poses: unpivoted LDL^T in LDS
+                } else if (n <= 64) {
+                    ok = solve_rows_64(W.S, n, ld, lane, sSol);
+                } else {  // more than 10 free poses: unpivoted LDL^T in LDS
                     double* S = W.S;
                     for (int j = 0; j < n; ++j) {
                         const double d = S[j * ld + j];
