@@ -1414,7 +1414,17 @@ int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
         budget_acquire(H->device, H->B.G);
         H->tokens = H->B.G;
     }
-    MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)H->lds));
+    {
+        // raise the dynamic-LDS limit ONCE per device to the solver's budget (a per-launch value would race
+        // between host threads launching windows of different sizes)
+        static std::mutex attr_mutex;
+        static bool attr_done[16] = {false};
+        std::lock_guard<std::mutex> lk(attr_mutex);
+        if (!attr_done[H->device & 15]) {
+            MVO_HIP(hipFuncSetAttribute((const void*)k_ba_lm, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET));
+            attr_done[H->device & 15] = true;
+        }
+    }
     if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, 64, ctx->stream));
     MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc, &H->B, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
     {
