@@ -10,6 +10,7 @@
 #include "my_slam/optimization/g2o_ba.h"
 #include "my_slam/optimization/g2o_facade.h"
 #include "my_slam/vo/frame.h"
+#include "my_slam/vo/ba_window.h"
 #include "my_slam/vo/mappoint.h"
 
 using namespace my_slam;
@@ -185,6 +186,47 @@ int main(int argc, char** argv) {
                     }
                 }
             }
+        }
+        // ---- vo.cpp:384-478: the marshalling itself (deque of frames + Map), skip rules included
+        {
+            vo::Map::Ptr map(new vo::Map());
+            for (auto& mp : map_pts) map->insertMapPoint(mp);
+            std::deque<vo::Frame::Ptr> buff;
+            vo::Frame::Ptr old_frame = vo::Frame::createFrame(cv::Mat());  // falls out of the 5-frame window
+            buff.push_back(old_frame);
+            vo::Frame::Ptr sparse = vo::Frame::createFrame(cv::Mat());     // < 3 connections -> skipped
+            sparse->keypoints_.resize(2);
+            sparse->inliers_to_mappt_connections_[0] = {-1, map_pts[0]->id_};
+            sparse->inliers_to_mappt_connections_[1] = {-1, map_pts[1]->id_};
+            for (int rep = 0; rep < 2; ++rep) buff.push_back(rep == 0 ? frames[2] : sparse);
+            buff.push_back(frames[1]);
+            buff.push_back(frames[0]);
+            // a deleted map point: connection is skipped
+            const int deleted_id = map_pts[5]->id_;
+            map->map_points_.erase(deleted_id);
+            vo::BaWindow w = vo::buildBundleAdjustmentWindow(buff, map, 5);
+            // buffered 5 frames -> min(5, 4) = 4 newest: frames[0], frames[1], sparse (skipped), frames[2]
+            bool ok = w.v_camera_poses.size() == 3 && w.frame_ids[0] == frames[0]->id_ && w.frame_ids[1] == frames[1]->id_ &&
+                      w.frame_ids[2] == frames[2]->id_ && w.v_pts_2d[0].size() == map_pts.size() - 1 &&
+                      w.um_pts_3d_in_prev_frames.count(deleted_id) == 0 && w.v_pts_3d_only_in_curr.size() == map_pts.size() - 1 &&
+                      w.v_camera_poses[0] == &frames[0]->T_w_c_;
+            if (!ok) {
+                fprintf(stderr, "buildBundleAdjustmentWindow: wrong window\n");
+                return 6;
+            }
+            vector<cv::Mat> before;
+            for (auto& fr : frames) before.push_back(fr->T_w_c_.clone());
+            vo::callBundleAdjustment(buff, map, K);  // shipped default: pose-only, poses overwritten in place
+            for (size_t f = 0; f < frames.size(); ++f) {
+                // same window as P1 except for the one deleted landmark: poses agree to the pixel-noise level
+                for (int r = 0; r < 3; ++r)
+                    if (std::fabs(frames[f]->T_w_c_.at<double>(r, 3) - P1[f].at<double>(r, 3)) > 1e-3) {
+                        fprintf(stderr, "callBundleAdjustment: pose %zu differs from the direct call\n", f);
+                        return 7;
+                    }
+                frames[f]->T_w_c_ = before[f];
+            }
+            map->insertMapPoint(map_pts[5]);
         }
         run(false, true, P2, X2);   // full BA: points move and are written back as f32
         for (auto& P : P2) dump(out, P.ptr<double>(0), 16);
