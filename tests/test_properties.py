@@ -1,0 +1,152 @@
+"""Size-independent properties.  CPU part: hypothesis-driven invariants of the oracle's order-sensitive host steps
+(grid sampling, de-dup, 2-NN tie rule).  GPU part: the same kind of properties at BASELINE.json's full sizes
+(2000 x 2000 descriptors, 640 x 480 frames, BA5) where an element-by-element oracle run would also pass but a
+structural bug could hide behind matching inputs."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 400), st.integers(1, 12), st.integers(1, 60), st.integers(0, 2 ** 31 - 1))
+def test_grid_sampling_invariants(n, per_cell, max_kp, seed):
+    from conftest import graft
+    O = graft.load_oracle()
+    rng = np.random.RandomState(seed)
+    kp = np.zeros(n, O.KEYPOINT_DTYPE)
+    kp["x"] = rng.uniform(0, 639.9, n).astype(np.float32)
+    kp["y"] = rng.uniform(0, 479.9, n).astype(np.float32)
+    p = O.default_params(max_keypoints=max_kp, grid_max_per_cell=per_cell)
+    out = O.select_uniform_kpts_by_grid(kp, 30, 40, p)
+    assert len(out) <= min(n, max_kp + 1)                               # the reference's max+1 quirk
+    # order preserved: out is a subsequence of kp
+    it = iter(range(n))
+    for r in out:
+        assert any(kp[i].tobytes() == r.tobytes() for i in it)
+    cells = (out["y"].astype(int) // 16) * 40 + out["x"].astype(int) // 16
+    assert len(out) == 0 or np.bincount(cells).max() <= per_cell
+    # idempotent when nothing is cut by the global cap
+    if len(out) <= max_kp:
+        assert O.select_uniform_kpts_by_grid(out, 30, 40, p).tobytes() == out.tobytes()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 300), st.integers(1, 50), st.integers(0, 2 ** 31 - 1))
+def test_dedup_invariants(n, n_train, seed):
+    from conftest import graft
+    O = graft.load_oracle()
+    mvo = graft.load_package()
+    rng = np.random.RandomState(seed)
+    m = np.zeros(n, O.DMATCH_DTYPE)
+    m["queryIdx"] = np.arange(n)
+    m["trainIdx"] = rng.randint(0, n_train, n)
+    m["distance"] = rng.randint(0, 256, n)
+    out = O.remove_duplicated_matches(m)
+    assert (np.diff(out["trainIdx"]) > 0).all()                         # sorted, unique
+    assert set(out["trainIdx"]) == set(m["trainIdx"])
+    assert O.remove_duplicated_matches(out).tobytes() == out.tobytes()  # idempotent
+    # the product's host-side implementation (same libstdc++ algorithm) picks the same survivors
+    assert mvo.remove_duplicated_matches(m.astype(mvo.DMATCH_DTYPE)).tobytes() == out.tobytes()
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.integers(1, 40), st.integers(0, 60), st.integers(1, 6), st.integers(0, 2 ** 31 - 1))
+def test_knn2_is_the_lexicographic_top2(nq, nt, n_distinct, seed):
+    from conftest import graft
+    O = graft.load_oracle()
+    rng = np.random.RandomState(seed)
+    base = rng.randint(0, 256, (n_distinct, 32)).astype(np.uint8)       # few distinct rows -> many ties
+    q = base[rng.randint(0, n_distinct, nq)]
+    t = base[rng.randint(0, n_distinct, nt)] if nt else np.zeros((0, 32), np.uint8)
+    idx, dist = O.match_knn2(q, t)
+    D = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2) if nt else np.zeros((nq, 0), int)
+    for i in range(nq):
+        order = sorted(range(nt), key=lambda j: (D[i, j], j))[:2]
+        exp_i = order + [-1] * (2 - len(order))
+        assert idx[i].tolist() == exp_i
+        assert dist[i].tolist() == [D[i, j] for j in order] + [np.iinfo(np.int32).max] * (2 - len(order))
+
+
+# --------------------------------------------------------------------------------------------- GPU, full size
+@pytest.mark.gpu
+def test_match_properties_full_size(mvo, ctx):
+    q, t = mvo.synth.match_inputs("perturbed", 2000, 2000)
+    idx, dist = ctx.match_knn2(q, t)
+    assert (dist[:, 0] <= dist[:, 1]).all() and (idx >= 0).all() and (idx[:, 0] != idx[:, 1]).all()
+    # self match: distance 0 to itself; with duplicates the lower index wins
+    i2, d2 = ctx.match_knn2(q, q)
+    assert (d2[:, 0] == 0).all() and (i2[:, 0] <= np.arange(2000)).all()
+    # permuting the train set permutes the answer (no ties in 'uniform' data with overwhelming probability)
+    qu, tu = mvo.synth.match_inputs("uniform", 2000, 2000)
+    perm = np.random.RandomState(0).permutation(2000)
+    ia, da = ctx.match_knn2(qu, tu)
+    ib, db = ctx.match_knn2(qu, tu[perm])
+    assert np.array_equal(da, db)
+    strict = da[:, 0] < da[:, 1]
+    assert np.array_equal(perm[ib[strict, 0]], ia[strict, 0])
+    # distances are exactly the popcounts
+    sel = np.arange(0, 2000, 37)
+    ref = np.unpackbits(qu[sel] ^ tu[ia[sel, 0]], axis=1).sum(1)
+    assert np.array_equal(ref, da[sel, 0])
+    # matchFeatures output: sorted unique trainIdx, subset of the 1-NN pairs, idempotent de-dup
+    m = ctx.match_features(q, t, 2, 2.0, 0.8)
+    assert (np.diff(m["trainIdx"]) > 0).all() and (idx[m["queryIdx"], 0] == m["trainIdx"]).all()
+    assert mvo.remove_duplicated_matches(m).tobytes() == m.tobytes()
+
+
+@pytest.mark.gpu
+def test_extraction_properties_full_size(mvo, ctx):
+    ctx.orb_configure(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=2000, grid_size=16,
+                      grid_max_per_cell=8)
+    seq = mvo.synth.Sequence(640, 480, 2, seed=4321, tex_size=1024)
+    img = seq.frame(0)
+    k = ctx.calc_keypoints(img, cap=4096)
+    c0 = ctx.debug_candidates()
+    # determinism: the same frame twice gives identical bytes
+    k_again = ctx.calc_keypoints(img, cap=4096)
+    assert k.tobytes() == k_again.tobytes()
+    k, d = ctx.calc_descriptors(img, k, reuse_pyramid=True)
+    assert len(k) <= 2001 and (np.diff(k["octave"]) >= 0).all()
+    cells = (k["y"].astype(int) // 16) * 40 + k["x"].astype(int) // 16
+    assert np.bincount(cells).max() <= 8
+    # gray input == BGR input with three equal channels (weights sum to 2^14)
+    kg = ctx.calc_keypoints(np.ascontiguousarray(img[:, :, 0]), cap=4096)
+    assert kg.tobytes() == k_again.tobytes()
+    # FAST/NMS/Harris/angle on level 0 are translation equivariant: shift the image by (8, 8) px
+    sh = np.roll(img, (8, 8), axis=(0, 1))
+    ctx.calc_keypoints(sh, cap=4096)
+    c1 = ctx.debug_candidates()
+    a = c0[(c0["level_score"] >> 16) == 0]
+    b = c1[(c1["level_score"] >> 16) == 0]
+    # compare candidates whose 31-px support stays away from the wrapped border in both images
+    sa = a[(a["x"] > 60) & (a["x"] < 560) & (a["y"] > 60) & (a["y"] < 400)]
+    sb = b[(b["x"] > 68) & (b["x"] < 568) & (b["y"] > 68) & (b["y"] < 408)].copy()
+    sb["x"] -= 8
+    sb["y"] -= 8
+    assert len(sa) > 500 and sa.tobytes() == sb.tobytes()
+
+
+@pytest.mark.gpu
+def test_ba_properties_full_size(mvo, ctx):
+    """BA5 (5 poses / 2000 landmarks / ~10k edges): cost never increases, a rigid change of the world frame leaves
+    the optimisation invariant (chi2 trajectory end point, relative poses), edge order does not matter."""
+    pb = mvo.synth.ba_problem(5, 2000, 7)
+    a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+    P, X, st = ctx.bundle_adjustment(*a, fix_points=True)
+    assert st["chi2_final"] <= st["chi2_initial"] and 1 <= st["iterations"] <= 50
+    # world-frame change: T_w'_c = G T_w_c, X' = G X  (pose-only BA is exactly equivariant)
+    rng = np.random.RandomState(1)
+    G = np.eye(4)
+    G[:3, :3] = mvo.synth._rot(rng.normal(size=3), 0.7)
+    G[:3, 3] = rng.normal(size=3)
+    P2, _, st2 = ctx.bundle_adjustment(G @ pb["poses0"], pb["points0"] @ G[:3, :3].T + G[:3, 3], *a[2:], fix_points=True)
+    assert abs(st2["chi2_final"] - st["chi2_final"]) < 1e-6 * st["chi2_final"]
+    assert np.abs(np.linalg.inv(G) @ P2 - P).max() < 1e-6
+    # shuffling the edge list does not change the result beyond rounding
+    perm = rng.permutation(len(pb["edge_pose"]))
+    P3, _, st3 = ctx.bundle_adjustment(pb["poses0"], pb["points0"], pb["edge_pose"][perm], pb["edge_point"][perm],
+                                       pb["edge_uv"][perm], *a[5:], fix_points=True)
+    assert np.abs(P3 - P).max() < 1e-8
+    # full BA decreases the cost further than pose-only BA
+    Pf, Xf, stf = ctx.bundle_adjustment(*a, fix_points=False)
+    assert stf["chi2_final"] < st["chi2_final"]
