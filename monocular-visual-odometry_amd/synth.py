@@ -38,7 +38,7 @@ class Sequence:
 
     def frame(self, i, channels=3):
         from scipy import ndimage
-        rng = np.random.RandomState(self.seed * 1000003 + i)
+        rng = np.random.RandomState((self.seed * 1000003 + i) % (2 ** 32))
         t = i / max(self.n - 1, 1)
         # smooth planar path: ~4 px/frame translation, 0.2 deg/frame roll, +-5 % scale
         cx = self.tex_size / 2 + 4.0 * i * np.cos(0.3) + 60 * np.sin(2 * np.pi * t)
