@@ -76,7 +76,8 @@ struct BaDev {
     // cross-workgroup exchange (agent-scope atomics only)
     double* xHpp;             // G x F x 49
     double* xG;               // G x npk: packed Schur partials (lower triangle + rhs)
-    double* xR;               // npk: the same entries summed over the workgroups
+    u64* xRg;                 // 2 x npk granules: the same entries summed over the workgroups
+    u64* xCg;                 // 2 (parity) x G x 4 granules: chi2 / predicted-decrease partials
     double* xSc;              // G x 4: chi2, scale, maxdiag
     unsigned* barrier;        // monotonically increasing arrival counter (zeroed before every launch)
     BaStatsDev* stats;
@@ -122,6 +123,28 @@ __device__ double block_max(double v, double* scratch) {
 #pragma unroll
     for (int w = 0; w < BA_WAVES; ++w) s = fmax(s, scratch[w]);
     return s;
+}
+
+// Data-tagged hand-off (no counter, no second round trip): a double travels as two 8-byte granules
+// {tag : 32 | half : 32}, each written by ONE write-through store; the consumer polls the granules themselves until
+// both carry the expected tag.  Tags are > 0 and increase by one per exchange; the buffers are zeroed per launch.
+__device__ __forceinline__ void gstore_d(u64* g, unsigned tag, double v) {
+    const u64 b = (u64)__double_as_longlong(v);
+    __hip_atomic_store(g, ((u64)tag << 32) | (b & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(g + 1, ((u64)tag << 32) | (b >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool gload_d(const u64* g, unsigned tag, double& v) {
+    for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+        const u64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) {
+            v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
+            return true;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    v = 0;
+    return false;
 }
 
 // Grid barrier over the G co-resident workgroups: arrive on a monotonic counter, poll relaxed, bounded spin.
@@ -573,13 +596,14 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
     __shared__ double sX[BA_MAX_WGS * 2];
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ int sFlag[4];
+    if (threadIdx.x == 0) sFlag[2] = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = blockIdx.x;
     const int n = B.n, ld = n + 1;
     const int pt_lo = B.wg_pt_start[g], Lg = B.wg_pt_start[g + 1] - pt_lo;
     const int e_lo = B.wg_edge_start[g], Eg = B.wg_edge_start[g + 1] - e_lo;
-    unsigned epoch = 0;
+    unsigned epoch = 0, tagA = 0, tagB = 0;
 
     // ---- carve the dynamic LDS
     WgLds W;
@@ -886,6 +910,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                 }
                 PH_END(4);
                 if (B.G > 1) {
+                    ++tagA;
                     // publish the needed entries (lower triangle + rhs) in packed order
                     for (int idx = tid; idx < nlow; idx += BA_THREADS) {
                         int i, j;
@@ -905,9 +930,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                     for (int el = tid; el < sln; el += BA_THREADS) {
                         double sum = 0;
                         for (int w = 0; w < B.G; ++w) sum += red[w * sln + el];
-                        xstore(B.xR + sl0 + el, sum);
+                        gstore_d(B.xRg + 2 * (size_t)(sl0 + el), tagA, sum);
                     }
-                    if (!grid_barrier(B, epoch, sFlag)) error = 1;
+                    // no barrier: the consumers below poll the tagged granules of the entries they need
                 }
             }
             PH_END(5);
@@ -916,7 +941,13 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                 int i, j;
                 packed_ij(idx, n, nlow, i, j);
                 double gsum = 0;
-                if (do_schur) gsum = B.G > 1 ? xload(B.xR + idx) : W.tile[tile_offset(i, j, n, B.NT)];
+                if (do_schur) {
+                    if (B.G > 1) {
+                        if (!gload_d(B.xRg + 2 * (size_t)idx, tagA, gsum)) sFlag[2] = 1;
+                    } else {
+                        gsum = W.tile[tile_offset(i, j, n, B.NT)];
+                    }
+                }
                 const int pi = sSlotPose[i / 6];
                 if (j == n) {
                     W.S[i * ld + n] = sBp[6 * pi + i % 6] - gsum;
@@ -928,6 +959,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                 }
             }
             __syncthreads();
+            if (sFlag[2]) error = 1;
             PH_END(6);
             if (wave == 0) {
                 int ok = 1;
@@ -1034,25 +1066,29 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             double tempChi = robust_chi2_local(B, W, Eg, sR, sT, sScr);
             PH_END(9);
             if (B.G > 1) {
+                ++tagB;
+                u64* slot = B.xCg + (size_t)(tagB & 1) * B.G * 4;
                 if (tid == 0) {
-                    xstore(B.xSc + 4 * g, tempChi);
-                    xstore(B.xSc + 4 * g + 1, scale);
+                    gstore_d(slot + 4 * g, tagB, tempChi);
+                    gstore_d(slot + 4 * g + 2, tagB, scale);
                 }
-                if (!grid_barrier(B, epoch, sFlag)) error = 1;
+                // every workgroup waits for the tagged partials of ALL workgroups: this is also the barrier that
+                // keeps a fast workgroup from overwriting exchange buffers a slow one still reads (a workgroup can
+                // be at most one chi2 exchange ahead, hence the two parity slots)
                 if (tid < B.G) {
-                    sX[2 * tid] = xload(B.xSc + 4 * tid);
-                    sX[2 * tid + 1] = xload(B.xSc + 4 * tid + 1);
+                    double c = 0, sc = 0;
+                    if (!gload_d(slot + 4 * tid, tagB, c) || !gload_d(slot + 4 * tid + 2, tagB, sc)) sFlag[2] = 1;
+                    sX[2 * tid] = c;
+                    sX[2 * tid + 1] = sc;
                 }
                 __syncthreads();
+                if (sFlag[2]) error = 1;
                 tempChi = 0;
                 scale = 0;
                 for (int w = 0; w < B.G; ++w) {
                     tempChi += sX[2 * w];
                     scale += sX[2 * w + 1];
                 }
-                // xSc / xHpp must not be overwritten before everyone has read them: with a Schur phase the next
-                // writes sit behind its barrier; without one (pose-only BA, no free pose) close the phase here
-                if (!do_schur && !grid_barrier(B, epoch, sFlag)) error = 1;
             }
             scale += 1e-3;
             if (!ok2) tempChi = 1.7976931348623157e308;
@@ -1180,7 +1216,7 @@ struct mvo_ba_handle {
     size_t bytes = 0;
     BaDev B{};
     int F = 0, L = 0;
-    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0, o_desc = 0;
+    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0, o_desc = 0, zero_bytes = 64;
     size_t lds = 16;
     bool fix_points = false;
 };
@@ -1305,8 +1341,12 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     const size_t upload_end = cv.off;
     const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
     const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg = cv.take((size_t)G * (((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15) * 8 + 256);
-    const size_t o_xr = cv.take(((size_t)n * (n + 1) / 2 + n + 16) * 8);
-    const size_t o_xs = cv.take((size_t)G * 32), o_bar = cv.take(64), o_desc = cv.take(sizeof(BaDev));
+
+    const size_t o_xs = cv.take((size_t)G * 32), o_desc = cv.take(sizeof(BaDev));
+    // zeroed before every launch: barrier counter | summed-entry granules | chi2 granules (contiguous)
+    const size_t npk_h = ((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15;
+    const size_t o_bar = cv.take(256), o_xr = cv.take(npk_h * 16), o_xc = cv.take((size_t)2 * G * 4 * 8);
+    const size_t zero_bytes = cv.off - o_bar;
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();
     hipError_t he = hipMalloc((void**)&H->dev, total);
@@ -1388,7 +1428,8 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.slot_pose = (const int*)(D + o_sp);
     B.xHpp = (double*)(D + o_xh);
     B.xG = (double*)(D + o_xg);
-    B.xR = (double*)(D + o_xr);
+    B.xRg = (u64*)(D + o_xr);
+    B.xCg = (u64*)(D + o_xc);
     B.xSc = (double*)(D + o_xs);
     B.barrier = (unsigned*)(D + o_bar);
     B.stats = (BaStatsDev*)(D + o_stats);
@@ -1399,6 +1440,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     H->o_pts = o_pts;
     H->o_bar = o_bar;
     H->o_desc = o_desc;
+    H->zero_bytes = zero_bytes;
     H->fix_points = p->fix_points != 0;
     H->lds = wg_lds_bytes(n, ntile, nfree, maxEg, maxLg, p->fix_points);
     H->device = ctx->device;
@@ -1425,7 +1467,7 @@ int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
             attr_done[H->device & 15] = true;
         }
     }
-    if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, 64, ctx->stream));
+    if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, H->zero_bytes, ctx->stream));
     MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc, &H->B, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
     {
         ProfScope ps(ctx, "k_ba_lm");
