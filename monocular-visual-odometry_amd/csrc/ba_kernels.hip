@@ -75,7 +75,7 @@ struct BaDev {
     const int* slot_pose;     // nfree
     // cross-workgroup exchange (agent-scope atomics only)
     double* xHpp;             // G x F x 49
-    double* xG;               // G x npk: packed Schur partials (lower triangle + rhs)
+    u64* xGg;                 // G x 2 npk granules: packed Schur partials (lower triangle + rhs)
     u64* xRg;                 // 2 x npk granules: the same entries summed over the workgroups
     u64* xCg;                 // 2 (parity) x G x 4 granules: chi2 / predicted-decrease partials
     double* xSc;              // G x 4: chi2, scale, maxdiag
@@ -915,16 +915,16 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
                     for (int idx = tid; idx < nlow; idx += BA_THREADS) {
                         int i, j;
                         packed_ij(idx, n, nlow, i, j);
-                        xstore(B.xG + (size_t)g * npk + idx, W.tile[tile_offset(i, j, n, B.NT)]);
+                        gstore_d(B.xGg + 2 * ((size_t)g * npk + idx), tagA, W.tile[tile_offset(i, j, n, B.NT)]);
                     }
-                    if (!grid_barrier(B, epoch, sFlag)) error = 1;
+                    __syncthreads();  // the tile is reused as staging buffer below
                     // stage 1 of the cross-workgroup sum: this workgroup reduces its SLICE of the packed entries
                     // over all G partials (one load per thread), in workgroup order, and republishes the slice
                     const int sl0 = g * slice, sln = max(0, min(slice, nlow - sl0));
                     double* red = W.tile;  // the published tile is no longer needed
                     for (int q = tid; q < sln * B.G; q += BA_THREADS) {
                         const int w = q / sln, el = q - w * sln;
-                        red[q] = xload(B.xG + (size_t)w * npk + sl0 + el);
+                        if (!gload_d(B.xGg + 2 * ((size_t)w * npk + sl0 + el), tagA, red[q])) sFlag[2] = 1;
                     }
                     __syncthreads();
                     for (int el = tid; el < sln; el += BA_THREADS) {
@@ -1340,12 +1340,14 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     const size_t o_slot = cv.take((size_t)F * 4 + 4), o_sp = cv.take((size_t)nfree * 4 + 4);
     const size_t upload_end = cv.off;
     const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
-    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg = cv.take((size_t)G * (((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15) * 8 + 256);
+    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg_unused = 0;
 
     const size_t o_xs = cv.take((size_t)G * 32), o_desc = cv.take(sizeof(BaDev));
     // zeroed before every launch: barrier counter | summed-entry granules | chi2 granules (contiguous)
     const size_t npk_h = ((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15;
     const size_t o_bar = cv.take(256), o_xr = cv.take(npk_h * 16), o_xc = cv.take((size_t)2 * G * 4 * 8);
+    const size_t o_xg = cv.take((size_t)G * npk_h * 16);
+    (void)o_xg_unused;
     const size_t zero_bytes = cv.off - o_bar;
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();
@@ -1427,7 +1429,7 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.pose_slot = (const int*)(D + o_slot);
     B.slot_pose = (const int*)(D + o_sp);
     B.xHpp = (double*)(D + o_xh);
-    B.xG = (double*)(D + o_xg);
+    B.xGg = (u64*)(D + o_xg);
     B.xRg = (u64*)(D + o_xr);
     B.xCg = (u64*)(D + o_xc);
     B.xSc = (double*)(D + o_xs);
