@@ -149,3 +149,39 @@ def test_error_paths(mvo, ctx):
     with pytest.raises(mvo.MvoError) as e:
         ctx.calc_descriptors(img, k, reuse_pyramid=True)
     assert e.value.code == mvo.MVO_ERR_STATE
+
+
+def test_row_stride_bgra_and_large_frames(mvo, O, ctx):
+    """Padded row strides (cv::Mat::step), 4-channel BGRA input, and a 1920x1080 frame."""
+    import ctypes as C
+    p = _cfg(mvo, O, ctx, max_keypoints=3000)
+    img = mvo.synth.small_test_image(77, 318, 203)
+    ko = O.calc_keypoints(img, p)
+    ko, do = O.calc_descriptors(img, ko, p)
+    # padded stride: 318 * 3 = 954 -> 1024 bytes per row
+    pad = np.zeros((203, 1024), np.uint8)
+    pad[:, :954] = img.reshape(203, 954)
+    out = np.zeros(4096, mvo.KEYPOINT_DTYPE)
+    n = C.c_int()
+    r = ctx.lib.mvo_calc_keypoints(ctx.h, pad.ctypes.data_as(C.c_void_p), 318, 203, 1024, 3, out.ctypes.data_as(C.c_void_p),
+                                   4096, C.byref(n))
+    assert r == 0
+    assert_struct_equal(out[:n.value], ko.astype(out.dtype), "padded stride")
+    desc = np.zeros((n.value, 32), np.uint8)
+    r = ctx.lib.mvo_calc_descriptors(ctx.h, pad.ctypes.data_as(C.c_void_p), 318, 203, 1024, 3, 0,
+                                     out.ctypes.data_as(C.c_void_p), C.byref(n), desc.ctypes.data_as(C.c_void_p), None)
+    assert r == 0 and np.array_equal(desc[:n.value], do)
+    # BGRA: the alpha channel is ignored
+    bgra = np.concatenate([img, np.full((203, 318, 1), 200, np.uint8)], axis=2)
+    k4 = ctx.calc_keypoints(np.ascontiguousarray(bgra), cap=4096)
+    assert_struct_equal(k4, ko.astype(k4.dtype), "BGRA")
+    # full-HD frame
+    seq = mvo.synth.Sequence(1920, 1080, 1, seed=5, tex_size=2048)
+    big = seq.frame(0)
+    p = _cfg(mvo, O, ctx, max_keypoints=8000, nfeatures=20000)
+    k = ctx.calc_keypoints(big, cap=16384)
+    kb = O.calc_keypoints(big, p)
+    assert_struct_equal(k, kb.astype(k.dtype), "1920x1080")
+    k, d = ctx.calc_descriptors(big, k, reuse_pyramid=True)
+    kb, db = O.calc_descriptors(big, kb, p)
+    assert np.array_equal(d, db) and len(k) > 4000
