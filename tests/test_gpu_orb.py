@@ -9,8 +9,15 @@ pytestmark = pytest.mark.gpu
 SIZES = [(160, 120, 3), (320, 240, 3), (333, 251, 1), (640, 480, 3)]
 
 
+DEFAULTS = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500, grid_size=16,
+                grid_max_per_cell=8)   # config/config.yaml:65-69,94-95
+
+
 def _cfg(mvo, O, ctx, **kw):
-    ctx.orb_configure(**kw)
+    """(Re)configures the shared ctx from the reference's defaults + overrides; returns the matching oracle params."""
+    full = dict(DEFAULTS)
+    full.update(kw)
+    ctx.orb_configure(**full)
     return O.default_params(**ctx.params)
 
 
