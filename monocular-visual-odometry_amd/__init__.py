@@ -129,9 +129,11 @@ class Context:
 
     # ---- extraction
     def orb_configure(self, **kw):
-        self.params.update(kw)
-        p = OrbParams(**self.params)
+        new = dict(self.params)
+        new.update(kw)
+        p = OrbParams(**new)
         self._chk(self.lib.mvo_orb_configure(self.h, C.byref(p)))
+        self.params = new
 
     def calc_keypoints(self, image, cap=None):
         """geometry::calcKeyPoints (feature_match.cpp:11-36)."""
