@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="also time the oracle with this many host threads, one sequence shard each (0 = skip)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--max-kp", type=int, default=2000)
@@ -269,6 +271,9 @@ def main():
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(args, shards[0])
 
+        cpu_mt = None
+        if not args.no_cpu_baseline and args.cpu_threads > 1:
+            cpu_mt = cpu_baseline_threads(args, shards[0], args.cpu_threads)
         result = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -283,6 +288,7 @@ def main():
                        "ba_trials_per_solve": trials0 / nprof},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "cpu_baseline_all_threads": cpu_mt,
             "kernel_ms_per_frame": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
         }
         print(json.dumps(result))
@@ -319,6 +325,37 @@ def cpu_baseline(args, shard):
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "%d frames of the same S%d + BA%d workload, oracle -O3 x86-64-v3, 1 thread, %.1f s on a %d-core host"
                       % (n, args.width, args.ba_poses, dt, os.cpu_count() or 0)}
+
+
+def cpu_baseline_threads(args, shard, nthreads):
+    """Secondary CPU number: the same oracle, one independent sequence per host thread
+    (the GPU side also fills the chip with independent sequences); ctypes releases the GIL inside the oracle."""
+    O = graft.load_oracle()
+    p = O.default_params(max_keypoints=args.max_kp)
+    per_thread = max(4, min(16, args.cpu_frames // 8))
+    done = []
+
+    def work(tid):
+        prev = None
+        for n in range(per_thread):
+            img = shard.host_frames[(n + tid) % len(shard.host_frames)]
+            k = O.calc_keypoints(img, p)
+            k, d = O.calc_descriptors(img, k, p)
+            if prev is not None:
+                O.match_features(prev, d, 2, 2.0, 0.8)
+            prev = d
+            O.bundle_adjustment(*shard.ba_args, **shard.ba_kw)
+        done.append(per_thread)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": sum(done) / dt, "unit": "frames/s", "cores": nthreads, "kind": "port",
+            "sample": "%d threads x %d frames, %.1f s on a %d-core host" % (nthreads, per_thread, dt, os.cpu_count() or 0)}
 
 
 if __name__ == "__main__":
