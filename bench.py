@@ -259,7 +259,7 @@ def main():
         # a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported uncorrected.
         default_workload = (args.width, args.height, args.max_kp, args.ba_poses, args.ba_points, args.ba) == \
             (640, 480, 2000, 5, 2000, "full")
-        pmc_kb = {"k_ba_lm": 21228.4 + 21654.1, "k_fast_nms": 2 * 1526.0 + 818.7, "k_blur": 2 * 2217.1 + 1012.1,
+        pmc_kb = {"k_ba_lm": 28419.6 + 55262.5, "k_fast_nms": 2 * 1526.0 + 818.7, "k_blur": 2 * 2217.1 + 1012.1,
                   "k_knn2_partial": 2 * 295.4 + 1016.5}
         roof["traffic"] = pmc_kb[dom] * 1024 if (default_workload and dom in pmc_kb) else None
         roof["traffic_source"] = "profiles/r01_pmc_fetch_write_size_per_kernel.csv" if roof["traffic"] else None
