@@ -78,7 +78,7 @@ struct BaDev {
     u64* xGg;                 // G x 2 npk granules: packed Schur partials (lower triangle + rhs)
     u64* xRg;                 // 2 x npk granules: the same entries summed over the workgroups
     u64* xCg;                 // 2 (parity) x G x 4 granules: chi2 / predicted-decrease partials
-    double* xSc;              // G x 4: chi2, scale, maxdiag
+    double* xSc;              // G x 4: initial chi2 (slot 0) and landmark max diagonal (slot 2), counter-barrier phases
     unsigned* barrier;        // monotonically increasing arrival counter (zeroed before every launch)
     BaStatsDev* stats;
 };
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             if (!grid_barrier(B, epoch, sFlag)) error = 1;
             c = 0;
             for (int w = 0; w < B.G; ++w) c += xload(B.xSc + 4 * w);
-            if (!grid_barrier(B, epoch, sFlag)) error = 1;  // xSc is reused below
+            if (!grid_barrier(B, epoch, sFlag)) error = 1;  // everybody has read slot 0
         }
         currentChi = c;
     }
@@ -1120,8 +1120,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
             ++it;
             break;
         }
-        // a Schur-less window has no barrier between this iteration's xSc reads and the next xHpp/xSc writes
-        // other than the one above; with Schur, the xHpp writes of the next iteration are behind the xSc barrier
+        // (the next iteration's xHpp writes are behind this trial's chi2 hand-off, which every workgroup enters only
+        // after it has finished reading the current xHpp)
     }
     // ---- write-back (g2o_ba.cpp:298-316): SE3Quat -> (R, t) -> 4x4 -> inverse; landmarks of the own range
     if (g == 0 && tid < B.F) {
@@ -1340,14 +1340,13 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     const size_t o_slot = cv.take((size_t)F * 4 + 4), o_sp = cv.take((size_t)nfree * 4 + 4);
     const size_t upload_end = cv.off;
     const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
-    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8), o_xg_unused = 0;
+    const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8);
 
     const size_t o_xs = cv.take((size_t)G * 32), o_desc = cv.take(sizeof(BaDev));
     // zeroed before every launch: barrier counter | summed-entry granules | chi2 granules (contiguous)
     const size_t npk_h = ((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15;
     const size_t o_bar = cv.take(256), o_xr = cv.take(npk_h * 16), o_xc = cv.take((size_t)2 * G * 4 * 8);
     const size_t o_xg = cv.take((size_t)G * npk_h * 16);
-    (void)o_xg_unused;
     const size_t zero_bytes = cv.off - o_bar;
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();

@@ -53,8 +53,7 @@ __global__ __launch_bounds__(64) void k_knn2_partial(const uint4* __restrict__ q
         const int cn = min(64, j1 - c0);  // wave-uniform
         const int tl = min(c0 + lane, nt - 1);
         const uint4 ta = t[2 * (size_t)tl], tb = t[2 * (size_t)tl + 1];
-#pragma unroll 4
-        for (int j = 0; j < cn; ++j) {
+        for (int j = 0; j < cn; ++j) {  // (v_readlane with a scalar lane index; the loop is not unrollable)
             int d = __popc(qa.x ^ rl(ta.x, j)) + __popc(qa.y ^ rl(ta.y, j)) + __popc(qa.z ^ rl(ta.z, j)) +
                     __popc(qa.w ^ rl(ta.w, j)) + __popc(qb.x ^ rl(tb.x, j)) + __popc(qb.y ^ rl(tb.y, j)) +
                     __popc(qb.z ^ rl(tb.z, j)) + __popc(qb.w ^ rl(tb.w, j));
