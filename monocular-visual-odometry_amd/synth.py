@@ -157,3 +157,43 @@ def ba_problem(n_poses=5, n_points=2000, seed=7, width=640, height=480, K=FR1_K,
         points0 = points0.astype(np.float32).astype(np.float64)
     return dict(poses_gt=poses_gt, poses0=poses0, points_gt=pts, points0=points0, edge_pose=ep,
                 edge_point=el, edge_uv=uv, focal=f, cx=cx, cy=cy)
+
+
+# ---------------------------------------------------------------- tracking inputs (vo.cpp:270-329)
+def tracking_problem(n_map=3000, seed=11, width=640, height=480, K=FR1_K, pix_noise=0.4, outlier_frac=0.25,
+                     behind_frac=0.15, planar=False):
+    """A map, a camera pose and the 3D-2D pairs the reference feeds to cv::solvePnPRansac.
+
+    Returns dict(map_pos [M,3] f32, map_desc [M,32] u8, T_w_c [4,4], K, cols, rows, pts3d [n,3] f32,
+    pts2d [n,2] f32, inlier_gt [n] bool).  The map has points behind the camera and outside the image so
+    that getMappointsInCurrentView_ has something to reject; `outlier_frac` of the pairs are wrong matches."""
+    rng = np.random.RandomState(seed)
+    f, cx, cy = K["fx"], K["cx"], K["cy"]
+    R_wc = _rot([0.2, 1.0, 0.1], np.deg2rad(7.0))
+    T = np.eye(4)
+    T[:3, :3] = R_wc
+    T[:3, 3] = [0.3, -0.05, 0.1]
+    # points around the camera: in a generous frustum (some outside the image) plus some behind it
+    z = rng.uniform(0.6, 4.0, n_map)
+    if planar:
+        z = 2.0 + 0.0 * z
+    u = rng.uniform(-0.25 * width, 1.25 * width, n_map)
+    v = rng.uniform(-0.25 * height, 1.25 * height, n_map)
+    pc = np.stack([(u - cx) / f * z, (v - cy) / K["fy"] * z, z], 1)
+    behind = rng.uniform(size=n_map) < behind_frac
+    pc[behind, 2] *= -1
+    pw = (pc @ R_wc.T + T[:3, 3]).astype(np.float32)
+    desc = rng.randint(0, 256, (n_map, 32)).astype(np.uint8)
+    # the pairs: visible points, measured pixel = projection + noise, a fraction replaced by wrong pixels
+    Tcw = np.linalg.inv(T)
+    q = pw.astype(np.float64) @ Tcw[:3, :3].T + Tcw[:3, 3]
+    pu = f * q[:, 0] / q[:, 2] + cx
+    pv = K["fy"] * q[:, 1] / q[:, 2] + cy
+    vis = (q[:, 2] > 0) & (pu > 0) & (pv > 0) & (pu < width) & (pv < height)
+    ids = np.nonzero(vis)[0]
+    ids = ids[rng.permutation(len(ids))]
+    uv = np.stack([pu[ids], pv[ids]], 1) + rng.normal(0, pix_noise, (len(ids), 2))
+    bad = rng.uniform(size=len(ids)) < outlier_frac
+    uv[bad] = np.stack([rng.uniform(0, width, int(bad.sum())), rng.uniform(0, height, int(bad.sum()))], 1)
+    return dict(map_pos=pw, map_desc=desc, T_w_c=T, K=K, cols=width, rows=height, pts3d=pw[ids].copy(),
+                pts2d=uv.astype(np.float32), inlier_gt=~bad, ids=ids)

@@ -132,6 +132,33 @@ int orc_bundle_adjustment(orc_ba_problem* prob, orc_ba_stats* stats);
  * b, robust chi2.  For known-answer tests of the Jacobians. */
 int orc_ba_linearize(const orc_ba_problem* prob, double* H, double* b, double* chi2, int ncap);
 
+/* --- tracking rows: pnp_oracle.cpp ---------------------------------- */
+/* cv::Mat::inv() of a 4x4 double matrix (LU, partial pivoting); returns 0 if singular. */
+int orc_invert4x4(const double* T, double* out);
+/* VisualOdometry::getMappointsInCurrentView_ (vo.cpp:16-49): indices (map iteration order) and pixels of
+ * the map points in front of the camera and strictly inside the image.  Returns the count. */
+int orc_map_in_view(const float* pos, int n, const double* T_w_c, double fx, double fy, double cx, double cy,
+                    int cols, int rows, int32_t* idx, float* px);
+/* RANSACPointSetRegistrator::getSubset driven by cv::RNG((uint64)-1): n_iters x model_points indices. */
+int orc_pnp_subsets(int count, int model_points, int n_iters, int32_t* idx);
+/* solvePnP(SOLVEPNP_EPNP) on a subset; K4 = {fx, fy, cx, cy}; R row-major; ut (optional) 12x12. */
+int orc_epnp(const float* p3, const float* p2, const int32_t* idx, int cnt, const double* K4, double* R,
+             double* t, double* ut);
+/* PnPRansacCallback::computeError + findInliers: returns the inlier count, mask (optional) n bytes. */
+int orc_pnp_score(const float* p3, const float* p2, int n, const double* K4, const double* R, const double* t,
+                  float reproj, uint8_t* mask);
+int orc_rodrigues(const double* r, double* R, double* J /* 3x9 or NULL */);
+int orc_rodrigues_inv(const double* R, double* r);
+/* cvFindExtrinsicCameraParams2 (DLT + CvLevMarq) on double points; param = {rvec, tvec}. */
+int orc_solve_pnp_iterative(const double* M, const double* m, int n, const double* K4, const double* init_R,
+                            const double* init_t, double* param, int* lm_iters, int* lm_evals);
+/* cv::solvePnPRansac as called at vo.cpp:326-329.  Returns 1 if a pose was found.  Debug outputs may be
+ * NULL: models [iters x 12] = (R row-major, t), counts [iters], info[4] = {best iteration, iterations run,
+ * DLT used, LM iterations}. */
+int orc_solve_pnp_ransac(const float* p3, const float* p2, int n, const double* K4, int iters, float reproj,
+                         double confidence, double* rvec, double* tvec, int32_t* inliers, int* n_inliers,
+                         double* models, int32_t* counts, int32_t* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,3 +241,111 @@ def ba_linearize(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, i
                                C.byref(chi), n)
     assert r == n, (r, n)
     return H, b, chi.value
+
+
+# ---------------------------------------------------------------- tracking rows (pnp_oracle.cpp)
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _K4(K):
+    return np.ascontiguousarray([K["fx"], K["fy"], K["cx"], K["cy"]], np.float64)
+
+
+def invert4x4(T):
+    T = np.ascontiguousarray(T, np.float64)
+    out = np.zeros((4, 4))
+    ok = lib().orc_invert4x4(_dp(T), _dp(out))
+    return out if ok else None
+
+
+def map_in_view(pos, T_w_c, K, cols, rows):
+    pos = np.ascontiguousarray(pos, np.float32)
+    T = np.ascontiguousarray(T_w_c, np.float64)
+    n = len(pos)
+    idx = np.zeros(n, np.int32)
+    px = np.zeros((n, 2), np.float32)
+    f = lib().orc_map_in_view
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                  C.c_int, C.c_void_p, C.c_void_p]
+    cnt = f(_dp(pos), n, _dp(T), K["fx"], K["fy"], K["cx"], K["cy"], cols, rows, _dp(idx), _dp(px))
+    assert cnt >= 0
+    return idx[:cnt].copy(), px[:cnt].copy()
+
+
+def pnp_subsets(count, n_iters, model_points=5):
+    idx = np.zeros((n_iters, model_points), np.int32)
+    r = lib().orc_pnp_subsets(count, model_points, n_iters, _dp(idx))
+    assert r == 0
+    return idx
+
+
+def epnp(p3, p2, idx, K, want_ut=False):
+    p3 = np.ascontiguousarray(p3, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    R, t, ut = np.zeros((3, 3)), np.zeros(3), np.zeros((12, 12))
+    k4 = _K4(K)
+    lib().orc_epnp(_dp(p3), _dp(p2), _dp(idx), len(idx), _dp(k4), _dp(R), _dp(t), _dp(ut))
+    return (R, t, ut) if want_ut else (R, t)
+
+
+def pnp_score(p3, p2, K, R, t, reproj=2.0):
+    p3 = np.ascontiguousarray(p3, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    R = np.ascontiguousarray(R, np.float64)
+    t = np.ascontiguousarray(t, np.float64)
+    mask = np.zeros(len(p3), np.uint8)
+    k4 = _K4(K)
+    f = lib().orc_pnp_score
+    f.argtypes = [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_float, C.c_void_p]
+    cnt = f(_dp(p3), _dp(p2), len(p3), _dp(k4), _dp(R), _dp(t), reproj, _dp(mask))
+    return cnt, mask
+
+
+def rodrigues(r, want_jac=False):
+    r = np.ascontiguousarray(r, np.float64)
+    R, J = np.zeros((3, 3)), np.zeros((3, 9))
+    lib().orc_rodrigues(_dp(r), _dp(R), _dp(J) if want_jac else None)
+    return (R, J) if want_jac else R
+
+
+def rodrigues_inv(R):
+    R = np.ascontiguousarray(R, np.float64)
+    r = np.zeros(3)
+    lib().orc_rodrigues_inv(_dp(R), _dp(r))
+    return r
+
+
+def solve_pnp_iterative(M, m, K, init_R=None, init_t=None):
+    M = np.ascontiguousarray(M, np.float64)
+    m = np.ascontiguousarray(m, np.float64)
+    R0 = np.ascontiguousarray(np.eye(3) if init_R is None else init_R, np.float64)
+    t0 = np.ascontiguousarray(np.zeros(3) if init_t is None else init_t, np.float64)
+    param = np.zeros(6)
+    it, ev = C.c_int(), C.c_int()
+    k4 = _K4(K)
+    dlt = lib().orc_solve_pnp_iterative(_dp(M), _dp(m), len(M), _dp(k4), _dp(R0), _dp(t0), _dp(param),
+                                        C.byref(it), C.byref(ev))
+    return dict(rvec=param[:3].copy(), tvec=param[3:].copy(), dlt=dlt, lm_iters=it.value, lm_evals=ev.value)
+
+
+def solve_pnp_ransac(p3, p2, K, iters=100, reproj=2.0, confidence=0.999):
+    """cv::solvePnPRansac as vo.cpp:326-329 calls it.  Returns a dict with ok, rvec, tvec, inliers and the
+    debug record (models [iters,12], counts [iters], best_iter, iters_run, dlt, lm_iters)."""
+    p3 = np.ascontiguousarray(p3, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    n = len(p3)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    inl = np.zeros(max(n, 1), np.int32)
+    n_inl = C.c_int()
+    models = np.full((iters, 12), np.nan)
+    counts = np.full(iters, -1, np.int32)
+    info = np.zeros(4, np.int32)
+    k4 = _K4(K)
+    f = lib().orc_solve_pnp_ransac
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_double] + [C.c_void_p] * 7
+    ok = f(_dp(p3), _dp(p2), n, _dp(k4), iters, reproj, confidence, _dp(rvec), _dp(tvec), _dp(inl),
+           C.addressof(n_inl), _dp(models), _dp(counts), _dp(info))
+    return dict(ok=bool(ok), rvec=rvec, tvec=tvec, inliers=inl[:n_inl.value].copy(), models=models, counts=counts,
+                best_iter=int(info[0]), iters_run=int(info[1]), dlt=int(info[2]), lm_iters=int(info[3]))
