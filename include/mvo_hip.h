@@ -154,6 +154,36 @@ int mvo_ba_solve_resident(mvo_ctx* ctx, mvo_ba_handle* handle);
 int mvo_ba_fetch(mvo_ctx* ctx, mvo_ba_handle* handle, double* poses, double* points, mvo_ba_stats* stats);
 void mvo_ba_release(mvo_ctx* ctx, mvo_ba_handle* handle);
 
+/* ---- tracking: the steps between matching and bundle adjustment -------- */
+/* The map (vo::Map::map_points_, include/my_slam/vo/map.h:19: MapPoint::pos_ + descriptor_) kept resident in
+ * HBM so that map descriptors never cross PCIe between frames.  The order of the uploaded arrays is the
+ * host's iteration order of map_points_; indices returned below refer to it. */
+typedef struct mvo_map mvo_map;
+int mvo_map_create(mvo_ctx* ctx, mvo_map** map);
+void mvo_map_release(mvo_ctx* ctx, mvo_map* map);
+/* Replaces the device copy: pos n x 3 float (cv::Point3f), desc n x 32 bytes. */
+int mvo_map_upload(mvo_ctx* ctx, mvo_map* map, const float* pos, const uint8_t* desc, int n);
+/* Positions [first, first+n) only -- what bundleAdjustment writes back (g2o_ba.cpp:306-316). */
+int mvo_map_update_positions(mvo_ctx* ctx, mvo_map* map, const float* pos, int first, int n);
+/* VisualOdometry::getMappointsInCurrentView_ (src/vo/vo.cpp:16-49): the map points with p_cam.z >= 0 whose
+ * pixel lies strictly inside the cols x rows image, in map order.  T_w_c: 4x4 row-major double (inverted
+ * on the host like cv::Mat::inv()).  idx / px (n x 2, cv::Point2f) are host outputs of capacity cap;
+ * *d_desc_out receives a device pointer (owned by the ctx, valid until the next call) to the gathered
+ * n x 32 descriptors = `corresponding_mappoints_descriptors`, ready for mvo_match_features_dev. */
+int mvo_map_points_in_view(mvo_ctx* ctx, mvo_map* map, const double* T_w_c, double fx, double fy, double cx,
+                           double cy, int cols, int rows, int32_t* idx, float* px, int cap, int* n,
+                           const void** d_desc_out);
+/* cv::solvePnPRansac(pts_3d, pts_2d, K, cv::Mat(), R_vec, t, false, iterations, reprojection_error,
+ * confidence, inliers) as called at src/vo/vo.cpp:326-329 (flags = SOLVEPNP_ITERATIVE): RANSAC over 5-point
+ * EPnP hypotheses with the subsets cv::RNG((uint64)-1) draws, then DLT + Levenberg-Marquardt on the inliers.
+ * pts3d n x 3 float, pts2d n x 2 float.  *found = 0 when no hypothesis reaches 5 inliers (solvePnPRansac
+ * returns false) or n < 5; inliers (ascending indices into the pairs) needs capacity cap >= n. */
+int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy,
+                         double cx, double cy, int iterations, float reprojection_error, double confidence,
+                         double* rvec, double* tvec, int32_t* inliers, int cap, int* n_inliers, int* found);
+/* cv::Rodrigues(rvec -> R, 3x3 row-major) as used at vo.cpp:334; host-side. */
+int mvo_rodrigues(const double* rvec, double* R);
+
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per
  * kernel name until reset. */
@@ -180,6 +210,11 @@ int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int 
 /* FAST+NMS survivors of the last detection in canonical (level,row,col) order as 16-byte records
  * {int16 x, y; int32 level<<16|fast_score; float harris; float angle}. */
 int mvo_debug_get_candidates(mvo_ctx* ctx, void* out, int cap, int* n);
+
+/* Record of the last mvo_solve_pnp_ransac on this ctx: models (iterations x 12: R row-major, t) and inlier
+ * counts of every hypothesis, info[6] = {best iteration, iterations the sequential loop would have run,
+ * DLT used, LM iterations, LM residual evaluations, hypotheses evaluated}. */
+int mvo_debug_get_pnp(mvo_ctx* ctx, double* models, int32_t* counts, int cap, int32_t* info);
 
 #ifdef __cplusplus
 }

@@ -302,6 +302,63 @@ class Context:
         self._chk(self.lib.mvo_bundle_adjustment(self.h, C.byref(pr), C.byref(st)))
         return poses.reshape(-1, 4, 4), points, {k: getattr(st, k) for k, _ in BaStats._fields_}
 
+    # ---- tracking rows (vo.cpp:16-49, 270-357)
+    def map_create(self):
+        m = C.c_void_p()
+        self._chk(self.lib.mvo_map_create(self.h, C.byref(m)))
+        return m
+
+    def map_release(self, m):
+        self.lib.mvo_map_release.restype = None
+        self.lib.mvo_map_release(self.h, m)
+
+    def map_upload(self, m, pos, desc):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        assert len(pos) == len(desc)
+        self._chk(self.lib.mvo_map_upload(self.h, m, _p(pos), _p(desc), len(pos)))
+
+    def map_update_positions(self, m, pos, first=0):
+        pos = np.ascontiguousarray(pos, np.float32).reshape(-1, 3)
+        self._chk(self.lib.mvo_map_update_positions(self.h, m, _p(pos), int(first), len(pos)))
+
+    def map_points_in_view(self, m, T_w_c, K, cols, rows, cap):
+        """-> (idx [n] int32, px [n,2] float32, device pointer of the gathered n x 32 descriptors)."""
+        T = np.ascontiguousarray(T_w_c, np.float64).reshape(4, 4)
+        idx = np.zeros(max(cap, 1), np.int32)
+        px = np.zeros((max(cap, 1), 2), np.float32)
+        n = C.c_int()
+        d = C.c_void_p()
+        self._chk(self.lib.mvo_map_points_in_view(self.h, m, _p(T), C.c_double(K["fx"]), C.c_double(K["fy"]),
+                                                  C.c_double(K["cx"]), C.c_double(K["cy"]), int(cols), int(rows),
+                                                  _p(idx), _p(px), int(cap), C.byref(n), C.byref(d)))
+        return idx[:n.value].copy(), px[:n.value].copy(), d.value
+
+    def solve_pnp_ransac(self, pts3d, pts2d, K, iterations=100, reprojection_error=2.0, confidence=0.999):
+        """cv::solvePnPRansac as vo.cpp:326-329 calls it -> dict(ok, rvec, tvec, inliers)."""
+        p3 = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3)
+        p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+        assert len(p3) == len(p2)
+        n = len(p3)
+        rvec, tvec = np.zeros(3), np.zeros(3)
+        inl = np.zeros(max(n, 1), np.int32)
+        n_inl, found = C.c_int(), C.c_int()
+        self._chk(self.lib.mvo_solve_pnp_ransac(self.h, _p(p3), _p(p2), n, C.c_double(K["fx"]), C.c_double(K["fy"]),
+                                                C.c_double(K["cx"]), C.c_double(K["cy"]), int(iterations),
+                                                C.c_float(reprojection_error), C.c_double(confidence), _p(rvec),
+                                                _p(tvec), _p(inl), len(inl), C.byref(n_inl), C.byref(found)))
+        return dict(ok=bool(found.value), rvec=rvec, tvec=tvec, inliers=inl[:n_inl.value].copy())
+
+    def debug_pnp(self, cap=4096):
+        models = np.zeros((cap, 12))
+        counts = np.zeros(cap, np.int32)
+        info = np.zeros(6, np.int32)
+        h = self.lib.mvo_debug_get_pnp(self.h, _p(models), _p(counts), cap, _p(info))
+        if h < 0:
+            self._chk(h)
+        return dict(models=models[:h].copy(), counts=counts[:h].copy(), best_iter=int(info[0]), iters_run=int(info[1]),
+                    dlt=int(info[2]), lm_iters=int(info[3]), lm_evals=int(info[4]), n_hyp=int(info[5]))
+
     # ---- measurement / debug
     def synchronize(self):
         self._chk(self.lib.mvo_synchronize(self.h))
@@ -344,6 +401,15 @@ def debug_set(key, value):
     r = load_library().mvo_debug_set(key.encode(), int(value))
     if r != MVO_OK:
         raise MvoError(r, "unknown debug key")
+
+
+def rodrigues(rvec):
+    """cv::Rodrigues(rvec) -> 3x3 (vo.cpp:334)."""
+    r = np.ascontiguousarray(rvec, np.float64).reshape(3)
+    R = np.zeros((3, 3))
+    if load_library().mvo_rodrigues(_p(r), _p(R)) != MVO_OK:
+        raise MvoError(MVO_ERR_INVALID, "mvo_rodrigues")
+    return R
 
 
 def remove_duplicated_matches(matches):

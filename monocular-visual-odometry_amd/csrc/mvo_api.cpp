@@ -85,6 +85,7 @@ void mvo_destroy(mvo_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    track_release(ctx);
     void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_score, ctx->d_tabs, ctx->d_cell_mask, ctx->d_cell_cnt, ctx->d_cell_off,
                    ctx->d_hdr, ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
                    ctx->d_mout};

@@ -60,6 +60,17 @@ struct CandHeader {
     int32_t pad[3];
 };
 
+// tracking rows (track_kernels.hip / track_host.cpp)
+struct TrackCamera {
+    double fx, fy, cx, cy;
+};
+struct TrackViewArgs {
+    double T[12];  // rows 0..2 of T_c_w = inv(T_w_c)
+    double fx, fy, cx, cy;
+    int cols, rows;
+};
+struct mvo_track_state;  // device buffers of the tracking rows, allocated on first use
+
 struct ProfEntry {
     int64_t launches = 0;
     double ms = 0;
@@ -103,6 +114,8 @@ struct mvo_ctx {
     float *d_mqxy = nullptr, *d_mtxy = nullptr;
     int32_t* d_mout = nullptr;
     int m_cap_q = 0, m_cap_t = 0;
+    // --- tracking rows
+    mvo_track_state* track = nullptr;
     // --- BA diagnostics of the last fetched solve
     long long ba_phase[16] = {0};
     int ba_wgs = 0;
@@ -148,6 +161,17 @@ int orb_launch_brief(mvo_ctx* ctx, int n);
 int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out);
 int match_launch_radius_l1(mvo_ctx* ctx, const uint8_t* d_q, const float* d_qxy, int nq, const uint8_t* d_t,
                            const float* d_txy, int nt, float max_px, int32_t* d_out);
+// track_kernels.hip
+int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_desc, int n, const TrackViewArgs& a,
+                             int32_t* d_idx, float* d_px, uint8_t* d_desc_out, int32_t* d_n);
+int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_p2, int n, const int32_t* d_subsets,
+                                int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
+                                uint8_t* d_masks);
+int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_mask, int n,
+                            const TrackCamera& cam, const double* d_model, int mode, double* d_Mg, double* d_mg,
+                            double* d_out);
+// track_host.cpp
+void track_release(mvo_ctx* ctx);
 // ba_kernels.hip
 struct mvo_ba_handle;
 int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st);

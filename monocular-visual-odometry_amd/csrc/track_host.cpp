@@ -1,0 +1,439 @@
+// csrc/track_host.cpp -- host side of the tracking rows (include/mvo_hip.h "tracking"): device buffers, the
+// sequential parts of cv::solvePnPRansac (subset drawing with cv::RNG, the adaptive iteration count) and the
+// map residency used by getMappointsInCurrentView_.  Reference: src/vo/vo.cpp:16-49 and 270-357.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "mvo_internal.h"
+
+struct mvo_map {
+    float* d_pos = nullptr;
+    uint8_t* d_desc = nullptr;
+    int n = 0, cap = 0;
+};
+
+struct mvo_track_state {
+    // PnP: pairs, subsets, per-hypothesis results, refinement scratch
+    float *d_p3 = nullptr, *d_p2 = nullptr;
+    double *d_Mg = nullptr, *d_mg = nullptr;
+    int cap_n = 0;
+    int32_t* d_subsets = nullptr;
+    double* d_models = nullptr;
+    int32_t* d_counts = nullptr;
+    double* d_out = nullptr;
+    int cap_h = 0;
+    uint8_t* d_masks = nullptr;
+    size_t cap_masks = 0;
+    // record of the last solve (mvo_debug_get_pnp)
+    std::vector<double> models;
+    std::vector<int32_t> counts;
+    int32_t info[6] = {-1, 0, 0, 0, 0, 0};
+    // map points in view
+    int32_t* d_view_idx = nullptr;
+    float* d_view_px = nullptr;
+    uint8_t* d_view_desc = nullptr;
+    int32_t* d_view_n = nullptr;
+    int cap_view = 0;
+};
+
+namespace {
+
+template <class T>
+void free_dev(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+mvo_track_state* state(mvo_ctx* ctx) {
+    if (!ctx->track) ctx->track = new mvo_track_state();
+    return ctx->track;
+}
+
+int ensure_pnp(mvo_ctx* ctx, int n, int n_hyp) {
+    mvo_track_state* s = state(ctx);
+    if (n > s->cap_n) {
+        free_dev(s->d_p3);
+        free_dev(s->d_p2);
+        free_dev(s->d_Mg);
+        free_dev(s->d_mg);
+        s->cap_n = 0;
+        const int cap = std::max(4096, n + n / 2);
+        MVO_HIP(hipMalloc((void**)&s->d_p3, (size_t)cap * 3 * sizeof(float)));
+        MVO_HIP(hipMalloc((void**)&s->d_p2, (size_t)cap * 2 * sizeof(float)));
+        MVO_HIP(hipMalloc((void**)&s->d_Mg, (size_t)cap * 3 * sizeof(double)));
+        MVO_HIP(hipMalloc((void**)&s->d_mg, (size_t)cap * 2 * sizeof(double)));
+        s->cap_n = cap;
+    }
+    if (n_hyp > s->cap_h) {
+        free_dev(s->d_subsets);
+        free_dev(s->d_models);
+        free_dev(s->d_counts);
+        s->cap_h = 0;
+        const int cap = std::max(128, n_hyp);
+        MVO_HIP(hipMalloc((void**)&s->d_subsets, (size_t)cap * 5 * sizeof(int32_t)));
+        MVO_HIP(hipMalloc((void**)&s->d_models, (size_t)cap * 12 * sizeof(double)));
+        MVO_HIP(hipMalloc((void**)&s->d_counts, (size_t)cap * sizeof(int32_t)));
+        s->cap_h = cap;
+    }
+    if (!s->d_out) MVO_HIP(hipMalloc((void**)&s->d_out, 16 * sizeof(double)));
+    const size_t need = (size_t)n_hyp * (size_t)n;
+    if (need > s->cap_masks) {
+        free_dev(s->d_masks);
+        s->cap_masks = 0;
+        const size_t cap = std::max<size_t>(need + need / 2, (size_t)1 << 20);
+        MVO_HIP(hipMalloc((void**)&s->d_masks, cap));
+        s->cap_masks = cap;
+    }
+    return MVO_OK;
+}
+
+// cv::RNG (multiply-with-carry) as RANSACPointSetRegistrator::run seeds it: RNG rng((uint64)-1).
+struct MwcRng {
+    uint64_t state = 0xffffffffffffffffULL;
+    uint32_t next() {
+        state = (uint64_t)(uint32_t)state * 4164903690ULL + (uint32_t)(state >> 32);
+        return (uint32_t)state;
+    }
+    int uniform(int lo, int hi) { return lo == hi ? lo : (int)(next() % (uint32_t)(hi - lo) + lo); }
+};
+
+// RANSACPointSetRegistrator::getSubset: draw until the slot differs from the earlier ones (PnP's checkSubset
+// accepts every sample).
+void draw_subsets(int count, int n_iters, int32_t* out) {
+    MwcRng rng;
+    for (int it = 0; it < n_iters; ++it) {
+        int32_t* s = out + 5 * it;
+        for (int i = 0; i < 5; ++i) {
+            bool fresh;
+            do {
+                s[i] = rng.uniform(0, count);
+                fresh = true;
+                for (int j = 0; j < i; ++j) fresh = fresh && s[j] != s[i];
+            } while (!fresh);
+        }
+    }
+}
+
+// cv::RANSACUpdateNumIters
+int update_num_iters(double p, double ep, int model_points, int max_iters) {
+    p = std::min(std::max(p, 0.), 1.);
+    ep = std::min(std::max(ep, 0.), 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+
+// cv::Mat::inv() (DECOMP_LU) of T_w_c, rows 0..2 only are needed by the kernel
+bool invert_pose_lu(const double* T, double* out12) {
+    double A[4][4], B[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = T[4 * i + j];
+            B[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int i = 0; i < 4; ++i) {
+        int piv = i;
+        for (int j = i + 1; j < 4; ++j)
+            if (std::fabs(A[j][i]) > std::fabs(A[piv][i])) piv = j;
+        if (std::fabs(A[piv][i]) < DBL_EPSILON * 100) return false;
+        if (piv != i) {
+            std::swap_ranges(A[i], A[i] + 4, A[piv]);
+            std::swap_ranges(B[i], B[i] + 4, B[piv]);
+        }
+        const double d = -1 / A[i][i];
+        for (int j = i + 1; j < 4; ++j) {
+            const double alpha = A[j][i] * d;
+            for (int c = i + 1; c < 4; ++c) A[j][c] += alpha * A[i][c];
+            for (int c = 0; c < 4; ++c) B[j][c] += alpha * B[i][c];
+        }
+    }
+    for (int i = 3; i >= 0; --i)
+        for (int j = 0; j < 4; ++j) {
+            double s = B[i][j];
+            for (int c = i + 1; c < 4; ++c) s -= A[i][c] * B[c][j];
+            B[i][j] = s / A[i][i];
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) out12[4 * i + j] = B[i][j];
+    return true;
+}
+
+}  // namespace
+
+void track_release(mvo_ctx* ctx) {
+    mvo_track_state* s = ctx->track;
+    if (!s) return;
+    free_dev(s->d_p3);
+    free_dev(s->d_p2);
+    free_dev(s->d_Mg);
+    free_dev(s->d_mg);
+    free_dev(s->d_subsets);
+    free_dev(s->d_models);
+    free_dev(s->d_counts);
+    free_dev(s->d_out);
+    free_dev(s->d_masks);
+    free_dev(s->d_view_idx);
+    free_dev(s->d_view_px);
+    free_dev(s->d_view_desc);
+    free_dev(s->d_view_n);
+    delete s;
+    ctx->track = nullptr;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------- map residency
+int mvo_map_create(mvo_ctx* ctx, mvo_map** map) {
+    if (!ctx || !map) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    *map = new mvo_map();
+    return MVO_OK;
+}
+
+void mvo_map_release(mvo_ctx* ctx, mvo_map* map) {
+    if (!map) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    free_dev(map->d_pos);
+    free_dev(map->d_desc);
+    delete map;
+}
+
+int mvo_map_upload(mvo_ctx* ctx, mvo_map* map, const float* pos, const uint8_t* desc, int n) {
+    if (!ctx || !map || n < 0 || (n && (!pos || !desc)))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    if (n > map->cap) {
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        free_dev(map->d_pos);
+        free_dev(map->d_desc);
+        map->cap = 0;
+        const int cap = std::max(4096, n + n / 2);
+        MVO_HIP(hipMalloc((void**)&map->d_pos, (size_t)cap * 3 * sizeof(float)));
+        MVO_HIP(hipMalloc((void**)&map->d_desc, (size_t)cap * 32));
+        map->cap = cap;
+    }
+    map->n = n;
+    if (n) {
+        // staged through pinned memory so that the caller's arrays may be reused as soon as we return
+        int r = mvo_ensure_pinned(ctx, (size_t)n * 44);
+        if (r) return r;
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(ctx->h_pin, pos, (size_t)n * 12);
+        std::memcpy(ctx->h_pin + (size_t)n * 12, desc, (size_t)n * 32);
+        MVO_HIP(hipMemcpyAsync(map->d_pos, ctx->h_pin, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        MVO_HIP(hipMemcpyAsync(map->d_desc, ctx->h_pin + (size_t)n * 12, (size_t)n * 32, hipMemcpyHostToDevice,
+                               ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return MVO_OK;
+}
+
+int mvo_map_update_positions(mvo_ctx* ctx, mvo_map* map, const float* pos, int first, int n) {
+    if (!ctx || !map || first < 0 || n < 0 || first + n > map->n || (n && !pos))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (!n) return MVO_OK;
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = mvo_ensure_pinned(ctx, (size_t)n * 12);
+    if (r) return r;
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->h_pin, pos, (size_t)n * 12);
+    MVO_HIP(hipMemcpyAsync(map->d_pos + 3 * (size_t)first, ctx->h_pin, (size_t)n * 12, hipMemcpyHostToDevice,
+                           ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    return MVO_OK;
+}
+
+int mvo_map_points_in_view(mvo_ctx* ctx, mvo_map* map, const double* T_w_c, double fx, double fy, double cx, double cy,
+                           int cols, int rows, int32_t* idx, float* px, int cap, int* n, const void** d_desc_out) {
+    if (!ctx || !map || !T_w_c || !n || cap < 0 || (cap && (!idx || !px)))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    *n = 0;
+    if (d_desc_out) *d_desc_out = nullptr;
+    TrackViewArgs a;
+    if (!invert_pose_lu(T_w_c, a.T)) return mvo_set_err(ctx, MVO_ERR_INVALID, "T_w_c is singular", hipSuccess);
+    a.fx = fx;
+    a.fy = fy;
+    a.cx = cx;
+    a.cy = cy;
+    a.cols = cols;
+    a.rows = rows;
+    if (map->n == 0) return MVO_OK;
+    MVO_HIP(hipSetDevice(ctx->device));
+    mvo_track_state* s = state(ctx);
+    if (map->n > s->cap_view) {
+        free_dev(s->d_view_idx);
+        free_dev(s->d_view_px);
+        free_dev(s->d_view_desc);
+        s->cap_view = 0;
+        const int c = std::max(4096, map->n + map->n / 2);
+        MVO_HIP(hipMalloc((void**)&s->d_view_idx, (size_t)c * 4));
+        MVO_HIP(hipMalloc((void**)&s->d_view_px, (size_t)c * 8));
+        MVO_HIP(hipMalloc((void**)&s->d_view_desc, (size_t)c * 32));
+        s->cap_view = c;
+    }
+    if (!s->d_view_n) MVO_HIP(hipMalloc((void**)&s->d_view_n, 4));
+    int r = track_launch_map_in_view(ctx, map->d_pos, map->d_desc, map->n, a, s->d_view_idx, s->d_view_px,
+                                     s->d_view_desc, s->d_view_n);
+    if (r) return r;
+    if ((r = mvo_ensure_pinned(ctx, 16 + (size_t)map->n * 12))) return r;
+    // count first (4 bytes), then exactly the survivors
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_view_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    int cnt;
+    std::memcpy(&cnt, ctx->h_pin, 4);
+    *n = cnt;
+    if (d_desc_out) *d_desc_out = s->d_view_desc;
+    if (ctx->prof) mvo_prof_collect(ctx);
+    if (cnt > cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "mvo_map_points_in_view: output buffers too small", hipSuccess);
+    if (cnt) {
+        MVO_HIP(hipMemcpyAsync(ctx->h_pin + 16, s->d_view_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipMemcpyAsync(ctx->h_pin + 16 + (size_t)cnt * 4, s->d_view_px, (size_t)cnt * 8, hipMemcpyDeviceToHost,
+                               ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        std::memcpy(idx, ctx->h_pin + 16, (size_t)cnt * 4);
+        std::memcpy(px, ctx->h_pin + 16 + (size_t)cnt * 4, (size_t)cnt * 8);
+    }
+    return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- solvePnPRansac
+int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy, double cx,
+                         double cy, int iterations, float reprojection_error, double confidence, double* rvec,
+                         double* tvec, int32_t* inliers, int cap, int* n_inliers, int* found) {
+    if (!ctx || n < 0 || (n && (!pts3d || !pts2d)) || !rvec || !tvec || !n_inliers || !found || cap < 0 ||
+        (cap && !inliers))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (!(confidence > 0 && confidence < 1))  // CV_Assert in RANSACPointSetRegistrator::run
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "mvo_solve_pnp_ransac: confidence must be in (0, 1)", hipSuccess);
+    *n_inliers = 0;
+    *found = 0;
+    for (int k = 0; k < 3; ++k) rvec[k] = tvec[k] = 0;
+    constexpr int kModel = 5;
+    mvo_track_state* s = state(ctx);
+    s->models.clear();
+    s->counts.clear();
+    s->info[0] = -1;
+    for (int k = 1; k < 6; ++k) s->info[k] = 0;
+    if (n < kModel) return MVO_OK;  // vo.cpp:321 (kMinPtsForPnP) never gets here; solvePnPRansac would reject it
+    if (cap < n) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "mvo_solve_pnp_ransac: inlier buffer smaller than n", hipSuccess);
+    const int n_hyp = n == kModel ? 1 : std::max(iterations, 1);
+    MVO_HIP(hipSetDevice(ctx->device));
+    int r = ensure_pnp(ctx, n, n_hyp);
+    if (r) return r;
+    // stage pairs + subsets
+    const size_t b3 = (size_t)n * 12, b2 = (size_t)n * 8, bs = (size_t)n_hyp * kModel * 4;
+    if ((r = mvo_ensure_pinned(ctx, std::max(b3 + b2 + bs, (size_t)n_hyp * 100 + (size_t)n + 256)))) return r;
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->h_pin, pts3d, b3);
+    std::memcpy(ctx->h_pin + b3, pts2d, b2);
+    int32_t* subsets = reinterpret_cast<int32_t*>(ctx->h_pin + b3 + b2);
+    if (n == kModel)
+        for (int i = 0; i < kModel; ++i) subsets[i] = i;
+    else
+        draw_subsets(n, n_hyp, subsets);
+    MVO_HIP(hipMemcpyAsync(s->d_p3, ctx->h_pin, b3, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(s->d_p2, ctx->h_pin + b3, b2, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(s->d_subsets, subsets, bs, hipMemcpyHostToDevice, ctx->stream));
+    const TrackCamera cam{fx, fy, cx, cy};
+    const float thr2 = (float)((double)reprojection_error * (double)reprojection_error);
+    if ((r = track_launch_pnp_hypotheses(ctx, s->d_p3, s->d_p2, n, s->d_subsets, n_hyp, cam, thr2, s->d_models, s->d_counts,
+                                         s->d_masks)))
+        return r;
+    // the sequential bookkeeping of RANSACPointSetRegistrator::run, replayed over the hypothesis results
+    MVO_HIP(hipStreamSynchronize(ctx->stream));  // the staging area is reused for the read-back
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_counts, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin + (size_t)n_hyp * 4, s->d_models, (size_t)n_hyp * 96, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    s->counts.assign(reinterpret_cast<int32_t*>(ctx->h_pin), reinterpret_cast<int32_t*>(ctx->h_pin) + n_hyp);
+    s->models.resize((size_t)n_hyp * 12);
+    std::memcpy(s->models.data(), ctx->h_pin + (size_t)n_hyp * 4, (size_t)n_hyp * 96);
+    s->info[5] = n_hyp;
+    int best = -1, mode = 0;
+    if (n == kModel) {  // "model_points == npoints": the kernel result is the answer and every pair an inlier
+        best = 0;
+        mode = 1;
+        s->info[1] = 1;
+    } else {
+        int niters = n_hyp, max_good = 0, it = 0;
+        for (; it < niters; ++it) {
+            const int good = s->counts[it];
+            if (good > std::max(max_good, kModel - 1)) {
+                max_good = good;
+                best = it;
+                niters = update_num_iters(confidence, (double)(n - good) / n, kModel, niters);
+            }
+        }
+        s->info[1] = it;
+    }
+    s->info[0] = best;
+    if (best < 0) {
+        if (ctx->prof) mvo_prof_collect(ctx);
+        return MVO_OK;  // no model with at least 5 inliers
+    }
+    if ((r = track_launch_pnp_refine(ctx, s->d_p3, s->d_p2, s->d_masks + (size_t)best * n, n, cam,
+                                     s->d_models + 12 * (size_t)best, mode, s->d_Mg, s->d_mg, s->d_out)))
+        return r;
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_out, 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (mode == 0)
+        MVO_HIP(hipMemcpyAsync(ctx->h_pin + 128, s->d_masks + (size_t)best * n, (size_t)n, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) mvo_prof_collect(ctx);
+    double out[10];
+    std::memcpy(out, ctx->h_pin, sizeof(out));
+    for (int k = 0; k < 3; ++k) {
+        rvec[k] = out[k];
+        tvec[k] = out[3 + k];
+    }
+    s->info[2] = (int)out[7];
+    s->info[3] = (int)out[8];
+    s->info[4] = (int)out[9];
+    int cnt = 0;
+    if (mode == 1) {
+        for (int i = 0; i < n; ++i) inliers[cnt++] = i;
+    } else {
+        const uint8_t* mask = ctx->h_pin + 128;
+        for (int i = 0; i < n; ++i)
+            if (mask[i]) inliers[cnt++] = i;
+    }
+    *n_inliers = cnt;
+    *found = 1;
+    return MVO_OK;
+}
+
+int mvo_rodrigues(const double* rvec, double* R) {
+    if (!rvec || !R) return MVO_ERR_INVALID;
+    const double x = rvec[0], y = rvec[1], z = rvec[2];
+    const double theta = std::sqrt(x * x + y * y + z * z);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        return MVO_OK;
+    }
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, it = 1. / theta;
+    const double rx = x * it, ry = y * it, rz = z * it;
+    const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
+    const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
+    for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * r_x[k];
+    return MVO_OK;
+}
+
+int mvo_debug_get_pnp(mvo_ctx* ctx, double* models, int32_t* counts, int cap, int32_t* info) {
+    if (!ctx || !ctx->track) return mvo_set_err(ctx, MVO_ERR_STATE, "no PnP solve on this ctx yet", hipSuccess);
+    const mvo_track_state* s = ctx->track;
+    const int h = (int)s->counts.size();
+    if (info) std::memcpy(info, s->info, sizeof(s->info));
+    if (h > cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "mvo_debug_get_pnp: buffers too small", hipSuccess);
+    if (models && h) std::memcpy(models, s->models.data(), (size_t)h * 96);
+    if (counts && h) std::memcpy(counts, s->counts.data(), (size_t)h * 4);
+    return h;
+}
+}

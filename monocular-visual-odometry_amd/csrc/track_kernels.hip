@@ -1,0 +1,147 @@
+// csrc/track_kernels.hip -- tracking rows between the matcher and bundle adjustment:
+//   k_map_in_view      VisualOdometry::getMappointsInCurrentView_ (src/vo/vo.cpp:16-49): project the resident map,
+//                      keep what is in front of the camera and inside the image, gather the descriptors.
+//   k_pnp_hypotheses   the RANSAC loop of cv::solvePnPRansac (vo.cpp:326-329): one wave per hypothesis runs the
+//                      5-point EPnP kernel and scores every 3D-2D pair.
+//   k_pnp_refine       the final cv::solvePnP(SOLVEPNP_ITERATIVE) on the inliers: DLT start + Levenberg-Marquardt.
+// The arithmetic lives in pnp_wave.h (wave-level SPMD code); this file binds it to threads and LDS.
+#include "mvo_internal.h"
+
+#define PW_FN __device__ __forceinline__
+#define PW_LANES(l) for (int l = (int)threadIdx.x, pw_once_ = 1; pw_once_; pw_once_ = 0)
+#define PW_SYNC() __syncthreads()
+#define PW_UNROLL _Pragma("unroll")
+#include "pnp_wave.h"
+
+// ------------------------------------------------------------------------------------------------ map in view
+// One workgroup walks the map in chunks of 1024 points and appends the survivors in map order (the reference
+// iterates Map::map_points_ and push_backs).  p_cam = (float)(T_c_w * p) accumulated in double like
+// basics::preTranslatePoint3f (opencv_funcs.cpp:67-78); pixel = (float)(fx * x / z + cx) like geometry::cam2pixel
+// (camera.cpp:23-28); the tests are `p_cam.z < 0` and the strict image bounds of vo.cpp:31-36.
+__global__ __launch_bounds__(1024) void k_map_in_view(const float* __restrict__ pos, const uint4* __restrict__ desc,
+                                                       int n, TrackViewArgs a, int32_t* __restrict__ idx,
+                                                       float2* __restrict__ px, uint4* __restrict__ desc_out,
+                                                       int32_t* __restrict__ n_out) {
+    __shared__ int wave_cnt[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int base = 0;
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + (int)threadIdx.x;
+        bool in = false;
+        float u = 0.f, v = 0.f;
+        if (i < n) {
+            const double p[4] = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], 1.0};
+            double res[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += a.T[4 * r + j] * p[j];
+                res[r] = acc;
+            }
+            const float pcx = (float)res[0], pcy = (float)res[1], pcz = (float)res[2];
+            in = !(pcz < 0);
+            u = (float)(a.fx * pcx / pcz + a.cx);
+            v = (float)(a.fy * pcy / pcz + a.cy);
+            in = in && (u > 0 && v > 0 && u < (float)a.cols && v < (float)a.rows);
+        }
+        const unsigned long long b = __ballot(in);
+        if (lane == 0) wave_cnt[w] = __popcll(b);
+        __syncthreads();
+        int off = base, total = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int c = wave_cnt[q];
+            off += q < w ? c : 0;
+            total += c;
+        }
+        if (in) {
+            const int o = off + __popcll(b & ((1ull << lane) - 1ull));
+            idx[o] = i;
+            px[o] = make_float2(u, v);
+            desc_out[2 * o] = desc[2 * i];
+            desc_out[2 * o + 1] = desc[2 * i + 1];
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_out = base;
+}
+
+int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_desc, int n, const TrackViewArgs& a,
+                             int32_t* d_idx, float* d_px, uint8_t* d_desc_out, int32_t* d_n) {
+    ProfScope ps(ctx, "k_map_in_view");
+    hipLaunchKernelGGL(k_map_in_view, dim3(1), dim3(1024), 0, ctx->stream, d_pos, (const uint4*)d_desc, n, a, d_idx,
+                       (float2*)d_px, (uint4*)d_desc_out, d_n);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ PnP RANSAC
+__global__ __launch_bounds__(64) void k_pnp_hypotheses(const float* __restrict__ p3, const float* __restrict__ p2, int n,
+                                                        const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
+                                                        double* __restrict__ models, int32_t* __restrict__ counts,
+                                                        uint8_t* __restrict__ masks) {
+    __shared__ pw::HypLds lds;
+    const int h = blockIdx.x;
+    const pw::Camera c{cam.fx, cam.fy, cam.cx, cam.cy};
+    double R[3][3], t[3];
+    pw::epnp_hypothesis(lds, p3, p2, subsets + pw::kModelPoints * h, c, R, t);
+    const int good = pw::score_model(lds, p3, p2, n, c, R, t, thr2, masks + (size_t)h * n);
+    if (threadIdx.x == 0) {
+        double* m = models + 12 * (size_t)h;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) m[3 * i + j] = R[i][j];
+            m[9 + i] = t[i];
+        }
+        counts[h] = good;
+    }
+}
+
+// out: param[6] = (rvec, tvec), then n_inliers, dlt used, LM iterations, LM evaluations (as doubles).
+__global__ __launch_bounds__(64) void k_pnp_refine(const float* __restrict__ p3, const float* __restrict__ p2,
+                                                    const uint8_t* __restrict__ mask, int n, TrackCamera cam,
+                                                    const double* __restrict__ model, int mode, double* Mg, double* mg,
+                                                    double* __restrict__ out) {
+    __shared__ pw::RefLds lds;
+    const pw::Camera c{cam.fx, cam.fy, cam.cx, cam.cy};
+    double R0[3][3], t0[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R0[i][j] = model[3 * i + j];
+        t0[i] = model[9 + i];
+    }
+    pw::RefineResult res;
+    pw::refine_pose(lds, p3, p2, mask, n, c, R0, t0, mode, Mg, mg, res);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out[k] = res.param[k];
+        out[6] = res.n_inliers;
+        out[7] = res.used_dlt;
+        out[8] = res.lm_iters;
+        out[9] = res.lm_evals;
+    }
+}
+
+int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_p2, int n, const int32_t* d_subsets,
+                                int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
+                                uint8_t* d_masks) {
+    ProfScope ps(ctx, "k_pnp_hypotheses");
+    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(n_hyp), dim3(64), 0, ctx->stream, d_p3, d_p2, n, d_subsets, cam, thr2,
+                       d_models, d_counts, d_masks);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}
+
+int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_mask, int n,
+                            const TrackCamera& cam, const double* d_model, int mode, double* d_Mg, double* d_mg,
+                            double* d_out) {
+    ProfScope ps(ctx, "k_pnp_refine");
+    hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(64), 0, ctx->stream, d_p3, d_p2, d_mask, n, cam, d_model, mode, d_Mg,
+                       d_mg, d_out);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}

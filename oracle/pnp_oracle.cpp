@@ -8,11 +8,15 @@
 // not vendored and not installed.  What is restated here is the published upstream structure
 // (RANSACPointSetRegistrator with RNG(-1) and 5-point EPnP hypotheses, then cvFindExtrinsicCameraParams2 = DLT
 // initialisation + CvLevMarq(20 it, FLT_EPSILON) on the inliers), with OUR canonical arithmetic wherever OpenCV
-// calls its SVD: a one-sided (Hestenes) Jacobi, cyclic pair order for n <= 6 and round-robin order for n = 12,
+// calls its SVD: a one-sided (Hestenes) Jacobi, round-robin pair order for n = 6 and 12, cyclic order otherwise,
 // right singular vectors taken from the accumulated rotations.  Documented deviations:
 //   - a hypothesis is carried as (R, t), not as (rvec, tvec): no Rodrigues round trip before scoring;
 //   - planar inlier sets (W[2]/W[1] < 1e-3) and sets with < 6 inliers start the refinement from the best RANSAC
 //     model instead of cv::findHomography / an under-determined DLT.
+// g++ 11 -O3 -fPIC SLP-vectorises the float narrowing in epnp_subset() away (the (float) round trip of the
+// normalised image coordinates disappears, a 1e-8 relative change); -O1/-O2, the sanitizer build and clang agree
+// with each other, so SLP vectorisation is switched off for this file.
+#pragma GCC optimize("no-tree-slp-vectorize")
 #include <float.h>
 #include <math.h>
 #include <string.h>
@@ -49,15 +53,16 @@ double cv_hypot(double a, double b) {
     return 0;
 }
 
-// Round-robin schedule for 12 rows: round r in 0..10, slot k in 0..5 -> disjoint pairs (i < j).
-void rr12_pair(int r, int k, int* i, int* j) {
+// Round-robin schedule for an even number of rows n: round r in 0..n-2, slot k in 0..n/2-1 -> disjoint pairs
+// (i < j).  The pairs of one round touch disjoint rows, so a round may be executed in any order (or in parallel).
+void rr_pair(int n, int r, int k, int* i, int* j) {
     int a, b;
     if (k == 0) {
-        a = 11;
+        a = n - 1;
         b = r;
     } else {
-        a = (r + k) % 11;
-        b = (r - k + 11) % 11;
+        a = (r + k) % (n - 1);
+        b = (r - k + (n - 1)) % (n - 1);
     }
     *i = a < b ? a : b;
     *j = a < b ? b : a;
@@ -108,11 +113,11 @@ void jacobi_svd(double* At, int n, int m, double* Vt, double* W) {
     const int max_iter = m > 30 ? m : 30;
     for (int it = 0; it < max_iter; it++) {
         bool changed = false;
-        if (n == 12) {
-            for (int r = 0; r < 11; r++)
-                for (int k = 0; k < 6; k++) {
+        if (n == 12 || n == 6) {
+            for (int r = 0; r < n - 1; r++)
+                for (int k = 0; k < n / 2; k++) {
                     int i, j;
-                    rr12_pair(r, k, &i, &j);
+                    rr_pair(n, r, k, &i, &j);
                     changed |= jacobi_pair(At, m, Vt, n, i, j);
                 }
         } else {
@@ -126,25 +131,18 @@ void jacobi_svd(double* At, int n, int m, double* Vt, double* W) {
         for (int k = 0; k < m; k++) sd += At[i * m + k] * At[i * m + k];
         W[i] = sqrt(sd);
     }
-    for (int i = 0; i < n - 1; i++) {
-        int j = i;
-        for (int k = i + 1; k < n; k++)
-            if (W[j] < W[k]) j = k;
-        if (i != j) {
-            double t = W[i];
-            W[i] = W[j];
-            W[j] = t;
-            for (int k = 0; k < m; k++) {
-                t = At[i * m + k];
-                At[i * m + k] = At[j * m + k];
-                At[j * m + k] = t;
-            }
-            for (int k = 0; k < n; k++) {
-                t = Vt[i * n + k];
-                Vt[i * n + k] = Vt[j * n + k];
-                Vt[j * n + k] = t;
-            }
-        }
+    // descending, equal values keep their order (rank sort; cv::SVD's selection sort agrees whenever the singular
+    // values are distinct)
+    double At0[12 * 12], Vt0[12 * 12], W0[12];
+    memcpy(At0, At, sizeof(double) * n * m);
+    memcpy(Vt0, Vt, sizeof(double) * n * n);
+    memcpy(W0, W, sizeof(double) * n);
+    for (int i = 0; i < n; i++) {
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (W0[j] > W0[i]) || (W0[j] == W0[i] && j < i);
+        W[rank] = W0[i];
+        memcpy(At + rank * m, At0 + i * m, sizeof(double) * m);
+        memcpy(Vt + rank * n, Vt0 + i * n, sizeof(double) * n);
     }
 }
 

@@ -1,0 +1,80 @@
+"""The PnP kernel SOURCE (csrc/pnp_wave.h) compiled for the host with an explicit 64-lane loop (tests/sim/) must
+reproduce the oracle: bit for bit in the RANSAC stage (EPnP hypotheses, scores, masks), to rounding in the
+refinement (its sums are lane-partitioned).  This is the CPU-side check of the kernel logic; the same header is what
+hipcc compiles into libmvo_hip.so, and the `-m gpu` tests repeat the comparison on the device."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "sim", "pnp_wave_sim.cpp")
+HDR = os.path.join(HERE, "..", "monocular-visual-odometry_amd", "csrc", "pnp_wave.h")
+OUT = os.path.join(HERE, "sim", "_build", "libpnp_wave_sim.so")
+
+
+@pytest.fixture(scope="module")
+def sim():
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
+                               "-Wno-unknown-pragmas", "-o", OUT, SRC])
+    lib = C.CDLL(OUT)
+    lib.sim_hypotheses.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def S():
+    from conftest import graft
+    return graft.load_package().synth
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _k4(K):
+    return np.array([K["fx"], K["fy"], K["cx"], K["cy"]])
+
+
+@pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(outlier_frac=0.5)), (15, dict(planar=True)),
+                                     (16, dict(n_map=400, pix_noise=0.0))])
+def test_hypotheses_match_the_oracle_bit_for_bit(O, S, sim, seed, kw):
+    pr = S.tracking_problem(seed=seed, **kw)
+    p3, p2, K = pr["pts3d"], pr["pts2d"], pr["K"]
+    n, H = len(p3), 100
+    sub = O.pnp_subsets(n, H)
+    models, counts, masks = np.zeros((H, 12)), np.zeros(H, np.int32), np.zeros((H, n), np.uint8)
+    k4 = _k4(K)
+    sim.sim_hypotheses(_dp(p3), _dp(p2), n, _dp(sub), H, _dp(k4), 4.0, _dp(models), _dp(counts), _dp(masks))
+    for h in range(H):
+        R, t = O.epnp(p3, p2, sub[h], K)
+        assert np.array_equal(np.concatenate([R.ravel(), t]), models[h], equal_nan=True), "hypothesis %d" % h
+        c, mk = O.pnp_score(p3, p2, K, R, t)
+        assert c == counts[h] and np.array_equal(mk, masks[h])
+    assert counts.max() > 0.4 * n
+
+
+@pytest.mark.parametrize("seed,kw,dlt", [(11, {}, 1), (15, dict(planar=True), 0), (17, dict(outlier_frac=0.6), 1)])
+def test_refinement_matches_the_oracle(O, S, sim, seed, kw, dlt):
+    pr = S.tracking_problem(seed=seed, **kw)
+    p3, p2, K = pr["pts3d"], pr["pts2d"], pr["K"]
+    n = len(p3)
+    ref = O.solve_pnp_ransac(p3, p2, K)
+    assert ref["ok"] and ref["dlt"] == dlt
+    model = np.ascontiguousarray(ref["models"][ref["best_iter"]])
+    mask = np.zeros(n, np.uint8)
+    mask[ref["inliers"]] = 1
+    k4 = _k4(K)
+    param, info = np.zeros(6), np.zeros(4, np.int32)
+    sim.sim_refine(_dp(p3), _dp(p2), _dp(mask), n, _dp(k4), _dp(model), 0, _dp(param), _dp(info))
+    assert info.tolist()[:3] == [len(ref["inliers"]), dlt, ref["lm_iters"]]
+    assert np.abs(param[:3] - ref["rvec"]).max() < 1e-10 and np.abs(param[3:] - ref["tvec"]).max() < 1e-10
+    # mode 1: (R, t) -> (rvec, tvec) only
+    sim.sim_refine(_dp(p3), _dp(p2), _dp(mask), 5, _dp(k4), _dp(model), 1, _dp(param), _dp(info))
+    assert np.abs(param[:3] - O.rodrigues_inv(model[:9].reshape(3, 3))).max() < 1e-15
+    assert np.array_equal(param[3:], model[9:])
