@@ -183,6 +183,9 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
                          double* rvec, double* tvec, int32_t* inliers, int cap, int* n_inliers, int* found);
 /* cv::Rodrigues(rvec -> R, 3x3 row-major) as used at vo.cpp:334; host-side. */
 int mvo_rodrigues(const double* rvec, double* R);
+/* cv::Mat::inv() of a 4x4 double matrix (LU with partial pivoting) -- the T_w_c <-> T_c_w flips at
+ * vo.cpp:31,349; host-side.  MVO_ERR_INVALID if singular. */
+int mvo_invert_pose(const double* T, double* T_inv);
 
 /* ---- measurement --------------------------------------------------------------------------- */
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per

@@ -129,8 +129,8 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
 }
 
-// cv::Mat::inv() (DECOMP_LU) of T_w_c, rows 0..2 only are needed by the kernel
-bool invert_pose_lu(const double* T, double* out12) {
+// cv::Mat::inv() (DECOMP_LU) of a 4x4 matrix; `rows` = how many rows of the inverse the caller wants
+bool invert_pose_lu(const double* T, double* out, int rows = 3) {
     double A[4][4], B[4][4];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
@@ -159,8 +159,8 @@ bool invert_pose_lu(const double* T, double* out12) {
             for (int c = i + 1; c < 4; ++c) s -= A[i][c] * B[c][j];
             B[i][j] = s / A[i][i];
         }
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 4; ++j) out12[4 * i + j] = B[i][j];
+    for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < 4; ++j) out[4 * i + j] = B[i][j];
     return true;
 }
 
@@ -423,6 +423,14 @@ int mvo_rodrigues(const double* rvec, double* R) {
     const double rrt[9] = {rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz};
     const double r_x[9] = {0, -rz, ry, rz, 0, -rx, -ry, rx, 0};
     for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * r_x[k];
+    return MVO_OK;
+}
+
+int mvo_invert_pose(const double* T, double* T_inv) {
+    if (!T || !T_inv) return MVO_ERR_INVALID;
+    double tmp[16];
+    if (!invert_pose_lu(T, tmp, 4)) return MVO_ERR_INVALID;
+    std::memcpy(T_inv, tmp, sizeof(tmp));
     return MVO_OK;
 }
 

@@ -23,7 +23,8 @@ public:
             {"lowe_method_dist_ratio", "0.8"}, {"method_3_feature_dist_threshold", "50.0"},
             {"kpts_uniform_selection_grid_size", "16"}, {"kpts_uniform_selection_max_pts_per_grid", "8"},
             {"is_enable_ba", "true"}, {"num_prev_frames_to_opti_by_ba", "5"}, {"information_matrix", "1.0 0.0 0.0 1.0"},
-            {"is_ba_fix_map_points", "true"}};
+            {"is_ba_fix_map_points", "true"}, {"feature_match_method_index_pnp", "1"},
+            {"max_matching_pixel_dist_in_pnp", "50"}, {"max_possible_dist_to_prev_keyframe", "0.3"}};
         return t;
     }
     static void set(const string& key, const string& value) { table()[key] = value; }

@@ -16,11 +16,13 @@
 
 typedef unsigned char uchar;
 #define CV_8U 0
+#define CV_32S 4
 #define CV_64F 6
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn)-1) << 3))
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
 #define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 #define CV_8UC4 CV_MAKETYPE(CV_8U, 4)
+#define CV_32SC1 CV_MAKETYPE(CV_32S, 1)
 #define CV_64FC1 CV_MAKETYPE(CV_64F, 1)
 
 namespace cv {
@@ -93,7 +95,7 @@ public:
     int type() const { return type_; }
     int depth() const { return type_ & 7; }
     int channels() const { return (type_ >> 3) + 1; }
-    size_t elemSize() const { return (size_t)channels() * (depth() == CV_64F ? 8 : 1); }
+    size_t elemSize() const { return (size_t)channels() * (depth() == CV_64F ? 8 : depth() == CV_32S ? 4 : 1); }
     bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
     bool isContinuous() const { return step == (size_t)cols * elemSize(); }
     template <class T>

@@ -55,3 +55,83 @@ def test_cpp_dropin_matches_oracle(mvo, O, tmp_path):
     # pose-only BA pulled the perturbed poses back to the truth (x = 0.05 f, y = z = 0) within the pixel noise
     assert np.abs(P1[:, :3, 3] - np.array([[0, 0, 0], [0.05, 0, 0], [0.10, 0, 0]])).max() < 2e-3
     assert np.isfinite(P2).all() and np.isfinite(X2).all() and len(X2) == 150
+
+
+TRACK_BIN = os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "tests", "test_tracking")
+
+
+def test_tracking_binary_is_built_and_links_only_the_hip_library():
+    assert os.path.exists(TRACK_BIN), "run __graft_entry__.build()"
+    ldd = subprocess.run(["ldd", TRACK_BIN], capture_output=True, text=True).stdout
+    assert "libmvo_hip.so" in ldd and "liboracle" not in ldd and "opencv" not in ldd.lower()
+
+
+@pytest.mark.gpu
+def test_cpp_tracking_mirror_matches_oracle(mvo, O, tmp_path):
+    """my_slam/vo/pnp_tracking.h run as vo.cpp:270-383 runs: same candidates, matches, inliers, pose, bookkeeping."""
+    pr = mvo.synth.tracking_problem(n_map=2500, seed=41, outlier_frac=0.0)
+    K, M = pr["K"], len(pr["map_pos"])
+    rng = np.random.RandomState(9)
+    vis, px_true = O.map_in_view(pr["map_pos"], pr["T_w_c"], K, pr["cols"], pr["rows"])
+    seen = rng.permutation(len(vis))[: int(0.7 * len(vis))]
+    bits = np.unpackbits(pr["map_desc"][vis[seen]], axis=1)
+    bits ^= (rng.uniform(size=bits.shape) < 0.03).astype(np.uint8)
+    desc = np.concatenate([np.packbits(bits, axis=1), rng.randint(0, 256, (300, 32)).astype(np.uint8)])
+    xy = np.concatenate([px_true[seen] + rng.normal(0, 0.3, (len(seen), 2)).astype(np.float32),
+                         rng.uniform(0, 480, (300, 2)).astype(np.float32)]).astype(np.float32)
+    # the frame's pose guess: a few millimetres / milliradians off, like the previous frame's pose
+    T_guess = pr["T_w_c"].copy()
+    T_guess[:3, 3] += [0.004, -0.003, 0.005]
+    T_prev = pr["T_w_c"].copy()
+    T_prev[:3, 3] += [0.02, 0.0, -0.01]
+    scene, out = tmp_path / "scene.bin", tmp_path / "out.bin"
+    with open(scene, "wb") as f:
+        f.write(np.array([M, len(xy), pr["cols"], pr["rows"]], "<i4").tobytes())
+        f.write(np.array([K["fx"], K["fy"], K["cx"], K["cy"]], "<f8").tobytes())
+        f.write(np.ascontiguousarray(T_guess, "<f8").tobytes())
+        f.write(np.ascontiguousarray(T_prev, "<f8").tobytes())
+        f.write(pr["map_pos"].astype("<f4").tobytes())
+        f.write(pr["map_desc"].tobytes())
+        f.write(xy.tobytes())
+        f.write(desc.tobytes())
+    r = subprocess.run([TRACK_BIN, str(scene), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(out, "rb") as f:
+        order = _read(f, "<i4")                      # iteration order of the unordered_map (ids)
+        ids = _read(f, "<i4")
+        px = _read(f, "<f4").reshape(-1, 2)
+        cdesc = _read(f, np.uint8).reshape(-1, 32)
+        good = int(_read(f, "<i4")[0])
+        matches = _read(f, O.DMATCH_DTYPE)
+        T_out = _read(f, "<f8").reshape(4, 4)
+        conn = _read(f, "<i4").reshape(-1, 2)
+        times = _read(f, "<i4").reshape(-1, 2)
+        R5 = _read(f, "<f8").reshape(3, 3)
+        t5 = _read(f, "<f8")
+    assert sorted(order.tolist()) == list(range(M))
+    # -- getMappointsInCurrentView_: the oracle on the map in the adapter's order
+    idx_o, px_o = O.map_in_view(pr["map_pos"][order], T_guess, K, pr["cols"], pr["rows"])
+    assert np.array_equal(ids, order[idx_o]) and np.array_equal(px, px_o)
+    assert np.array_equal(cdesc, pr["map_desc"][ids])
+    # -- matchFeatures (method 1) + the 3D-2D pairs + solvePnPRansac
+    m_o = O.match_features(pr["map_desc"][ids], desc, 1, 2.0, 1.0)
+    p3 = pr["map_pos"][ids[m_o["queryIdx"]]]
+    p2 = xy[m_o["trainIdx"]]
+    ref = O.solve_pnp_ransac(p3, p2, K)
+    assert ref["ok"] and good == 1
+    assert_struct_equal(matches, m_o[ref["inliers"]], "curr_->matches_with_map_ after the inlier swap")
+    T_c_w = np.eye(4)
+    T_c_w[:3, :3] = O.rodrigues(ref["rvec"])
+    T_c_w[:3, 3] = ref["tvec"]
+    assert np.abs(T_out - np.linalg.inv(T_c_w)).max() < 1e-8
+    assert np.abs(T_out - pr["T_w_c"]).max() < 2e-3
+    want_conn = {int(m["trainIdx"]): int(ids[m["queryIdx"]]) for m in m_o[ref["inliers"]]}
+    assert {int(a): int(b) for a, b in conn} == want_conn
+    vis_times = np.ones(M, int)
+    vis_times[ids] += 1
+    mt = np.ones(M, int)
+    np.add.at(mt, ids[m_o["queryIdx"]][ref["inliers"]], 1)
+    assert np.array_equal(times[:, 0], vis_times) and np.array_equal(times[:, 1], mt)
+    # -- the literal cv::solvePnPRansac / cv::Rodrigues call on 5 pairs
+    five = O.solve_pnp_ransac(pr["map_pos"][ids[:5]], px[:5], K)
+    assert np.abs(R5 - O.rodrigues(five["rvec"])).max() < 1e-12 and np.abs(t5 - five["tvec"]).max() < 1e-12
