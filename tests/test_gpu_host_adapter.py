@@ -128,7 +128,7 @@ def test_cpp_tracking_mirror_matches_oracle(mvo, O, tmp_path):
     want_conn = {int(m["trainIdx"]): int(ids[m["queryIdx"]]) for m in m_o[ref["inliers"]]}
     assert {int(a): int(b) for a, b in conn} == want_conn
     vis_times = np.ones(M, int)
-    vis_times[ids] += 1
+    vis_times[ids] += 2                            # the program looks at the view twice (alone, then inside PnP)
     mt = np.ones(M, int)
     np.add.at(mt, ids[m_o["queryIdx"]][ref["inliers"]], 1)
     assert np.array_equal(times[:, 0], vis_times) and np.array_equal(times[:, 1], mt)
