@@ -3,13 +3,16 @@
 // cv::solvePnPRansac as the reference calls it (src/vo/vo.cpp:318-329): one wave per RANSAC hypothesis (5-point
 // EPnP + scoring of all pairs) and one wave for the final DLT + Levenberg-Marquardt refinement on the inliers.
 //
-// Style: SPMD with the lane loop spelled out.  Code outside PW_LANES is wave-uniform (every lane computes the same
-// values in registers); PW_LANES(l) { ... } is the per-lane part; data crosses lanes only through the LDS struct,
-// separated by PW_SYNC().  The including translation unit defines
-//     PW_FN       function qualifier            (__device__ __forceinline__)
-//     PW_LANES(l) the lane loop                 (one trip with l = threadIdx.x)
-//     PW_SYNC()   LDS hand-over between phases  (__syncthreads(), the workgroup is one wave)
-//     PW_UNROLL   loop unrolling pragma
+// Style: SPMD with the lane loop spelled out.  Code outside PW_LANES is uniform (every lane of the workgroup
+// computes the same values in registers); PW_LANES(l, NL) { ... } is the per-lane part of a workgroup of NL lanes;
+// PW_WAVES(w, NW) { ... } is code that is uniform inside a wave but differs between the NW waves (no PW_SYNC
+// inside); data crosses lanes only through the LDS struct, separated by PW_SYNC().  The including translation
+// unit defines
+//     PW_FN           function qualifier            (__device__ __forceinline__)
+//     PW_LANES(l, NL) the lane loop                 (one trip with l = threadIdx.x; blockDim.x == NL)
+//     PW_WAVES(w, NW) the wave loop                 (one trip with w = threadIdx.x / 64)
+//     PW_SYNC()       LDS hand-over between phases  (__syncthreads())
+//     PW_UNROLL       loop unrolling pragma
 // tests/sim/pnp_wave_sim.cpp compiles the same header with an explicit 64-trip lane loop so that the kernel logic
 // can be checked bit for bit against the CPU restatement on a machine without a GPU; the library itself has no CPU path.
 //
@@ -21,15 +24,17 @@
 #include <math.h>
 #include <stdint.h>
 
-#if !defined(PW_FN) || !defined(PW_LANES) || !defined(PW_SYNC) || !defined(PW_UNROLL)
-#error "define PW_FN, PW_LANES, PW_SYNC and PW_UNROLL before including pnp_wave.h"
+#if !defined(PW_FN) || !defined(PW_LANES) || !defined(PW_WAVES) || !defined(PW_SYNC) || !defined(PW_UNROLL)
+#error "define PW_FN, PW_LANES, PW_WAVES, PW_SYNC and PW_UNROLL before including pnp_wave.h"
 #endif
 
 namespace pw {
 
-constexpr int kLanes = 64;
+constexpr int kWave = 64;
+constexpr int kHypLanes = 192;  // one hypothesis per workgroup of 3 waves: the three EPnP beta variants run side by side
+constexpr int kRefLanes = 64;   // the refinement runs on one wave
 constexpr int kModelPoints = 5;  // solvePnPRansac: SOLVEPNP_ITERATIVE -> EPnP kernel on 5 points
-constexpr int kPartStride = 65;  // per-lane partial sums in LDS, padded against bank conflicts
+constexpr int kPartStride = kRefLanes + 1;  // per-lane partial sums in LDS, padded against bank conflicts
 
 PW_FN double hypot2(double a, double b) {
     a = fabs(a);
@@ -242,34 +247,57 @@ PW_FN void rr_pair(int n, int r, int k, int* i, int* j) {
 }
 
 struct JacobiLds {
-    double cs[12];  // (c, s) per pair
+    double dots[18];  // per pair: |Ai|^2, |Aj|^2, Ai.Aj
+    double cs[12];    // (c, s) per pair
     double W[12];
     int rot[6];
     int perm[12];
     int changed;
 };
 
-template <int N>
+template <int N, int NL>
 PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
-    PW_LANES(l) {
-        for (int e = l; e < N * N; e += kLanes) Vt[e] = (e / N == e % N) ? 1.0 : 0.0;
+    PW_LANES(l, NL) {
+        for (int e = l; e < N * N; e += NL) Vt[e] = (e / N == e % N) ? 1.0 : 0.0;
     }
     PW_SYNC();
     const int max_iter = 30;
     for (int it = 0; it < max_iter; it++) {
-        PW_LANES(l) {
+        PW_LANES(l, NL) {
             if (l == 0) js.changed = 0;
         }
         PW_SYNC();
         for (int r = 0; r < N - 1; r++) {
-            PW_LANES(l) {
+            // three inner products per pair (|Ai|^2, |Aj|^2, Ai.Aj): one lane each when the workgroup has several
+            // waves to hide the extra hand-over, one lane per pair (the three chains interleave) on a single wave
+            if (NL > kWave) {
+                PW_LANES(l, NL) {
+                    if (l < 3 * (N / 2)) {
+                        int i, j;
+                        rr_pair(N, r, l / 3, &i, &j);
+                        const double* x = At + N * (l % 3 == 1 ? j : i);
+                        const double* y = At + N * (l % 3 == 0 ? i : j);
+                        double d = 0;
+                        for (int k = 0; k < N; k++) d += x[k] * y[k];
+                        js.dots[l] = d;
+                    }
+                }
+                PW_SYNC();
+            }
+            PW_LANES(l, NL) {
                 if (l < N / 2) {
-                    int i, j;
-                    rr_pair(N, r, l, &i, &j);
                     double a = 0, b = 0, p = 0, c = 1, s = 0;
-                    for (int k = 0; k < N; k++) a += At[i * N + k] * At[i * N + k];
-                    for (int k = 0; k < N; k++) b += At[j * N + k] * At[j * N + k];
-                    for (int k = 0; k < N; k++) p += At[i * N + k] * At[j * N + k];
+                    if (NL > kWave) {
+                        a = js.dots[3 * l];
+                        b = js.dots[3 * l + 1];
+                        p = js.dots[3 * l + 2];
+                    } else {
+                        int i, j;
+                        rr_pair(N, r, l, &i, &j);
+                        for (int k = 0; k < N; k++) a += At[i * N + k] * At[i * N + k];
+                        for (int k = 0; k < N; k++) b += At[j * N + k] * At[j * N + k];
+                        for (int k = 0; k < N; k++) p += At[i * N + k] * At[j * N + k];
+                    }
                     const bool rot = jacobi_cs(a, b, p, &c, &s);
                     js.cs[2 * l] = c;
                     js.cs[2 * l + 1] = s;
@@ -278,8 +306,8 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
                 }
             }
             PW_SYNC();
-            PW_LANES(l) {
-                for (int e = l; e < N * N; e += kLanes) {  // (pair, At|Vt, column)
+            PW_LANES(l, NL) {
+                for (int e = l; e < N * N; e += NL) {  // (pair, At|Vt, column)
                     const int k = e / (2 * N), rem = e % (2 * N), col = rem % N;
                     double* arr = rem >= N ? Vt : At;
                     if (js.rot[k]) {
@@ -298,7 +326,7 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
         PW_SYNC();
         if (!changed) break;
     }
-    PW_LANES(l) {
+    PW_LANES(l, NL) {
         if (l < N) {
             double sd = 0;
             for (int k = 0; k < N; k++) sd += At[l * N + k] * At[l * N + k];
@@ -306,7 +334,7 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
         }
     }
     PW_SYNC();
-    PW_LANES(l) {
+    PW_LANES(l, NL) {
         if (l < N) {
             int src = l;
             for (int i = 0; i < N; i++) {
@@ -334,8 +362,11 @@ struct HypLds {
     double alphas[kModelPoints * 4];
     double us[kModelPoints * 2];
     double l6x10[60];
+    double var_err[3];  // per beta variant: mean reprojection error, R, t
+    double var_R[3][9];
+    double var_t[3][3];
     JacobiLds js;
-    int cnt[kLanes];
+    int cnt[kHypLanes];
 };
 
 PW_FN double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -654,8 +685,8 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
         s.us[2 * i + 1] = e.us[i][1];
     }
     PW_SYNC();
-    PW_LANES(l) {
-        for (int el = l; el < 2 * n * 12; el += kLanes) {
+    PW_LANES(l, kHypLanes) {
+        for (int el = l; el < 2 * n * 12; el += kHypLanes) {
             const int r = el / 12, c = el % 12, i = r / 2, k = c / 3, comp = c % 3;
             const double a = s.alphas[4 * i + k];
             double val;
@@ -667,8 +698,8 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
         }
     }
     PW_SYNC();
-    PW_LANES(l) {
-        for (int el = l; el < 144; el += kLanes) {
+    PW_LANES(l, kHypLanes) {
+        for (int el = l; el < 144; el += kHypLanes) {
             const int a = el / 12, b = el % 12;
             double sum = 0;
             for (int r = 0; r < 2 * n; r++) sum += s.M[r * 12 + a] * s.M[r * 12 + b];
@@ -676,9 +707,9 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
         }
     }
     PW_SYNC();
-    jacobi_rr<12>(s.At, s.Vt, s.js);
+    jacobi_rr<12, kHypLanes>(s.At, s.Vt, s.js);
     // compute_L_6x10 from the four eigenvectors of the smallest eigenvalues
-    PW_LANES(l) {
+    PW_LANES(l, kHypLanes) {
         if (l < 60) {
             const int i = l / 10, c = l % 10;
             const int xs[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3}, ys[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
@@ -713,22 +744,32 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
     rho[3] = dist2(e.cws[1], e.cws[2]);
     rho[4] = dist2(e.cws[1], e.cws[3]);
     rho[5] = dist2(e.cws[2], e.cws[3]);
-    double best_err = 0;
-    for (int variant = 1; variant <= 3; variant++) {
-        double betas[4], R[3][3], t[3];
-        find_betas(l6, rho, variant, betas);
-        gauss_newton(l6, rho, betas);
-        const double err = compute_R_and_t(e, cam, v, betas, R, t);
-        // N = 1; if (rep[2] < rep[1]) N = 2; if (rep[3] < rep[N]) N = 3
-        if (variant == 1 || err < best_err) {
-            best_err = err;
+    // the three beta initialisations (epnp::find_betas_approx_1/2/3 + Gauss-Newton + compute_R_and_t) are
+    // independent: wave w takes variant w + 1
+    PW_WAVES(w, kHypLanes / kWave) {
+        for (int variant = 1 + w; variant <= 3; variant += kHypLanes / kWave) {
+            double betas[4], R[3][3], t[3];
+            find_betas(l6, rho, variant, betas);
+            gauss_newton(l6, rho, betas);
+            s.var_err[variant - 1] = compute_R_and_t(e, cam, v, betas, R, t);
             PW_UNROLL
             for (int i = 0; i < 3; i++) {
                 PW_UNROLL
-                for (int j = 0; j < 3; j++) Rout[i][j] = R[i][j];
-                tout[i] = t[i];
+                for (int j = 0; j < 3; j++) s.var_R[variant - 1][3 * i + j] = R[i][j];
+                s.var_t[variant - 1][i] = t[i];
             }
         }
+    }
+    PW_SYNC();
+    // N = 1; if (rep_errors[2] < rep_errors[1]) N = 2; if (rep_errors[3] < rep_errors[N]) N = 3;
+    int N = 0;
+    if (s.var_err[1] < s.var_err[0]) N = 1;
+    if (s.var_err[2] < s.var_err[N]) N = 2;
+    PW_UNROLL
+    for (int i = 0; i < 3; i++) {
+        PW_UNROLL
+        for (int j = 0; j < 3; j++) Rout[i][j] = s.var_R[N][3 * i + j];
+        tout[i] = s.var_t[N][i];
     }
     PW_SYNC();
 }
@@ -737,9 +778,9 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
 // reprojection error (float, as cv::projectPoints / norm(NORM_L2SQR) produce it) is <= thr2.  Returns the count.
 PW_FN int score_model(HypLds& s, const float* p3, const float* p2, int n, const Camera& cam, const double (&R)[3][3],
                       const double (&t)[3], float thr2, uint8_t* mask) {
-    PW_LANES(l) {
+    PW_LANES(l, kHypLanes) {
         int good = 0;
-        for (int i = l; i < n; i += kLanes) {
+        for (int i = l; i < n; i += kHypLanes) {
             const double X = p3[3 * i], Y = p3[3 * i + 1], Z = p3[3 * i + 2];
             double x = R[0][0] * X + R[0][1] * Y + R[0][2] * Z + t[0];
             double y = R[1][0] * X + R[1][1] * Y + R[1][2] * Z + t[1];
@@ -760,7 +801,7 @@ PW_FN int score_model(HypLds& s, const float* p3, const float* p2, int n, const 
     }
     PW_SYNC();
     int total = 0;
-    for (int q = 0; q < kLanes; q++) total += s.cnt[q];
+    for (int q = 0; q < kHypLanes; q++) total += s.cnt[q];
     PW_SYNC();
     return total;
 }
@@ -773,8 +814,8 @@ struct RefLds {
     double At[144];
     double Vt[144];
     JacobiLds js;
-    int cnt[kLanes];
-    int offs[kLanes + 1];
+    int cnt[kRefLanes];
+    int offs[kRefLanes + 1];
 };
 
 PW_FN void rodrigues_fwd(const double (&r)[3], double (&R)[9], double (&J)[27], bool want_j) {
@@ -853,10 +894,10 @@ PW_FN void rodrigues_inv(const double (&Rin)[3][3], double (&r)[3]) {
 // Sum over lanes of NV per-lane values already stored at part[v * kPartStride + lane] -> red[v].
 PW_FN void reduce_parts(RefLds& s, int nv) {
     PW_SYNC();
-    PW_LANES(l) {
-        for (int v = l; v < nv; v += kLanes) {
+    PW_LANES(l, kRefLanes) {
+        for (int v = l; v < nv; v += kRefLanes) {
             double sum = 0;
-            for (int q = 0; q < kLanes; q++) sum += s.part[v * kPartStride + q];
+            for (int q = 0; q < kRefLanes; q++) sum += s.part[v * kPartStride + q];
             s.red[v] = sum;
         }
     }
@@ -870,10 +911,10 @@ PW_FN void lm_evaluate(RefLds& s, const double* Mg, const double* mg, int cnt, c
     double R[9], dRdr[27];
     const double rv[3] = {param[0], param[1], param[2]};
     rodrigues_fwd(rv, R, dRdr, with_j);
-    PW_LANES(l) {
+    PW_LANES(l, kRefLanes) {
         double acc[28];
         for (int k = 0; k < 28; k++) acc[k] = 0;
-        for (int i = l; i < cnt; i += kLanes) {
+        for (int i = l; i < cnt; i += kRefLanes) {
             const double X = Mg[3 * i], Y = Mg[3 * i + 1], Z = Mg[3 * i + 2];
             double x = R[0] * X + R[1] * Y + R[2] * Z + param[3];
             double y = R[3] * X + R[4] * Y + R[5] * Z + param[4];
@@ -936,7 +977,7 @@ PW_FN void lm_step(RefLds& s, const double (&JtJ)[21], const double (&JtErr)[6],
             }
     }
     PW_SYNC();
-    jacobi_rr<6>(s.At, s.Vt, s.js);
+    jacobi_rr<6, kRefLanes>(s.At, s.Vt, s.js);
     double W[6], thr = 0, x[6] = {0, 0, 0, 0, 0, 0};
     for (int p = 0; p < 6; p++) {
         W[p] = s.js.W[s.js.perm[p]];
@@ -987,28 +1028,28 @@ PW_FN void refine_pose(RefLds& s, const float* p3, const float* p2, const uint8_
         return;
     }
     // ordered compaction of the inliers: lane l owns the contiguous block [l * blk, (l + 1) * blk)
-    const int blk = (n + kLanes - 1) / kLanes;
-    PW_LANES(l) {
+    const int blk = (n + kRefLanes - 1) / kRefLanes;
+    PW_LANES(l, kRefLanes) {
         int c = 0;
         const int lo = l * blk, hi = (lo + blk) < n ? (lo + blk) : n;
         for (int i = lo; i < hi; i++) c += mask[i] != 0;
         s.cnt[l] = c;
     }
     PW_SYNC();
-    PW_LANES(l) {
+    PW_LANES(l, kRefLanes) {
         if (l == 0) {
             int run = 0;
-            for (int q = 0; q < kLanes; q++) {
+            for (int q = 0; q < kRefLanes; q++) {
                 s.offs[q] = run;
                 run += s.cnt[q];
             }
-            s.offs[kLanes] = run;
+            s.offs[kRefLanes] = run;
         }
     }
     PW_SYNC();
-    const int cnt = s.offs[kLanes];
+    const int cnt = s.offs[kRefLanes];
     out.n_inliers = cnt;
-    PW_LANES(l) {
+    PW_LANES(l, kRefLanes) {
         int o = s.offs[l];
         const int lo = l * blk, hi = (lo + blk) < n ? (lo + blk) : n;
         for (int i = lo; i < hi; i++)
@@ -1023,18 +1064,18 @@ PW_FN void refine_pose(RefLds& s, const float* p3, const float* p2, const uint8_
     }
     PW_SYNC();
     // planarity test: singular values of the centred second-moment matrix of the object points
-    PW_LANES(l) {
+    PW_LANES(l, kRefLanes) {
         double a[3] = {0, 0, 0};
-        for (int i = l; i < cnt; i += kLanes)
+        for (int i = l; i < cnt; i += kRefLanes)
             for (int j = 0; j < 3; j++) a[j] += Mg[3 * i + j];
         for (int j = 0; j < 3; j++) s.part[j * kPartStride + l] = a[j];
     }
     reduce_parts(s, 3);
     double Mc[3];
     for (int j = 0; j < 3; j++) Mc[j] = s.red[j] / cnt;
-    PW_LANES(l) {
+    PW_LANES(l, kRefLanes) {
         double a[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = l; i < cnt; i += kLanes) {
+        for (int i = l; i < cnt; i += kRefLanes) {
             const double d0 = Mg[3 * i] - Mc[0], d1 = Mg[3 * i + 1] - Mc[1], d2 = Mg[3 * i + 2] - Mc[2];
             a[0] += d0 * d0;
             a[1] += d0 * d1;
@@ -1063,10 +1104,10 @@ PW_FN void refine_pose(RefLds& s, const float* p3, const float* p2, const uint8_
         out.used_dlt = 1;
         const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
         // L^T L (12 x 12, 78 unique sums over the 2 cnt rows of the DLT system)
-        PW_LANES(l) {
+        PW_LANES(l, kRefLanes) {
             double acc[78];
             for (int k = 0; k < 78; k++) acc[k] = 0;
-            for (int i = l; i < cnt; i += kLanes) {
+            for (int i = l; i < cnt; i += kRefLanes) {
                 const double x = -((mg[2 * i] - cam.uc) * ifx), y = -((mg[2 * i + 1] - cam.vc) * ify);
                 const double X = Mg[3 * i], Y = Mg[3 * i + 1], Z = Mg[3 * i + 2];
                 const double l0[12] = {X, Y, Z, 1., 0., 0., 0., 0., x * X, x * Y, x * Z, x};
@@ -1081,14 +1122,14 @@ PW_FN void refine_pose(RefLds& s, const float* p3, const float* p2, const uint8_
             for (int k = 0; k < 78; k++) s.part[k * kPartStride + l] = acc[k];
         }
         reduce_parts(s, 78);
-        PW_LANES(l) {
-            for (int el = l; el < 144; el += kLanes) {
+        PW_LANES(l, kRefLanes) {
+            for (int el = l; el < 144; el += kRefLanes) {
                 const int a = el / 12, b = el % 12, lo = a < b ? a : b, hi = a < b ? b : a;
                 s.At[el] = s.red[lo * 12 - lo * (lo - 1) / 2 + (hi - lo)];
             }
         }
         PW_SYNC();
-        jacobi_rr<12>(s.At, s.Vt, s.js);
+        jacobi_rr<12, kRefLanes>(s.At, s.Vt, s.js);
         const double* v = s.Vt + 12 * s.js.perm[11];
         double RR[3][3], tt[3];
         for (int i = 0; i < 3; i++) {

@@ -1,14 +1,15 @@
 // csrc/track_kernels.hip -- tracking rows between the matcher and bundle adjustment:
 //   k_map_in_view      VisualOdometry::getMappointsInCurrentView_ (src/vo/vo.cpp:16-49): project the resident map,
 //                      keep what is in front of the camera and inside the image, gather the descriptors.
-//   k_pnp_hypotheses   the RANSAC loop of cv::solvePnPRansac (vo.cpp:326-329): one wave per hypothesis runs the
-//                      5-point EPnP kernel and scores every 3D-2D pair.
+//   k_pnp_hypotheses   the RANSAC loop of cv::solvePnPRansac (vo.cpp:326-329): one workgroup of three waves per
+//                      hypothesis runs the 5-point EPnP kernel (one wave per beta variant) and scores every pair.
 //   k_pnp_refine       the final cv::solvePnP(SOLVEPNP_ITERATIVE) on the inliers: DLT start + Levenberg-Marquardt.
 // The arithmetic lives in pnp_wave.h (wave-level SPMD code); this file binds it to threads and LDS.
 #include "mvo_internal.h"
 
 #define PW_FN __device__ __forceinline__
-#define PW_LANES(l) for (int l = (int)threadIdx.x, pw_once_ = 1; pw_once_; pw_once_ = 0)
+#define PW_LANES(l, NL) for (int l = (int)threadIdx.x, pw_once_ = 1; pw_once_; pw_once_ = 0)
+#define PW_WAVES(w, NW) for (int w = (int)(threadIdx.x >> 6), pw_once_ = 1; pw_once_; pw_once_ = 0)
 #define PW_SYNC() __syncthreads()
 #define PW_UNROLL _Pragma("unroll")
 #include "pnp_wave.h"
@@ -78,7 +79,7 @@ int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_
 }
 
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
-__global__ __launch_bounds__(64) void k_pnp_hypotheses(const float* __restrict__ p3, const float* __restrict__ p2, int n,
+__global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* __restrict__ p3, const float* __restrict__ p2, int n,
                                                         const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
                                                         double* __restrict__ models, int32_t* __restrict__ counts,
                                                         uint8_t* __restrict__ masks) {
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(64) void k_pnp_hypotheses(const float* __restrict__
 }
 
 // out: param[6] = (rvec, tvec), then n_inliers, dlt used, LM iterations, LM evaluations (as doubles).
-__global__ __launch_bounds__(64) void k_pnp_refine(const float* __restrict__ p3, const float* __restrict__ p2,
+__global__ __launch_bounds__(pw::kRefLanes) void k_pnp_refine(const float* __restrict__ p3, const float* __restrict__ p2,
                                                     const uint8_t* __restrict__ mask, int n, TrackCamera cam,
                                                     const double* __restrict__ model, int mode, double* Mg, double* mg,
                                                     double* __restrict__ out) {
@@ -130,7 +131,7 @@ int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_
                                 int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
                                 uint8_t* d_masks) {
     ProfScope ps(ctx, "k_pnp_hypotheses");
-    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(n_hyp), dim3(64), 0, ctx->stream, d_p3, d_p2, n, d_subsets, cam, thr2,
+    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(n_hyp), dim3(pw::kHypLanes), 0, ctx->stream, d_p3, d_p2, n, d_subsets, cam, thr2,
                        d_models, d_counts, d_masks);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
@@ -140,7 +141,7 @@ int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, 
                             const TrackCamera& cam, const double* d_model, int mode, double* d_Mg, double* d_mg,
                             double* d_out) {
     ProfScope ps(ctx, "k_pnp_refine");
-    hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(64), 0, ctx->stream, d_p3, d_p2, d_mask, n, cam, d_model, mode, d_Mg,
+    hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(pw::kRefLanes), 0, ctx->stream, d_p3, d_p2, d_mask, n, cam, d_model, mode, d_Mg,
                        d_mg, d_out);
     MVO_HIP(hipGetLastError());
     return MVO_OK;

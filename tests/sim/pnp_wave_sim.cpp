@@ -1,5 +1,5 @@
 // tests/sim/pnp_wave_sim.cpp -- TEST AID: compiles the PnP kernel source (csrc/pnp_wave.h) for the host with the
-// 64-lane loop made explicit, so that the kernel logic can be compared bit for bit with the oracle where no GPU
+// lane and wave loops made explicit, so that the kernel logic can be compared bit for bit with the oracle where no GPU
 // exists (pytest -m "not gpu").  Built by tests/test_pnp_wave_sim.py into tests/sim/_build/; never part of
 // libmvo_hip.so -- the library has no CPU path.
 #include <stdint.h>
@@ -8,7 +8,8 @@
 #include <vector>
 
 #define PW_FN static inline
-#define PW_LANES(l) for (int l = 0; l < 64; ++l)
+#define PW_LANES(l, NL) for (int l = 0; l < (NL); ++l)
+#define PW_WAVES(w, NW) for (int w = 0; w < (NW); ++w)
 #define PW_SYNC() ((void)0)
 #define PW_UNROLL
 #include "../../monocular-visual-odometry_amd/csrc/pnp_wave.h"
