@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=12, help="sequence shards in flight per GPU")
     ap.add_argument("--ba", default="full", choices=["full", "full_fix0", "pose_only"],
                     help="full = points + poses free (reference is_fix_map_pts=false branch, no vertex fixed)")
+    ap.add_argument("--track", action="store_true",
+                    help="also run the tracking rows every frame (map points in view -> match against the map -> "
+                         "solvePnPRansac, vo.cpp:270-357); off by default: BASELINE.json's metric is extract+match+BA")
     ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150)
@@ -85,6 +88,13 @@ class Shard:
                         pb["cx"], pb["cy"])
         self.ba_kw = ba_kwargs(args.ba, args.ba_poses)
         self.ba = self.ctx.ba_prepare(*self.ba_args, **self.ba_kw)
+        self.track = None
+        if args.track:            # a resident map + the 3D-2D pairs PnP sees
+            tp = mvo.synth.tracking_problem(n_map=3000, seed=11 + shard_id, width=args.width, height=args.height, K=K)
+            self.track = tp
+            self.map = self.ctx.map_create()
+            self.ctx.map_upload(self.map, tp["map_pos"], tp["map_desc"])
+            self.n_inliers = 0
         self.prev = None          # (device ptr, n) of the previous frame's descriptors
         self.traj = []
         self.n_kp = self.n_match = 0
@@ -101,6 +111,13 @@ class Shard:
             m = ctx.match_features_dev(self.prev[0], self.prev[1], dptr, len(k), 2, 2.0, 0.8)
             self.n_match = len(m)
         self.prev = (dptr, len(k))
+        if self.track is not None:
+            tp = self.track
+            idx, _, d_map = ctx.map_points_in_view(self.map, tp["T_w_c"], tp["K"], a.width, a.height, cap=len(tp["map_pos"]))
+            if len(idx) and len(k):
+                ctx.match_features_dev(d_map, len(idx), dptr, len(k), 1, 2.0, 1.0)
+            pose = ctx.solve_pnp_ransac(tp["pts3d"], tp["pts2d"], tp["K"])
+            self.n_inliers = len(pose["inliers"])
         ctx.ba_solve_resident(self.ba)
         P, _, st = ctx.ba_fetch(self.ba, want_points=False)
         self.n_kp = len(k)
@@ -287,7 +304,9 @@ def main():
                                                           len(s0.pb["edge_pose"])),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
                        "keypoints": s0.n_kp, "matches": s0.n_match,
-                       "ba_trials_per_solve": trials0 / nprof},
+                       "ba_trials_per_solve": trials0 / nprof,
+                       "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers)"
+                                         % (len(s0.track["pts3d"]), s0.n_inliers)) if args.track else "off"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_baseline_all_threads": cpu_mt,
