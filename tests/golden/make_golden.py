@@ -44,6 +44,16 @@ def main():
                         intr=np.array([pb["focal"], pb["cx"], pb["cy"]]), pose_only_poses=P1,
                         pose_only_chi2=np.array([st1["chi2_initial"], st1["chi2_final"]]), full3_poses=P2,
                         full3_points=X2, full3_chi2=np.array([st2["chi2_initial"], st2["chi2_final"]]))
+    # ---- tracking rows: 300 map points, ~100 3D-2D pairs with 30 % wrong matches, 40 RANSAC iterations
+    tp = S.tracking_problem(n_map=300, seed=99, outlier_frac=0.3)
+    k4 = np.array([tp["K"][k] for k in ("fx", "fy", "cx", "cy")])
+    vis_idx, vis_px = O.map_in_view(tp["map_pos"], tp["T_w_c"], tp["K"], tp["cols"], tp["rows"])
+    res = O.solve_pnp_ransac(tp["pts3d"], tp["pts2d"], tp["K"], iters=40)
+    np.savez_compressed(os.path.join(HERE, "track_300.npz"), map_pos=tp["map_pos"], map_desc=tp["map_desc"],
+                        T_w_c=tp["T_w_c"], K4=k4, size=np.array([tp["cols"], tp["rows"]]), view_idx=vis_idx,
+                        view_px=vis_px, pts3d=tp["pts3d"], pts2d=tp["pts2d"], subsets=O.pnp_subsets(len(tp["pts3d"]), 40),
+                        models=res["models"], counts=res["counts"], best_iter=res["best_iter"], iters_run=res["iters_run"],
+                        inliers=res["inliers"], rvec=res["rvec"], tvec=res["tvec"])
     print("golden fixtures written to", HERE)
 
 

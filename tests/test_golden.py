@@ -38,6 +38,44 @@ def test_oracle_reproduces_match_and_ba_golden(O):
     assert np.abs(P2 - b["full3_poses"]).max() < 1e-12 and np.abs(X2 - b["full3_points"]).max() < 1e-12
 
 
+def _track_K(t):
+    return dict(fx=t["K4"][0], fy=t["K4"][1], cx=t["K4"][2], cy=t["K4"][3])
+
+
+def test_oracle_reproduces_tracking_golden(O):
+    t = _load("track_300.npz")
+    K = _track_K(t)
+    idx, px = O.map_in_view(t["map_pos"], t["T_w_c"], K, int(t["size"][0]), int(t["size"][1]))
+    assert np.array_equal(idx, t["view_idx"]) and np.array_equal(px, t["view_px"])
+    assert np.array_equal(O.pnp_subsets(len(t["pts3d"]), 40), t["subsets"])
+    res = O.solve_pnp_ransac(t["pts3d"], t["pts2d"], K, iters=40)
+    run = int(t["iters_run"])
+    assert res["best_iter"] == int(t["best_iter"]) and res["iters_run"] == run
+    assert np.array_equal(res["counts"], t["counts"]) and np.array_equal(res["inliers"], t["inliers"])
+    assert np.array_equal(res["models"][:run], t["models"][:run], equal_nan=True)
+    assert np.abs(res["rvec"] - t["rvec"]).max() < 1e-13 and np.abs(res["tvec"] - t["tvec"]).max() < 1e-13
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_tracking_golden(mvo, ctx):
+    t = _load("track_300.npz")
+    K = _track_K(t)
+    m = ctx.map_create()
+    try:
+        ctx.map_upload(m, t["map_pos"], t["map_desc"])
+        idx, px, _ = ctx.map_points_in_view(m, t["T_w_c"], K, int(t["size"][0]), int(t["size"][1]), cap=len(t["map_pos"]))
+    finally:
+        ctx.map_release(m)
+    assert np.array_equal(idx, t["view_idx"]) and np.array_equal(px, t["view_px"])
+    res = ctx.solve_pnp_ransac(t["pts3d"], t["pts2d"], K, iterations=40)
+    dbg = ctx.debug_pnp()
+    run = int(t["iters_run"])
+    assert res["ok"] and dbg["best_iter"] == int(t["best_iter"]) and dbg["iters_run"] == run
+    assert np.array_equal(dbg["counts"][:run], t["counts"][:run]) and np.array_equal(res["inliers"], t["inliers"])
+    assert np.array_equal(dbg["models"][:run], t["models"][:run], equal_nan=True)
+    assert np.abs(res["rvec"] - t["rvec"]).max() < 1e-8 and np.abs(res["tvec"] - t["tvec"]).max() < 1e-8
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_golden(mvo, ctx):
     g = _load("orb_176x144.npz")

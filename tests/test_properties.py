@@ -150,3 +150,71 @@ def test_ba_properties_full_size(mvo, ctx):
     # full BA decreases the cost further than pose-only BA
     Pf, Xf, stf = ctx.bundle_adjustment(*a, fix_points=False)
     assert stf["chi2_final"] < st["chi2_final"]
+
+
+@settings(max_examples=25, deadline=None)
+@given(n=st.integers(5, 400), iters=st.integers(1, 60), seed=st.integers(0, 10 ** 6))
+def test_pnp_subsets_invariants(n, iters, seed):
+    """getSubset: 5 distinct indices below n per iteration; the stream does not depend on how many are drawn."""
+    from conftest import graft
+    O = graft.load_oracle()
+    s = O.pnp_subsets(n, iters)
+    assert s.shape == (iters, 5) and s.min() >= 0 and s.max() < n
+    assert all(len(set(r)) == 5 for r in s.tolist())
+    assert np.array_equal(O.pnp_subsets(n, iters + 7)[:iters], s)
+
+
+@pytest.mark.gpu
+def test_tracking_properties_full_size(mvo, ctx):
+    """Size-independent properties of the tracking rows at map / pair counts the oracle is not asked to follow."""
+    import threading
+    pr = mvo.synth.tracking_problem(n_map=60000, seed=5, outlier_frac=0.3)
+    K, p3, p2 = pr["K"], pr["pts3d"], pr["pts2d"]
+    assert len(p3) > 15000
+    m = ctx.map_create()
+    try:
+        ctx.map_upload(m, pr["map_pos"], pr["map_desc"])
+        idx, px, _ = ctx.map_points_in_view(m, pr["T_w_c"], K, pr["cols"], pr["rows"], cap=len(pr["map_pos"]))
+    finally:
+        ctx.map_release(m)
+    # the view: ascending indices (map order), strictly inside the image, exactly the generator's visible set
+    assert np.all(np.diff(idx) > 0) and set(idx.tolist()) == set(pr["ids"].tolist())
+    assert (px > 0).all() and (px[:, 0] < pr["cols"]).all() and (px[:, 1] < pr["rows"]).all()
+    # PnP: inliers ascending, every one within 2 px of the BEST HYPOTHESIS' projection, none of the others is
+    res = ctx.solve_pnp_ransac(p3, p2, K)
+    dbg = ctx.debug_pnp()
+    assert res["ok"] and np.all(np.diff(res["inliers"]) > 0)
+    assert dbg["counts"][dbg["best_iter"]] == len(res["inliers"]) == dbg["counts"][:dbg["iters_run"]].max()
+    M = dbg["models"][dbg["best_iter"]]
+    q = p3.astype(np.float64) @ M[:9].reshape(3, 3).T + M[9:]
+    uv = np.stack([q[:, 0] / q[:, 2] * K["fx"] + K["cx"], q[:, 1] / q[:, 2] * K["fy"] + K["cy"]], 1)
+    e2 = ((uv - p2) ** 2).sum(1)
+    inl = np.zeros(len(p3), bool)
+    inl[res["inliers"]] = True
+    sure = np.abs(e2 - 4.0) > 1e-2
+    assert np.array_equal(inl[sure], (e2 <= 4.0)[sure])
+    assert (inl == pr["inlier_gt"]).mean() > 0.995
+    # the refined pose explains the inliers better than the hypothesis it started from
+    R = mvo.rodrigues(res["rvec"])
+    q = p3[inl].astype(np.float64) @ R.T + res["tvec"]
+    uv2 = np.stack([q[:, 0] / q[:, 2] * K["fx"] + K["cx"], q[:, 1] / q[:, 2] * K["fy"] + K["cy"]], 1)
+    assert ((uv2 - p2[inl]) ** 2).sum() <= e2[inl].sum() * (1 + 1e-9)
+    # bit-reproducible: again on this ctx, and on four other contexts running concurrently on their own streams
+    again = ctx.solve_pnp_ransac(p3, p2, K)
+    assert np.array_equal(again["inliers"], res["inliers"]) and np.array_equal(again["rvec"], res["rvec"])
+    outs = [None] * 4
+
+    def work(i):
+        c = mvo.Context(0)
+        try:
+            for _ in range(3):
+                outs[i] = c.solve_pnp_ransac(p3, p2, K)
+        finally:
+            c.close()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for o in outs:
+        assert o is not None and np.array_equal(o["inliers"], res["inliers"])
+        assert np.array_equal(o["rvec"], res["rvec"]) and np.array_equal(o["tvec"], res["tvec"])
