@@ -202,7 +202,9 @@ int mvo_profile_get(mvo_ctx* ctx, mvo_kernel_time* out, int cap);
 
 /* ---- debug / test hooks (used by tests/ to localise a parity failure; not part of the drop-in) ---- */
 /* key "ba_mfma": 1 (default) = matrix-core contractions, 0 = plain VALU loops computing the same sums;
- * key "ba_wgs": workgroups (CUs) one BA window is split over, 0 (default) = automatic. */
+ * key "ba_wgs": workgroups (CUs) one BA window is split over, 0 (default) = automatic;
+ * key "pnp_replay_skew": 1 = the device replays the RANSAC loop with a wrong confidence, so that the host's
+ * verification of the selected hypothesis has something to correct (tests only). */
 int mvo_debug_set(const char* key, int value);
 /* Shader-clock cycles the last fetched BA solve spent per phase (ids in csrc/ba_kernels.hip), and the number
  * of workgroups it ran on. */
@@ -216,7 +218,8 @@ int mvo_debug_get_candidates(mvo_ctx* ctx, void* out, int cap, int* n);
 
 /* Record of the last mvo_solve_pnp_ransac on this ctx: models (iterations x 12: R row-major, t) and inlier
  * counts of every hypothesis, info[6] = {best iteration, iterations the sequential loop would have run,
- * DLT used, LM iterations, LM residual evaluations, hypotheses evaluated}. */
+ * DLT used, LM iterations, LM residual evaluations, hypotheses evaluated (negative when the host had to correct
+ * the device's choice of hypothesis)}. */
 int mvo_debug_get_pnp(mvo_ctx* ctx, double* models, int32_t* counts, int cap, int32_t* info);
 
 #ifdef __cplusplus

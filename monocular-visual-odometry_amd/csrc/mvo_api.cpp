@@ -503,6 +503,10 @@ int mvo_debug_set(const char* key, int value) {
         g_ba_wgs = value;
         return MVO_OK;
     }
+    if (key && !std::strcmp(key, "pnp_replay_skew")) {
+        g_pnp_replay_skew = value;
+        return MVO_OK;
+    }
     return MVO_ERR_INVALID;
 }
 

@@ -167,9 +167,11 @@ int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_
 int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_p2, int n, const int32_t* d_subsets,
                                 int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
                                 uint8_t* d_masks);
-int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_mask, int n,
-                            const TrackCamera& cam, const double* d_model, int mode, double* d_Mg, double* d_mg,
-                            double* d_out);
+int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_masks, int n,
+                            const TrackCamera& cam, const double* d_models, const int32_t* d_counts, int n_hyp,
+                            double confidence, int forced_best, int mode, double* d_Mg, double* d_mg,
+                            uint8_t* d_best_mask, double* d_out);
+extern int g_pnp_replay_skew;  // test hook: the device replays the RANSAC loop with a wrong confidence
 // track_host.cpp
 void track_release(mvo_ctx* ctx);
 // ba_kernels.hip

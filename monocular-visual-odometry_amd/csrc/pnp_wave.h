@@ -807,6 +807,39 @@ PW_FN int score_model(HypLds& s, const float* p3, const float* p2, int n, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The sequential bookkeeping of RANSACPointSetRegistrator::run over the inlier counts of the hypotheses, in
+// iteration order: a hypothesis becomes the best model when its count exceeds max(best so far, modelPoints - 1),
+// and every new best shortens the loop through cv::RANSACUpdateNumIters.  Uniform.  pow / log differ in the last
+// ulp between math libraries; the host repeats this loop with its own libm on the same counts and re-runs the
+// refinement in the (never observed) case that it would have chosen differently.
+PW_FN int ransac_update_num_iters(double p, double ep, int model_points, int max_iters) {
+    p = p > 0. ? p : 0.;
+    p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.;
+    ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+PW_FN void ransac_replay(const int32_t* counts, int n_hyp, int n, double confidence, int* best, int* iters_run) {
+    int niters = n_hyp, max_good = 0, b = -1, it = 0;
+    for (; it < niters; it++) {
+        const int good = counts[it];
+        if (good > (max_good > kModelPoints - 1 ? max_good : kModelPoints - 1)) {
+            max_good = good;
+            b = it;
+            niters = ransac_update_num_iters(confidence, (double)(n - good) / n, kModelPoints, niters);
+        }
+    }
+    *best = b;
+    *iters_run = it;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Refinement: cvFindExtrinsicCameraParams2(useExtrinsicGuess = 0) on the inliers = DLT start + CvLevMarq.
 struct RefLds {
     double part[78 * kPartStride];  // per-lane partial sums

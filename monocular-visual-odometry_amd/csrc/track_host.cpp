@@ -19,6 +19,7 @@ struct mvo_track_state {
     // PnP: pairs, subsets, per-hypothesis results, refinement scratch
     float *d_p3 = nullptr, *d_p2 = nullptr;
     double *d_Mg = nullptr, *d_mg = nullptr;
+    uint8_t* d_best_mask = nullptr;
     int cap_n = 0;
     int32_t* d_subsets = nullptr;
     double* d_models = nullptr;
@@ -38,6 +39,8 @@ struct mvo_track_state {
     int32_t* d_view_n = nullptr;
     int cap_view = 0;
 };
+
+int g_pnp_replay_skew = 0;
 
 namespace {
 
@@ -59,12 +62,14 @@ int ensure_pnp(mvo_ctx* ctx, int n, int n_hyp) {
         free_dev(s->d_p2);
         free_dev(s->d_Mg);
         free_dev(s->d_mg);
+        free_dev(s->d_best_mask);
         s->cap_n = 0;
         const int cap = std::max(4096, n + n / 2);
         MVO_HIP(hipMalloc((void**)&s->d_p3, (size_t)cap * 3 * sizeof(float)));
         MVO_HIP(hipMalloc((void**)&s->d_p2, (size_t)cap * 2 * sizeof(float)));
         MVO_HIP(hipMalloc((void**)&s->d_Mg, (size_t)cap * 3 * sizeof(double)));
         MVO_HIP(hipMalloc((void**)&s->d_mg, (size_t)cap * 2 * sizeof(double)));
+        MVO_HIP(hipMalloc((void**)&s->d_best_mask, (size_t)cap));
         s->cap_n = cap;
     }
     if (n_hyp > s->cap_h) {
@@ -173,6 +178,7 @@ void track_release(mvo_ctx* ctx) {
     free_dev(s->d_p2);
     free_dev(s->d_Mg);
     free_dev(s->d_mg);
+    free_dev(s->d_best_mask);
     free_dev(s->d_subsets);
     free_dev(s->d_models);
     free_dev(s->d_counts);
@@ -330,7 +336,7 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     if (r) return r;
     // stage pairs + subsets
     const size_t b3 = (size_t)n * 12, b2 = (size_t)n * 8, bs = (size_t)n_hyp * kModel * 4;
-    if ((r = mvo_ensure_pinned(ctx, std::max(b3 + b2 + bs, (size_t)n_hyp * 100 + (size_t)n + 256)))) return r;
+    if ((r = mvo_ensure_pinned(ctx, std::max(b3 + b2 + bs, (size_t)n_hyp * 100 + (size_t)n + 512)))) return r;
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     std::memcpy(ctx->h_pin, pts3d, b3);
     std::memcpy(ctx->h_pin + b3, pts2d, b2);
@@ -347,20 +353,35 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     if ((r = track_launch_pnp_hypotheses(ctx, s->d_p3, s->d_p2, n, s->d_subsets, n_hyp, cam, thr2, s->d_models, s->d_counts,
                                          s->d_masks)))
         return r;
-    // the sequential bookkeeping of RANSACPointSetRegistrator::run, replayed over the hypothesis results
-    MVO_HIP(hipStreamSynchronize(ctx->stream));  // the staging area is reused for the read-back
-    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_counts, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(ctx->h_pin + (size_t)n_hyp * 4, s->d_models, (size_t)n_hyp * 96, hipMemcpyDeviceToHost,
-                           ctx->stream));
-    MVO_HIP(hipStreamSynchronize(ctx->stream));
-    s->counts.assign(reinterpret_cast<int32_t*>(ctx->h_pin), reinterpret_cast<int32_t*>(ctx->h_pin) + n_hyp);
+    // The refinement kernel replays the sequential bookkeeping of RANSACPointSetRegistrator::run over the counts and
+    // refines the model it selects; the host repeats the replay (its own libm) on the counts that come back with
+    // the result and only launches again if it disagrees -- one host round trip per call.
+    const int mode = n == kModel ? 1 : 0;
+    const double dev_conf = g_pnp_replay_skew ? 0.5 : confidence;
+    if ((r = track_launch_pnp_refine(ctx, s->d_p3, s->d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp, dev_conf,
+                                     mode == 1 ? 0 : -1, mode, s->d_Mg, s->d_mg, s->d_best_mask, s->d_out)))
+        return r;
+    // (the staging area is reused for the read-back: same stream, so the copies below run after the uploads above)
+    uint8_t* h_out = ctx->h_pin;
+    uint8_t* h_counts = h_out + 128;
+    uint8_t* h_models = h_counts + (size_t)n_hyp * 4;
+    uint8_t* h_mask = h_models + (size_t)n_hyp * 96;
+    auto fetch = [&]() -> int {
+        MVO_HIP(hipMemcpyAsync(h_out, s->d_out, 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipMemcpyAsync(h_mask, s->d_best_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        return MVO_OK;
+    };
+    MVO_HIP(hipMemcpyAsync(h_counts, s->d_counts, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(h_models, s->d_models, (size_t)n_hyp * 96, hipMemcpyDeviceToHost, ctx->stream));
+    if ((r = fetch())) return r;
+    s->counts.assign(reinterpret_cast<int32_t*>(h_counts), reinterpret_cast<int32_t*>(h_counts) + n_hyp);
     s->models.resize((size_t)n_hyp * 12);
-    std::memcpy(s->models.data(), ctx->h_pin + (size_t)n_hyp * 4, (size_t)n_hyp * 96);
+    std::memcpy(s->models.data(), h_models, (size_t)n_hyp * 96);
     s->info[5] = n_hyp;
-    int best = -1, mode = 0;
-    if (n == kModel) {  // "model_points == npoints": the kernel result is the answer and every pair an inlier
+    int best = -1;
+    if (mode == 1) {  // "model_points == npoints": the kernel result is the answer and every pair an inlier
         best = 0;
-        mode = 1;
         s->info[1] = 1;
     } else {
         int niters = n_hyp, max_good = 0, it = 0;
@@ -375,21 +396,18 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
         s->info[1] = it;
     }
     s->info[0] = best;
-    if (best < 0) {
-        if (ctx->prof) mvo_prof_collect(ctx);
-        return MVO_OK;  // no model with at least 5 inliers
+    double out[12];
+    std::memcpy(out, h_out, sizeof(out));
+    if (best >= 0 && (int)out[10] != best) {  // the device's replay chose differently: refine the right hypothesis
+        s->info[5] = -n_hyp;                  // (visible to tests through mvo_debug_get_pnp)
+        if ((r = track_launch_pnp_refine(ctx, s->d_p3, s->d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp,
+                                         confidence, best, mode, s->d_Mg, s->d_mg, s->d_best_mask, s->d_out)))
+            return r;
+        if ((r = fetch())) return r;
+        std::memcpy(out, h_out, sizeof(out));
     }
-    if ((r = track_launch_pnp_refine(ctx, s->d_p3, s->d_p2, s->d_masks + (size_t)best * n, n, cam,
-                                     s->d_models + 12 * (size_t)best, mode, s->d_Mg, s->d_mg, s->d_out)))
-        return r;
-    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_out, 10 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    if (mode == 0)
-        MVO_HIP(hipMemcpyAsync(ctx->h_pin + 128, s->d_masks + (size_t)best * n, (size_t)n, hipMemcpyDeviceToHost,
-                               ctx->stream));
-    MVO_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) mvo_prof_collect(ctx);
-    double out[10];
-    std::memcpy(out, ctx->h_pin, sizeof(out));
+    if (best < 0) return MVO_OK;  // no model with at least 5 inliers
     for (int k = 0; k < 3; ++k) {
         rvec[k] = out[k];
         tvec[k] = out[3 + k];
@@ -401,9 +419,8 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     if (mode == 1) {
         for (int i = 0; i < n; ++i) inliers[cnt++] = i;
     } else {
-        const uint8_t* mask = ctx->h_pin + 128;
         for (int i = 0; i < n; ++i)
-            if (mask[i]) inliers[cnt++] = i;
+            if (h_mask[i]) inliers[cnt++] = i;
     }
     *n_inliers = cnt;
     *found = 1;

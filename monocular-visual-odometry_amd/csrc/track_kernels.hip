@@ -101,13 +101,31 @@ __global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* _
     }
 }
 
-// out: param[6] = (rvec, tvec), then n_inliers, dlt used, LM iterations, LM evaluations (as doubles).
+// Picks the best hypothesis (the RANSAC loop's bookkeeping replayed over the counts, or `forced_best` >= 0), keeps
+// its mask in best_mask for the host and refines it.  out: param[6] = (rvec, tvec), n_inliers, dlt used, LM
+// iterations, LM evaluations, best hypothesis (-1: none reached 5 inliers), iterations the sequential loop runs.
 __global__ __launch_bounds__(pw::kRefLanes) void k_pnp_refine(const float* __restrict__ p3, const float* __restrict__ p2,
-                                                    const uint8_t* __restrict__ mask, int n, TrackCamera cam,
-                                                    const double* __restrict__ model, int mode, double* Mg, double* mg,
-                                                    double* __restrict__ out) {
+                                                              const uint8_t* __restrict__ masks, int n, TrackCamera cam,
+                                                              const double* __restrict__ models,
+                                                              const int32_t* __restrict__ counts, int n_hyp,
+                                                              double confidence, int forced_best, int mode, double* Mg,
+                                                              double* mg, uint8_t* __restrict__ best_mask,
+                                                              double* __restrict__ out) {
     __shared__ pw::RefLds lds;
     const pw::Camera c{cam.fx, cam.fy, cam.cx, cam.cy};
+    int best = forced_best, iters_run = mode == 1 ? 1 : 0;
+    if (forced_best < 0) pw::ransac_replay(counts, n_hyp, n, confidence, &best, &iters_run);
+    if (best < 0) {
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < 10; ++k) out[k] = 0;
+            out[10] = -1;
+            out[11] = iters_run;
+        }
+        return;
+    }
+    const uint8_t* mask = masks + (size_t)best * n;
+    const double* model = models + 12 * (size_t)best;
+    for (int i = threadIdx.x; i < n; i += pw::kRefLanes) best_mask[i] = mask[i];
     double R0[3][3], t0[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -124,6 +142,8 @@ __global__ __launch_bounds__(pw::kRefLanes) void k_pnp_refine(const float* __res
         out[7] = res.used_dlt;
         out[8] = res.lm_iters;
         out[9] = res.lm_evals;
+        out[10] = best;
+        out[11] = iters_run;
     }
 }
 
@@ -137,12 +157,13 @@ int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_
     return MVO_OK;
 }
 
-int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_mask, int n,
-                            const TrackCamera& cam, const double* d_model, int mode, double* d_Mg, double* d_mg,
-                            double* d_out) {
+int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_masks, int n,
+                            const TrackCamera& cam, const double* d_models, const int32_t* d_counts, int n_hyp,
+                            double confidence, int forced_best, int mode, double* d_Mg, double* d_mg,
+                            uint8_t* d_best_mask, double* d_out) {
     ProfScope ps(ctx, "k_pnp_refine");
-    hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(pw::kRefLanes), 0, ctx->stream, d_p3, d_p2, d_mask, n, cam, d_model, mode, d_Mg,
-                       d_mg, d_out);
+    hipLaunchKernelGGL(k_pnp_refine, dim3(1), dim3(pw::kRefLanes), 0, ctx->stream, d_p3, d_p2, d_masks, n, cam, d_models,
+                       d_counts, n_hyp, confidence, forced_best, mode, d_Mg, d_mg, d_best_mask, d_out);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

@@ -79,7 +79,7 @@ def test_solve_pnp_ransac_matches_the_oracle(mvo, O, ctx, seed, kw):
     assert got["ok"] == ref["ok"]
     # the device evaluates all 100 hypotheses; the oracle stops where the sequential loop stops
     run = ref["iters_run"]
-    assert dbg["n_hyp"] == 100 and dbg["iters_run"] == run and dbg["best_iter"] == ref["best_iter"]
+    assert dbg["n_hyp"] == 100 and dbg["iters_run"] == run and dbg["best_iter"] == ref["best_iter"]   # 100: no correction
     assert np.array_equal(dbg["counts"][:run], ref["counts"][:run])
     assert _same_models(dbg["models"][:run], ref["models"][:run])
     assert np.array_equal(got["inliers"], ref["inliers"])
@@ -130,6 +130,30 @@ def test_solve_pnp_ransac_edge_cases(mvo, O, ctx):
     nan3[7] = np.nan                                                       # a NaN pair is never an inlier
     bad, bad_o = ctx.solve_pnp_ransac(nan3, p2[:50], K), O.solve_pnp_ransac(nan3, p2[:50], K)
     assert bad["ok"] == bad_o["ok"] and np.array_equal(bad["inliers"], bad_o["inliers"]) and 7 not in bad["inliers"]
+
+
+def test_host_corrects_a_wrong_device_choice(mvo, O, ctx):
+    """The device replays the RANSAC loop itself (one host round trip per solve) and the host re-checks the choice on
+    the returned counts.  With the test hook the device replays with confidence 0.5, stops the loop early and picks
+    an earlier hypothesis than the real loop would: the result must still be the oracle's."""
+    pr = mvo.synth.tracking_problem(seed=12, outlier_frac=0.5)
+    p3, p2, K = pr["pts3d"], pr["pts2d"], pr["K"]
+    ref = O.solve_pnp_ransac(p3, p2, K)
+    corrected = 0
+    try:
+        mvo.debug_set("pnp_replay_skew", 1)
+        for conf in (0.999, 0.9999999):
+            ref = O.solve_pnp_ransac(p3, p2, K, confidence=conf)
+            got = ctx.solve_pnp_ransac(p3, p2, K, confidence=conf)
+            dbg = ctx.debug_pnp()
+            corrected += dbg["n_hyp"] < 0
+            assert dbg["best_iter"] == ref["best_iter"] and np.array_equal(got["inliers"], ref["inliers"])
+            assert np.abs(got["rvec"] - ref["rvec"]).max() < 1e-8 and np.abs(got["tvec"] - ref["tvec"]).max() < 1e-8
+    finally:
+        mvo.debug_set("pnp_replay_skew", 0)
+    assert corrected >= 1, "the hook never made the device choose differently: the test does not test the correction"
+    got = ctx.solve_pnp_ransac(p3, p2, K)
+    assert ctx.debug_pnp()["n_hyp"] == 100                      # normal operation: no correction needed
 
 
 def test_rodrigues_host(mvo, O):
