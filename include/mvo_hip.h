@@ -181,6 +181,21 @@ int mvo_map_points_in_view(mvo_ctx* ctx, mvo_map* map, const double* T_w_c, doub
 int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy,
                          double cx, double cy, int iterations, float reprojection_error, double confidence,
                          double* rvec, double* tvec, int32_t* inliers, int cap, int* n_inliers, int* found);
+/* ---- keyframe insertion (partial: triangulation + culling) ---------------- */
+/* geometry::helperTriangulatePoints (src/geometry/motion_estimation.cpp:214-247, called at
+ * vo_addFrame.cpp:114-116): pixel2CamNormPlane on the matched pixels of the previous / current keyframe
+ * (n x 2 float each, KeyPoint::pt), cv::triangulatePoints with [I|0] and [R|t] = T_curr_to_prev, then
+ * basics::transCoord.  Outputs n x 3 float (either may be NULL): the points in the previous camera frame
+ * (doTriangulation, epipolar_geometry.cpp:130-175) and what helperTriangulatePoints returns. */
+int mvo_triangulate_points(mvo_ctx* ctx, const float* kp_prev, const float* kp_curr, int n, double fx, double fy,
+                           double cx, double cy, const double* R, const double* t, float* pts3d_in_prev,
+                           float* pts3d_in_curr);
+/* VisualOdometry::retainGoodTriangulationResult_ (src/vo/vo.cpp:181-244), host-side (acos + a sort for the
+ * median): keep[i] lists the points whose triangulation angle (degrees) is >= min_triang_angle and at most
+ * max_ratio_to_median times the median; angles (n, may be NULL) receives every angle. */
+int mvo_retain_good_triangulation(const float* pts3d_in_curr, int n, const double* T_w_c_curr, const double* T_w_c_ref,
+                                  double min_triang_angle, double max_ratio_to_median, int32_t* keep, int* n_keep,
+                                  double* angles);
 /* cv::Rodrigues(rvec -> R, 3x3 row-major) as used at vo.cpp:334; host-side. */
 int mvo_rodrigues(const double* rvec, double* R);
 /* cv::Mat::inv() of a 4x4 double matrix (LU with partial pivoting) -- the T_w_c <-> T_c_w flips at

@@ -349,6 +349,19 @@ class Context:
                                                 _p(tvec), _p(inl), len(inl), C.byref(n_inl), C.byref(found)))
         return dict(ok=bool(found.value), rvec=rvec, tvec=tvec, inliers=inl[:n_inl.value].copy())
 
+    def triangulate_points(self, kp_prev, kp_curr, K, R, t):
+        """geometry::helperTriangulatePoints -> (points in the previous camera frame, returned points), n x 3 f32."""
+        a = np.ascontiguousarray(kp_prev, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(kp_curr, np.float32).reshape(-1, 2)
+        assert len(a) == len(b)
+        R = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+        t = np.ascontiguousarray(t, np.float64).reshape(3)
+        n = len(a)
+        pp, pc = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        self._chk(self.lib.mvo_triangulate_points(self.h, _p(a), _p(b), n, C.c_double(K["fx"]), C.c_double(K["fy"]),
+                                                  C.c_double(K["cx"]), C.c_double(K["cy"]), _p(R), _p(t), _p(pp), _p(pc)))
+        return pp, pc
+
     def debug_pnp(self, cap=4096):
         models = np.zeros((cap, 12))
         counts = np.zeros(cap, np.int32)
@@ -410,6 +423,20 @@ def rodrigues(rvec):
     if load_library().mvo_rodrigues(_p(r), _p(R)) != MVO_OK:
         raise MvoError(MVO_ERR_INVALID, "mvo_rodrigues")
     return R
+
+
+def retain_good_triangulation(pts3d_in_curr, T_w_c_curr, T_w_c_ref, min_triang_angle=1.0, max_ratio_to_median=20.0):
+    """VisualOdometry::retainGoodTriangulationResult_ -> (kept indices, all angles in degrees)."""
+    p = np.ascontiguousarray(pts3d_in_curr, np.float32).reshape(-1, 3)
+    Tc = np.ascontiguousarray(T_w_c_curr, np.float64).reshape(4, 4)
+    Tr = np.ascontiguousarray(T_w_c_ref, np.float64).reshape(4, 4)
+    n = len(p)
+    keep, ang, cnt = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1)), C.c_int()
+    r = load_library().mvo_retain_good_triangulation(_p(p), n, _p(Tc), _p(Tr), C.c_double(min_triang_angle),
+                                                     C.c_double(max_ratio_to_median), _p(keep), C.byref(cnt), _p(ang))
+    if r != MVO_OK:
+        raise MvoError(r, "mvo_retain_good_triangulation")
+    return keep[:cnt.value].copy(), ang[:n].copy()
 
 
 def remove_duplicated_matches(matches):

@@ -171,6 +171,8 @@ int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, 
                             const TrackCamera& cam, const double* d_models, const int32_t* d_counts, int n_hyp,
                             double confidence, int forced_best, int mode, double* d_Mg, double* d_mg,
                             uint8_t* d_best_mask, double* d_out);
+int track_launch_triangulate(mvo_ctx* ctx, const float* d_kp1, const float* d_kp2, int n, const TrackCamera& cam,
+                             const double* R, const double* t, float* d_prev, float* d_curr);
 extern int g_pnp_replay_skew;  // test hook: the device replays the RANSAC loop with a wrong confidence
 // track_host.cpp
 void track_release(mvo_ctx* ctx);

@@ -807,6 +807,46 @@ PW_FN int score_model(HypLds& s, const float* p3, const float* p2, int n, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// geometry::helperTriangulatePoints for ONE match (motion_estimation.cpp:214-247): pixel2CamNormPlane on both
+// pixels, cv::triangulatePoints with P1 = [I | 0], P2 = [R | t] (the 4x4 DLT system, right singular vector of the
+// smallest singular value, stored as float like OpenCV does for Point2f input), division by w in float, then
+// basics::transCoord.  Per-lane code: every lane works on its own match.
+PW_FN void triangulate_match(const float* kp1, const float* kp2, const Camera& cam, const double (&R)[9],
+                             const double (&t)[3], float (&p_prev)[3], float (&p_curr)[3]) {
+    const float n1[2] = {(float)((kp1[0] - cam.uc) / cam.fu), (float)((kp1[1] - cam.vc) / cam.fv)};
+    const float n2[2] = {(float)((kp2[0] - cam.uc) / cam.fu), (float)((kp2[1] - cam.vc) / cam.fv)};
+    const double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const double P2[12] = {R[0], R[1], R[2], t[0], R[3], R[4], R[5], t[1], R[6], R[7], R[8], t[2]};
+    double At[4][4], Vt[4][4], W[4];
+    {
+        const double x = n1[0], y = n1[1];
+        PW_UNROLL
+        for (int k = 0; k < 4; k++) {
+            At[k][0] = x * P1[8 + k] - P1[k];
+            At[k][1] = y * P1[8 + k] - P1[4 + k];
+        }
+    }
+    {
+        const double x = n2[0], y = n2[1];
+        PW_UNROLL
+        for (int k = 0; k < 4; k++) {
+            At[k][2] = x * P2[8 + k] - P2[k];
+            At[k][3] = y * P2[8 + k] - P2[4 + k];
+        }
+    }
+    svd_small<4, 4>(At, Vt, W);
+    const float X[4] = {(float)Vt[3][0], (float)Vt[3][1], (float)Vt[3][2], (float)Vt[3][3]};
+    PW_UNROLL
+    for (int r = 0; r < 3; r++) p_prev[r] = X[r] / X[3];
+    PW_UNROLL
+    for (int r = 0; r < 3; r++) {
+        double s = R[3 * r] * (double)p_prev[0] + R[3 * r + 1] * (double)p_prev[1];
+        s = s + R[3 * r + 2] * (double)p_prev[2];
+        p_curr[r] = (float)(s + t[r]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The sequential bookkeeping of RANSACPointSetRegistrator::run over the inlier counts of the hypotheses, in
 // iteration order: a hypothesis becomes the best model when its count exceeds max(best so far, modelPoints - 1),
 // and every new best shortens the loop through cv::RANSACUpdateNumIters.  Uniform.  pow / log differ in the last

@@ -32,6 +32,9 @@ struct mvo_track_state {
     std::vector<double> models;
     std::vector<int32_t> counts;
     int32_t info[6] = {-1, 0, 0, 0, 0, 0};
+    // triangulation
+    float *d_tri_in = nullptr, *d_tri_out = nullptr;
+    int cap_tri = 0;
     // map points in view
     int32_t* d_view_idx = nullptr;
     float* d_view_px = nullptr;
@@ -188,6 +191,8 @@ void track_release(mvo_ctx* ctx) {
     free_dev(s->d_view_px);
     free_dev(s->d_view_desc);
     free_dev(s->d_view_n);
+    free_dev(s->d_tri_in);
+    free_dev(s->d_tri_out);
     delete s;
     ctx->track = nullptr;
 }
@@ -424,6 +429,81 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     }
     *n_inliers = cnt;
     *found = 1;
+    return MVO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- keyframe row
+int mvo_triangulate_points(mvo_ctx* ctx, const float* kp_prev, const float* kp_curr, int n, double fx, double fy, double cx,
+                           double cy, const double* R, const double* t, float* pts3d_in_prev, float* pts3d_in_curr) {
+    if (!ctx || n < 0 || !R || !t || (n && (!kp_prev || !kp_curr || (!pts3d_in_prev && !pts3d_in_curr))))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (n == 0) return MVO_OK;
+    MVO_HIP(hipSetDevice(ctx->device));
+    mvo_track_state* s = state(ctx);
+    if (n > s->cap_tri) {
+        free_dev(s->d_tri_in);
+        free_dev(s->d_tri_out);
+        s->cap_tri = 0;
+        const int cap = std::max(4096, n + n / 2);
+        MVO_HIP(hipMalloc((void**)&s->d_tri_in, (size_t)cap * 4 * sizeof(float)));
+        MVO_HIP(hipMalloc((void**)&s->d_tri_out, (size_t)cap * 6 * sizeof(float)));
+        s->cap_tri = cap;
+    }
+    int r = mvo_ensure_pinned(ctx, (size_t)n * 24);
+    if (r) return r;
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(ctx->h_pin, kp_prev, (size_t)n * 8);
+    std::memcpy(ctx->h_pin + (size_t)n * 8, kp_curr, (size_t)n * 8);
+    MVO_HIP(hipMemcpyAsync(s->d_tri_in, ctx->h_pin, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+    const TrackCamera cam{fx, fy, cx, cy};
+    if ((r = track_launch_triangulate(ctx, s->d_tri_in, s->d_tri_in + 2 * (size_t)n, n, cam, R, t, s->d_tri_out,
+                                      s->d_tri_out + 3 * (size_t)n)))
+        return r;
+    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_tri_out, (size_t)n * 24, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->prof) mvo_prof_collect(ctx);
+    if (pts3d_in_prev) std::memcpy(pts3d_in_prev, ctx->h_pin, (size_t)n * 12);
+    if (pts3d_in_curr) std::memcpy(pts3d_in_curr, ctx->h_pin + (size_t)n * 12, (size_t)n * 12);
+    return MVO_OK;
+}
+
+int mvo_retain_good_triangulation(const float* pts3d_in_curr, int n, const double* T_w_c_curr, const double* T_w_c_ref,
+                                  double min_triang_angle, double max_ratio_to_median, int32_t* keep, int* n_keep,
+                                  double* angles) {
+    if (n < 0 || !n_keep || !T_w_c_curr || !T_w_c_ref || (n && (!pts3d_in_curr || !keep))) return MVO_ERR_INVALID;
+    *n_keep = 0;
+    if (n == 0) return MVO_OK;  // vo.cpp:198-199
+    std::vector<double> ang(n);
+    for (int i = 0; i < n; ++i) {
+        const float* pc = pts3d_in_curr + 3 * (size_t)i;
+        double to_curr[3], to_ref[3];
+        for (int r = 0; r < 3; ++r) {  // preTranslatePoint3f(p_in_curr, T_w_c) -> float, then the two rays
+            const double* row = T_w_c_curr + 4 * r;
+            double acc = 0;
+            acc += row[0] * (double)pc[0];
+            acc += row[1] * (double)pc[1];
+            acc += row[2] * (double)pc[2];
+            acc += row[3] * 1.0;
+            const double pw = (double)(float)acc;
+            to_curr[r] = T_w_c_curr[4 * r + 3] - pw;
+            to_ref[r] = T_w_c_ref[4 * r + 3] - pw;
+        }
+        double dot = 0, n1 = 0, n2 = 0;
+        for (int r = 0; r < 3; ++r) dot += to_curr[r] * to_ref[r];
+        for (int r = 0; r < 3; ++r) n1 = n1 + to_curr[r] * to_curr[r];
+        for (int r = 0; r < 3; ++r) n2 = n2 + to_ref[r] * to_ref[r];
+        ang[i] = std::acos(dot / (std::sqrt(n1) * std::sqrt(n2))) / 3.1415926 * 180.0;  // vo.cpp:210
+    }
+    std::vector<double> sorted(ang);
+    std::sort(sorted.begin(), sorted.end());
+    const double median = sorted[n / 2];
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+        if (angles) angles[i] = ang[i];
+        if (ang[i] < min_triang_angle || ang[i] / median > max_ratio_to_median) continue;  // vo.cpp:233-235
+        keep[cnt++] = i;
+    }
+    *n_keep = cnt;
     return MVO_OK;
 }
 

@@ -4,6 +4,7 @@
 //   k_pnp_hypotheses   the RANSAC loop of cv::solvePnPRansac (vo.cpp:326-329): one workgroup of three waves per
 //                      hypothesis runs the 5-point EPnP kernel (one wave per beta variant) and scores every pair.
 //   k_pnp_refine       the final cv::solvePnP(SOLVEPNP_ITERATIVE) on the inliers: DLT start + Levenberg-Marquardt.
+//   k_triangulate      geometry::helperTriangulatePoints (motion_estimation.cpp:214-247) on a keyframe's matches.
 // The arithmetic lives in pnp_wave.h (wave-level SPMD code); this file binds it to threads and LDS.
 #include "mvo_internal.h"
 
@@ -145,6 +146,39 @@ __global__ __launch_bounds__(pw::kRefLanes) void k_pnp_refine(const float* __res
         out[10] = best;
         out[11] = iters_run;
     }
+}
+
+// ------------------------------------------------------------------------------------------------ triangulation
+// geometry::helperTriangulatePoints (motion_estimation.cpp:214-247): one lane per match.
+struct TrackPose {
+    double R[9], t[3];
+};
+__global__ __launch_bounds__(256) void k_triangulate(const float2* __restrict__ kp1, const float2* __restrict__ kp2, int n,
+                                                      TrackCamera cam, TrackPose pose, float* __restrict__ pts_prev,
+                                                      float* __restrict__ pts_curr) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const pw::Camera c{cam.fx, cam.fy, cam.cx, cam.cy};
+    const float a[2] = {kp1[i].x, kp1[i].y}, b[2] = {kp2[i].x, kp2[i].y};
+    float pp[3], pc[3];
+    pw::triangulate_match(a, b, c, pose.R, pose.t, pp, pc);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        pts_prev[3 * i + r] = pp[r];
+        pts_curr[3 * i + r] = pc[r];
+    }
+}
+
+int track_launch_triangulate(mvo_ctx* ctx, const float* d_kp1, const float* d_kp2, int n, const TrackCamera& cam,
+                             const double* R, const double* t, float* d_prev, float* d_curr) {
+    TrackPose pose;
+    for (int k = 0; k < 9; ++k) pose.R[k] = R[k];
+    for (int k = 0; k < 3; ++k) pose.t[k] = t[k];
+    ProfScope ps(ctx, "k_triangulate");
+    hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float2*)d_kp1,
+                       (const float2*)d_kp2, n, cam, pose, d_prev, d_curr);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
 }
 
 int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_p2, int n, const int32_t* d_subsets,

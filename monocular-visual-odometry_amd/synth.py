@@ -197,3 +197,38 @@ def tracking_problem(n_map=3000, seed=11, width=640, height=480, K=FR1_K, pix_no
     uv[bad] = np.stack([rng.uniform(0, width, int(bad.sum())), rng.uniform(0, height, int(bad.sum()))], 1)
     return dict(map_pos=pw, map_desc=desc, T_w_c=T, K=K, cols=width, rows=height, pts3d=pw[ids].copy(),
                 pts2d=uv.astype(np.float32), inlier_gt=~bad, ids=ids)
+
+
+# ---------------------------------------------------------------- keyframe inputs (vo_addFrame.cpp:93-124)
+def keyframe_problem(n=600, seed=21, width=640, height=480, K=FR1_K, pix_noise=0.3, outlier_frac=0.2, baseline=0.25):
+    """Two keyframes looking at n scene points: matched pixels (kp_ref, kp_cur, a fraction of them wrong), the two
+    camera poses T_w_c and T_curr_to_prev = inv(T_w_cur) ... as getMotionFromFrame1to2(curr, ref) gives it
+    (vo_commons.cpp:9-16), the ground-truth points in the reference camera frame."""
+    rng = np.random.RandomState(seed)
+    f, cx, cy = K["fx"], K["cx"], K["cy"]
+    T_ref = np.eye(4)
+    T_ref[:3, :3] = _rot([0, 1, 0], np.deg2rad(2.0))
+    T_ref[:3, 3] = [0.1, 0.0, 0.05]
+    T_cur = np.eye(4)
+    T_cur[:3, :3] = _rot([0.1, 1.0, 0.05], np.deg2rad(6.0))
+    T_cur[:3, 3] = T_ref[:3, 3] + np.array([baseline, 0.02, 0.03])
+    z = rng.uniform(1.0, 5.0, n)
+    u = rng.uniform(0.15 * width, 0.85 * width, n)
+    v = rng.uniform(0.15 * height, 0.85 * height, n)
+    p_ref = np.stack([(u - cx) / f * z, (v - cy) / K["fy"] * z, z], 1)
+    p_w = p_ref @ T_ref[:3, :3].T + T_ref[:3, 3]
+
+    def proj(T):
+        Tcw = np.linalg.inv(T)
+        q = p_w @ Tcw[:3, :3].T + Tcw[:3, 3]
+        return np.stack([f * q[:, 0] / q[:, 2] + cx, K["fy"] * q[:, 1] / q[:, 2] + cy], 1), q
+
+    kp_ref, _ = proj(T_ref)
+    kp_cur, q_cur = proj(T_cur)
+    kp_ref = kp_ref + rng.normal(0, pix_noise, kp_ref.shape)
+    kp_cur = kp_cur + rng.normal(0, pix_noise, kp_cur.shape)
+    bad = rng.uniform(size=n) < outlier_frac
+    kp_cur[bad] = np.stack([rng.uniform(0, width, int(bad.sum())), rng.uniform(0, height, int(bad.sum()))], 1)
+    T_cur_to_ref = np.linalg.inv(T_cur) @ T_ref          # getMotionFromFrame1to2(curr, ref) = T_w_curr^-1 T_w_ref
+    return dict(kp_ref=kp_ref.astype(np.float32), kp_cur=kp_cur.astype(np.float32), T_w_ref=T_ref, T_w_cur=T_cur,
+                T_curr_to_prev=T_cur_to_ref, K=K, p_ref=p_ref, p_cur=q_cur, inlier_gt=~bad, cols=width, rows=height)

@@ -159,6 +159,15 @@ int orc_solve_pnp_ransac(const float* p3, const float* p2, int n, const double* 
                          double confidence, double* rvec, double* tvec, int32_t* inliers, int* n_inliers,
                          double* models, int32_t* counts, int32_t* info);
 
+/* --- keyframe row: keyframe_oracle.cpp -------------------------------- */
+/* geometry::helperTriangulatePoints (motion_estimation.cpp:214-247): matched pixels of the previous / current
+ * keyframe + T_curr_to_prev -> points in the previous camera frame and after basics::transCoord. */
+int orc_triangulate_points(const float* kp1, const float* kp2, int n, const double* K4, const double* R, const double* t,
+                           float* pts_prev, float* pts_curr);
+/* VisualOdometry::retainGoodTriangulationResult_ (vo.cpp:181-244); returns the count kept. */
+int orc_retain_good_triangulation(const float* pts_curr, int n, const double* T_w_c_curr, const double* T_w_c_ref,
+                                  double min_angle, double max_ratio, int32_t* keep, double* angles);
+
 #ifdef __cplusplus
 }
 #endif

@@ -349,3 +349,31 @@ def solve_pnp_ransac(p3, p2, K, iters=100, reproj=2.0, confidence=0.999):
            C.addressof(n_inl), _dp(models), _dp(counts), _dp(info))
     return dict(ok=bool(ok), rvec=rvec, tvec=tvec, inliers=inl[:n_inl.value].copy(), models=models, counts=counts,
                 best_iter=int(info[0]), iters_run=int(info[1]), dlt=int(info[2]), lm_iters=int(info[3]))
+
+
+# ---------------------------------------------------------------- keyframe row (keyframe_oracle.cpp)
+def triangulate_points(kp1, kp2, K, R, t):
+    """helperTriangulatePoints -> (pts in the previous camera frame, pts after transCoord), n x 3 float32 each."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    R = np.ascontiguousarray(R, np.float64)
+    t = np.ascontiguousarray(t, np.float64).reshape(3)
+    n = len(kp1)
+    a, b = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    k4 = _K4(K)
+    lib().orc_triangulate_points(_dp(kp1), _dp(kp2), n, _dp(k4), _dp(R), _dp(t), _dp(a), _dp(b))
+    return a, b
+
+
+def retain_good_triangulation(pts_curr, T_w_c_curr, T_w_c_ref, min_angle=1.0, max_ratio=20.0):
+    """retainGoodTriangulationResult_ -> (kept indices, angles in degrees of all points)."""
+    p = np.ascontiguousarray(pts_curr, np.float32).reshape(-1, 3)
+    Tc = np.ascontiguousarray(T_w_c_curr, np.float64)
+    Tr = np.ascontiguousarray(T_w_c_ref, np.float64)
+    n = len(p)
+    keep = np.zeros(max(n, 1), np.int32)
+    ang = np.zeros(max(n, 1))
+    f = lib().orc_retain_good_triangulation
+    f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    cnt = f(_dp(p), n, _dp(Tc), _dp(Tr), min_angle, max_ratio, _dp(keep), _dp(ang))
+    return keep[:cnt].copy(), ang[:n].copy()

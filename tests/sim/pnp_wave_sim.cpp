@@ -51,6 +51,21 @@ int sim_epnp_debug(const float* p3, const float* p2, const int32_t* idx, const d
     return 0;
 }
 
+int sim_triangulate(const float* kp1, const float* kp2, int n, const double* K4, const double* R, const double* t,
+                    float* pts_prev, float* pts_curr) {
+    const pw::Camera cam{K4[0], K4[1], K4[2], K4[3]};
+    double Rm[9], tv[3];
+    memcpy(Rm, R, sizeof(Rm));
+    memcpy(tv, t, sizeof(tv));
+    for (int i = 0; i < n; i++) {
+        float pp[3], pc[3];
+        pw::triangulate_match(kp1 + 2 * i, kp2 + 2 * i, cam, Rm, tv, pp, pc);
+        memcpy(pts_prev + 3 * i, pp, sizeof(pp));
+        memcpy(pts_curr + 3 * i, pc, sizeof(pc));
+    }
+    return 0;
+}
+
 int sim_refine(const float* p3, const float* p2, const uint8_t* mask, int n, const double* K4, const double* model,
                int mode, double* param, int32_t* info) {
     const pw::Camera cam{K4[0], K4[1], K4[2], K4[3]};

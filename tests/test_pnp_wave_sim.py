@@ -78,3 +78,14 @@ def test_refinement_matches_the_oracle(O, S, sim, seed, kw, dlt):
     sim.sim_refine(_dp(p3), _dp(p2), _dp(mask), 5, _dp(k4), _dp(model), 1, _dp(param), _dp(info))
     assert np.abs(param[:3] - O.rodrigues_inv(model[:9].reshape(3, 3))).max() < 1e-15
     assert np.array_equal(param[3:], model[9:])
+
+
+def test_triangulation_matches_the_oracle_bit_for_bit(O, S, sim):
+    kf = S.keyframe_problem(n=700, seed=6)
+    T = kf["T_curr_to_prev"]
+    R, t = np.ascontiguousarray(T[:3, :3]), np.ascontiguousarray(T[:3, 3])
+    pp, pc = np.zeros((700, 3), np.float32), np.zeros((700, 3), np.float32)
+    k4 = _k4(kf["K"])
+    sim.sim_triangulate(_dp(kf["kp_ref"]), _dp(kf["kp_cur"]), 700, _dp(k4), _dp(R), _dp(t), _dp(pp), _dp(pc))
+    po, co = O.triangulate_points(kf["kp_ref"], kf["kp_cur"], kf["K"], R, t)
+    assert np.array_equal(pp, po, equal_nan=True) and np.array_equal(pc, co, equal_nan=True)
