@@ -1,7 +1,7 @@
 // oracle/linalg_oracle.h -- small dense linear algebra shared by the tracking / keyframe oracles (pnp_oracle.cpp,
 // keyframe_oracle.cpp).  TEST INFRASTRUCTURE ONLY (see oracle.h).  This is OUR canonical arithmetic wherever OpenCV
 // calls cv::SVD / cv::solve(DECOMP_SVD) / cv::invert: a one-sided (Hestenes) Jacobi with OpenCV's rotation formulas
-// and 10*DBL_EPSILON test, round-robin pair order for 6 and 12 rows, cyclic order otherwise, right singular vectors
+// and 10*DBL_EPSILON test, round-robin pair order for 6, 10 and 12 rows, cyclic order otherwise, right singular vectors
 // from the accumulated rotations, stable descending order.
 #ifndef MVO_ORACLE_LINALG_H
 #define MVO_ORACLE_LINALG_H
@@ -92,13 +92,14 @@ inline bool jacobi_pair(double* At, int m, double* Vt, int n, int i, int j) {
 
 // At: n rows of length m (the COLUMNS of the matrix being decomposed).  On exit row i = sigma_i * u_i, Vt row i
 // = v_i, W sorted descending (rows permuted with it).
+// (cv::RNG lives here too: RANSACPointSetRegistrator seeds it with (uint64)-1 for solvePnPRansac and findEssentialMat)
 inline void jacobi_svd(double* At, int n, int m, double* Vt, double* W) {
     for (int i = 0; i < n; i++)
         for (int k = 0; k < n; k++) Vt[i * n + k] = i == k ? 1.0 : 0.0;
     const int max_iter = m > 30 ? m : 30;
     for (int it = 0; it < max_iter; it++) {
         bool changed = false;
-        if (n == 12 || n == 6) {
+        if (n == 12 || n == 10 || n == 6) {
             for (int r = 0; r < n - 1; r++)
                 for (int k = 0; k < n / 2; k++) {
                     int i, j;

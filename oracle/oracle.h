@@ -168,6 +168,18 @@ int orc_triangulate_points(const float* kp1, const float* kp2, int n, const doub
 int orc_retain_good_triangulation(const float* pts_curr, int n, const double* T_w_c_curr, const double* T_w_c_ref,
                                   double min_angle, double max_ratio, int32_t* keep, double* angles);
 
+/* cv::findEssentialMat's five-point kernel on 5 normalised correspondences (x2^T E x1 = 0): up to 10 unit-norm
+ * row-major candidates in E; dbg (optional, 257 doubles): null space 4x9, reduced 10x20 system, the degree-10
+ * polynomial (11), its real roots (10, NaN padded). */
+int orc_five_point(const double* q1, const double* q2, double* E, double* dbg);
+/* real roots (ascending) of c[0] z^10 + ... + c[10]: Sturm isolation + bisection */
+int orc_real_roots_deg10(const double* c, double* roots);
+/* geometry::helperFindInlierMatchesByEpipolarCons (motion_estimation.cpp:182-198) = inlier mask of
+ * cv::findEssentialMat(..., RANSAC, prob, threshold) as called at epipolar_geometry.cpp:36-39.  Returns the
+ * inlier count. */
+int orc_find_essential_inliers(const float* kp1, const float* kp2, int n, const double* K4, double prob, double threshold,
+                               int max_iters, int32_t* inliers, int32_t* counts, int32_t* info, double* bestE);
+
 #ifdef __cplusplus
 }
 #endif

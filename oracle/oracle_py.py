@@ -377,3 +377,41 @@ def retain_good_triangulation(pts_curr, T_w_c_curr, T_w_c_ref, min_angle=1.0, ma
     f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     cnt = f(_dp(p), n, _dp(Tc), _dp(Tr), min_angle, max_ratio, _dp(keep), _dp(ang))
     return keep[:cnt].copy(), ang[:n].copy()
+
+
+def five_point(q1, q2, want_dbg=False):
+    """five-point kernel on 5 normalised correspondences -> E candidates [k, 3, 3] (x2^T E x1 = 0)."""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2)
+    q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    E = np.zeros((10, 3, 3))
+    dbg = np.zeros(257)
+    k = lib().orc_five_point(_dp(q1), _dp(q2), _dp(E), _dp(dbg))
+    if want_dbg:
+        return E[:k].copy(), dict(basis=dbg[:36].reshape(4, 9), A=dbg[36:236].reshape(10, 20), poly=dbg[236:247],
+                                  roots=dbg[247:257])
+    return E[:k].copy()
+
+
+def real_roots_deg10(c):
+    c = np.ascontiguousarray(c, np.float64).reshape(11)
+    r = np.zeros(10)
+    k = lib().orc_real_roots_deg10(_dp(c), _dp(r))
+    return r[:k].copy()
+
+
+def find_essential_inliers(kp1, kp2, K, prob=0.999, threshold=1.0, max_iters=1000):
+    """helperFindInlierMatchesByEpipolarCons -> dict(inliers, counts [max_iters, 10], best_iter, best_model,
+    iters_run, n_models, E)."""
+    kp1 = np.ascontiguousarray(kp1, np.float32).reshape(-1, 2)
+    kp2 = np.ascontiguousarray(kp2, np.float32).reshape(-1, 2)
+    n = len(kp1)
+    inl = np.zeros(max(n, 1), np.int32)
+    counts = np.full((max_iters, 10), -2, np.int32)
+    info = np.zeros(4, np.int32)
+    E = np.zeros((3, 3))
+    k4 = _K4(K)
+    f = lib().orc_find_essential_inliers
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int] + [C.c_void_p] * 4
+    cnt = f(_dp(kp1), _dp(kp2), n, _dp(k4), prob, threshold, max_iters, _dp(inl), _dp(counts), _dp(info), _dp(E))
+    return dict(inliers=inl[:cnt].copy(), counts=counts, best_iter=int(info[0]), best_model=int(info[1]),
+                iters_run=int(info[2]), n_models=int(info[3]), E=E)
