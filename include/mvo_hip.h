@@ -181,7 +181,7 @@ int mvo_map_points_in_view(mvo_ctx* ctx, mvo_map* map, const double* T_w_c, doub
 int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, int n, double fx, double fy,
                          double cx, double cy, int iterations, float reprojection_error, double confidence,
                          double* rvec, double* tvec, int32_t* inliers, int cap, int* n_inliers, int* found);
-/* ---- keyframe insertion (partial: triangulation + culling) ---------------- */
+/* ---- keyframe insertion: epipolar inlier filter, triangulation, culling ---- */
 /* geometry::helperTriangulatePoints (src/geometry/motion_estimation.cpp:214-247, called at
  * vo_addFrame.cpp:114-116): pixel2CamNormPlane on the matched pixels of the previous / current keyframe
  * (n x 2 float each, KeyPoint::pt), cv::triangulatePoints with [I|0] and [R|t] = T_curr_to_prev, then
@@ -190,6 +190,14 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
 int mvo_triangulate_points(mvo_ctx* ctx, const float* kp_prev, const float* kp_curr, int n, double fx, double fy,
                            double cx, double cy, const double* R, const double* t, float* pts3d_in_prev,
                            float* pts3d_in_curr);
+/* geometry::helperFindInlierMatchesByEpipolarCons (src/geometry/motion_estimation.cpp:182-198, called at
+ * vo_addFrame.cpp:104-106) = the inlier mask of cv::findEssentialMat(pts1, pts2, focal = (fx + fy) / 2,
+ * pp = Point2f(cx, cy), cv::RANSAC, prob, threshold) (epipolar_geometry.cpp:17-47): RANSAC (cv::RNG subsets, at
+ * most 1000 iterations, adaptive count) over five-point hypotheses scored by the Sampson distance.  kp_prev /
+ * kp_curr: the matched pixels (n x 2 float); inliers: ascending indices into the matches, capacity cap >= n. */
+int mvo_find_essential_inliers(mvo_ctx* ctx, const float* kp_prev, const float* kp_curr, int n, double fx, double fy,
+                               double cx, double cy, double prob, double threshold, int32_t* inliers, int cap,
+                               int* n_inliers);
 /* VisualOdometry::retainGoodTriangulationResult_ (src/vo/vo.cpp:181-244), host-side (acos + a sort for the
  * median): keep[i] lists the points whose triangulation angle (degrees) is >= min_triang_angle and at most
  * max_ratio_to_median times the median; angles (n, may be NULL) receives every angle. */
@@ -236,6 +244,11 @@ int mvo_debug_get_candidates(mvo_ctx* ctx, void* out, int cap, int* n);
  * DLT used, LM iterations, LM residual evaluations, hypotheses evaluated (negative when the host had to correct
  * the device's choice of hypothesis)}. */
 int mvo_debug_get_pnp(mvo_ctx* ctx, double* models, int32_t* counts, int cap, int32_t* info);
+
+/* Record of the last mvo_find_essential_inliers on this ctx: inlier counts of every evaluated hypothesis
+ * (iterations x 10 candidates, -1 = no such candidate), info[5] = {best iteration, best candidate, iterations
+ * the sequential loop ran, iterations evaluated, 0}.  Returns the number of evaluated iterations. */
+int mvo_debug_get_essential(mvo_ctx* ctx, int32_t* counts, int cap_iters, int32_t* info);
 
 #ifdef __cplusplus
 }

@@ -362,6 +362,28 @@ class Context:
                                                   C.c_double(K["cx"]), C.c_double(K["cy"]), _p(R), _p(t), _p(pp), _p(pc)))
         return pp, pc
 
+    def find_essential_inliers(self, kp_prev, kp_curr, K, prob=0.999, threshold=1.0):
+        """geometry::helperFindInlierMatchesByEpipolarCons -> ascending inlier indices into the matches."""
+        a = np.ascontiguousarray(kp_prev, np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(kp_curr, np.float32).reshape(-1, 2)
+        assert len(a) == len(b)
+        n = len(a)
+        inl = np.zeros(max(n, 1), np.int32)
+        cnt = C.c_int()
+        self._chk(self.lib.mvo_find_essential_inliers(self.h, _p(a), _p(b), n, C.c_double(K["fx"]), C.c_double(K["fy"]),
+                                                      C.c_double(K["cx"]), C.c_double(K["cy"]), C.c_double(prob),
+                                                      C.c_double(threshold), _p(inl), len(inl), C.byref(cnt)))
+        return inl[:cnt.value].copy()
+
+    def debug_essential(self):
+        counts = np.zeros((1000, 10), np.int32)
+        info = np.zeros(5, np.int32)
+        it = self.lib.mvo_debug_get_essential(self.h, _p(counts), 1000, _p(info))
+        if it < 0:
+            self._chk(it)
+        return dict(counts=counts[:it].copy(), best_iter=int(info[0]), best_model=int(info[1]), iters_run=int(info[2]),
+                    evaluated=int(info[3]))
+
     def debug_pnp(self, cap=4096):
         models = np.zeros((cap, 12))
         counts = np.zeros(cap, np.int32)

@@ -173,6 +173,10 @@ int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, 
                             uint8_t* d_best_mask, double* d_out);
 int track_launch_triangulate(mvo_ctx* ctx, const float* d_kp1, const float* d_kp2, int n, const TrackCamera& cam,
                              const double* R, const double* t, float* d_prev, float* d_curr);
+int track_launch_em_hypotheses(mvo_ctx* ctx, const double* d_q1, const double* d_q2, int n, const int32_t* d_subsets,
+                               int n_hyp, float thr2, double* d_E, int32_t* d_nm, int32_t* d_counts);
+int track_launch_em_mask(mvo_ctx* ctx, const double* d_q1, const double* d_q2, int n, const double* d_E, float thr2,
+                         uint8_t* d_mask);
 extern int g_pnp_replay_skew;  // test hook: the device replays the RANSAC loop with a wrong confidence
 // track_host.cpp
 void track_release(mvo_ctx* ctx);

@@ -230,7 +230,7 @@ PW_FN void nearest_rotation_uvt(const double (&A)[3][3], double (&R)[3][3]) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Lane-parallel one-sided Jacobi on an N x N matrix in LDS (N = 6 or 12), round-robin pair schedule: the N/2
+// Lane-parallel one-sided Jacobi on N rows of length M in LDS (N = 6, 10 or 12), round-robin pair schedule: the N/2
 // pairs of a round touch disjoint rows, lane k < N/2 derives the rotation of pair k, then all lanes apply the
 // rotations to the rows of At and Vt.  perm[p] = row holding the p-th largest singular value.
 PW_FN void rr_pair(int n, int r, int k, int* i, int* j) {
@@ -255,13 +255,16 @@ struct JacobiLds {
     int changed;
 };
 
-template <int N, int NL>
-PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
-    PW_LANES(l, NL) {
-        for (int e = l; e < N * N; e += NL) Vt[e] = (e / N == e % N) ? 1.0 : 0.0;
+template <int N, int M, int NL>
+PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {  // At: N rows of length M; Vt: N x N or nullptr
+    const int NV = Vt ? N : 0;
+    if (Vt) {
+        PW_LANES(l, NL) {
+            for (int e = l; e < N * N; e += NL) Vt[e] = (e / N == e % N) ? 1.0 : 0.0;
+        }
     }
     PW_SYNC();
-    const int max_iter = 30;
+    const int max_iter = M > 30 ? M : 30;
     for (int it = 0; it < max_iter; it++) {
         PW_LANES(l, NL) {
             if (l == 0) js.changed = 0;
@@ -275,10 +278,10 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
                     if (l < 3 * (N / 2)) {
                         int i, j;
                         rr_pair(N, r, l / 3, &i, &j);
-                        const double* x = At + N * (l % 3 == 1 ? j : i);
-                        const double* y = At + N * (l % 3 == 0 ? i : j);
+                        const double* x = At + M * (l % 3 == 1 ? j : i);
+                        const double* y = At + M * (l % 3 == 0 ? i : j);
                         double d = 0;
-                        for (int k = 0; k < N; k++) d += x[k] * y[k];
+                        for (int k = 0; k < M; k++) d += x[k] * y[k];
                         js.dots[l] = d;
                     }
                 }
@@ -294,9 +297,9 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
                     } else {
                         int i, j;
                         rr_pair(N, r, l, &i, &j);
-                        for (int k = 0; k < N; k++) a += At[i * N + k] * At[i * N + k];
-                        for (int k = 0; k < N; k++) b += At[j * N + k] * At[j * N + k];
-                        for (int k = 0; k < N; k++) p += At[i * N + k] * At[j * N + k];
+                        for (int k = 0; k < M; k++) a += At[i * M + k] * At[i * M + k];
+                        for (int k = 0; k < M; k++) b += At[j * M + k] * At[j * M + k];
+                        for (int k = 0; k < M; k++) p += At[i * M + k] * At[j * M + k];
                     }
                     const bool rot = jacobi_cs(a, b, p, &c, &s);
                     js.cs[2 * l] = c;
@@ -307,16 +310,17 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
             }
             PW_SYNC();
             PW_LANES(l, NL) {
-                for (int e = l; e < N * N; e += NL) {  // (pair, At|Vt, column)
-                    const int k = e / (2 * N), rem = e % (2 * N), col = rem % N;
-                    double* arr = rem >= N ? Vt : At;
+                for (int e = l; e < (N / 2) * (M + NV); e += NL) {  // (pair, column of At | column of Vt)
+                    const int k = e / (M + NV), rem = e % (M + NV);
                     if (js.rot[k]) {
                         int i, j;
                         rr_pair(N, r, k, &i, &j);
                         const double c = js.cs[2 * k], s = js.cs[2 * k + 1];
-                        const double x = arr[i * N + col], y = arr[j * N + col];
-                        arr[i * N + col] = c * x + s * y;
-                        arr[j * N + col] = c * y - s * x;
+                        double* pi = rem < M ? At + i * M + rem : Vt + i * N + (rem - M);
+                        double* pj = rem < M ? At + j * M + rem : Vt + j * N + (rem - M);
+                        const double x = *pi, y = *pj;
+                        *pi = c * x + s * y;
+                        *pj = c * y - s * x;
                     }
                 }
             }
@@ -329,7 +333,7 @@ PW_FN void jacobi_rr(double* At, double* Vt, JacobiLds& js) {
     PW_LANES(l, NL) {
         if (l < N) {
             double sd = 0;
-            for (int k = 0; k < N; k++) sd += At[l * N + k] * At[l * N + k];
+            for (int k = 0; k < M; k++) sd += At[l * M + k] * At[l * M + k];
             js.W[l] = sqrt(sd);
         }
     }
@@ -707,7 +711,7 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
         }
     }
     PW_SYNC();
-    jacobi_rr<12, kHypLanes>(s.At, s.Vt, s.js);
+    jacobi_rr<12, 12, kHypLanes>(s.At, s.Vt, s.js);
     // compute_L_6x10 from the four eigenvectors of the smallest eigenvalues
     PW_LANES(l, kHypLanes) {
         if (l < 60) {
@@ -1050,7 +1054,7 @@ PW_FN void lm_step(RefLds& s, const double (&JtJ)[21], const double (&JtErr)[6],
             }
     }
     PW_SYNC();
-    jacobi_rr<6, kRefLanes>(s.At, s.Vt, s.js);
+    jacobi_rr<6, 6, kRefLanes>(s.At, s.Vt, s.js);
     double W[6], thr = 0, x[6] = {0, 0, 0, 0, 0, 0};
     for (int p = 0; p < 6; p++) {
         W[p] = s.js.W[s.js.perm[p]];
@@ -1202,7 +1206,7 @@ PW_FN void refine_pose(RefLds& s, const float* p3, const float* p2, const uint8_
             }
         }
         PW_SYNC();
-        jacobi_rr<12, kRefLanes>(s.At, s.Vt, s.js);
+        jacobi_rr<12, 12, kRefLanes>(s.At, s.Vt, s.js);
         const double* v = s.Vt + 12 * s.js.perm[11];
         double RR[3][3], tt[3];
         for (int i = 0; i < 3; i++) {

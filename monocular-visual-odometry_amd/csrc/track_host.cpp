@@ -35,6 +35,14 @@ struct mvo_track_state {
     // triangulation
     float *d_tri_in = nullptr, *d_tri_out = nullptr;
     int cap_tri = 0;
+    // essential-matrix RANSAC
+    double* d_emq = nullptr;  // q1 (2n) then q2 (2n)
+    uint8_t* d_em_mask = nullptr;
+    int cap_em = 0;
+    int32_t *d_em_subsets = nullptr, *d_em_nm = nullptr, *d_em_counts = nullptr;
+    double* d_em_E = nullptr;
+    std::vector<int32_t> em_counts;  // record of the last call: [iterations evaluated x 10]
+    int32_t em_info[5] = {-1, -1, 0, 0, 0};
     // map points in view
     int32_t* d_view_idx = nullptr;
     float* d_view_px = nullptr;
@@ -193,6 +201,12 @@ void track_release(mvo_ctx* ctx) {
     free_dev(s->d_view_n);
     free_dev(s->d_tri_in);
     free_dev(s->d_tri_out);
+    free_dev(s->d_emq);
+    free_dev(s->d_em_mask);
+    free_dev(s->d_em_subsets);
+    free_dev(s->d_em_nm);
+    free_dev(s->d_em_counts);
+    free_dev(s->d_em_E);
     delete s;
     ctx->track = nullptr;
 }
@@ -465,6 +479,135 @@ int mvo_triangulate_points(mvo_ctx* ctx, const float* kp_prev, const float* kp_c
     if (pts3d_in_prev) std::memcpy(pts3d_in_prev, ctx->h_pin, (size_t)n * 12);
     if (pts3d_in_curr) std::memcpy(pts3d_in_curr, ctx->h_pin + (size_t)n * 12, (size_t)n * 12);
     return MVO_OK;
+}
+
+// geometry::helperFindInlierMatchesByEpipolarCons = the inlier mask of cv::findEssentialMat(RANSAC)
+int mvo_find_essential_inliers(mvo_ctx* ctx, const float* kp_prev, const float* kp_curr, int n, double fx, double fy,
+                               double cx, double cy, double prob, double threshold, int32_t* inliers, int cap,
+                               int* n_inliers) {
+    if (!ctx || n < 0 || !n_inliers || cap < 0 || (n && (!kp_prev || !kp_curr)) || (cap && !inliers))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
+    if (!(prob > 0 && prob < 1))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "mvo_find_essential_inliers: prob must be in (0, 1)", hipSuccess);
+    *n_inliers = 0;
+    mvo_track_state* s = state(ctx);
+    s->em_counts.clear();
+    s->em_info[0] = s->em_info[1] = -1;
+    s->em_info[2] = s->em_info[3] = s->em_info[4] = 0;
+    constexpr int kModel = 5, kMaxIters = 1000;  // createRANSACPointSetRegistrator(cb, 5, threshold, prob) -> maxIters 1000
+    if (n < kModel) return MVO_OK;
+    if (cap < n) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "mvo_find_essential_inliers: inlier buffer smaller than n", hipSuccess);
+    MVO_HIP(hipSetDevice(ctx->device));
+    if (n > s->cap_em) {
+        free_dev(s->d_emq);
+        free_dev(s->d_em_mask);
+        s->cap_em = 0;
+        const int c = std::max(4096, n + n / 2);
+        MVO_HIP(hipMalloc((void**)&s->d_emq, (size_t)c * 4 * sizeof(double)));
+        MVO_HIP(hipMalloc((void**)&s->d_em_mask, (size_t)c));
+        s->cap_em = c;
+    }
+    if (!s->d_em_subsets) {
+        MVO_HIP(hipMalloc((void**)&s->d_em_subsets, (size_t)kMaxIters * 5 * sizeof(int32_t)));
+        MVO_HIP(hipMalloc((void**)&s->d_em_nm, (size_t)kMaxIters * sizeof(int32_t)));
+        MVO_HIP(hipMalloc((void**)&s->d_em_counts, (size_t)kMaxIters * 10 * sizeof(int32_t)));
+        MVO_HIP(hipMalloc((void**)&s->d_em_E, (size_t)kMaxIters * 90 * sizeof(double)));
+    }
+    // findEssentialMat(points1, points2, focal, pp, ...): K = [focal 0 pp.x; 0 focal pp.y], pp a cv::Point2f built from
+    // K(0,2), K(1,2) (epipolar_geometry.cpp:27-28); points to double, (p - c) / f; threshold /= (fx + fy) / 2
+    const double focal = (fx + fy) / 2;
+    const double pcx = (double)(float)cx, pcy = (double)(float)cy;
+    const size_t bq = (size_t)n * 4 * sizeof(double), bs = (size_t)kMaxIters * 5 * sizeof(int32_t);
+    int r = mvo_ensure_pinned(ctx, std::max(bq + bs, (size_t)kMaxIters * 40 + (size_t)n + 64));
+    if (r) return r;
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    double* q = reinterpret_cast<double*>(ctx->h_pin);
+    for (int i = 0; i < n; ++i) {
+        q[2 * i] = ((double)kp_prev[2 * i] - pcx) / focal;
+        q[2 * i + 1] = ((double)kp_prev[2 * i + 1] - pcy) / focal;
+        q[2 * (size_t)n + 2 * i] = ((double)kp_curr[2 * i] - pcx) / focal;
+        q[2 * (size_t)n + 2 * i + 1] = ((double)kp_curr[2 * i + 1] - pcy) / focal;
+    }
+    int32_t* subsets = reinterpret_cast<int32_t*>(ctx->h_pin + bq);
+    const int total = n == kModel ? 1 : kMaxIters;
+    if (n == kModel)
+        for (int i = 0; i < kModel; ++i) subsets[i] = i;
+    else
+        draw_subsets(n, kMaxIters, subsets);
+    MVO_HIP(hipMemcpyAsync(s->d_emq, q, bq, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(s->d_em_subsets, subsets, (size_t)total * 5 * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const double thr = threshold / ((focal + focal) / 2);
+    const float thr2 = (float)(thr * thr);
+    const double* d_q1 = s->d_emq;
+    const double* d_q2 = s->d_emq + 2 * (size_t)n;
+    // The hypotheses are evaluated in growing chunks; after each chunk the sequential bookkeeping of
+    // RANSACPointSetRegistrator::run is advanced over the new counts until the loop's own stopping rule is met.
+    const int chunk_end[3] = {64, 256, kMaxIters};
+    int evaluated = 0, niters = total, max_good = 0, it = 0, best_it = -1, best_m = -1;
+    bool first_wait = true;
+    for (int c = 0; c < 3 && it < niters; ++c) {
+        const int end = std::min(chunk_end[c], total);
+        if (end <= evaluated) continue;
+        if ((r = track_launch_em_hypotheses(ctx, d_q1, d_q2, n, s->d_em_subsets + 5 * (size_t)evaluated, end - evaluated, thr2,
+                                            s->d_em_E + 90 * (size_t)evaluated, s->d_em_nm + evaluated,
+                                            s->d_em_counts + 10 * (size_t)evaluated)))
+            return r;
+        if (first_wait) {  // the staging area still holds the uploads of this call
+            MVO_HIP(hipStreamSynchronize(ctx->stream));
+            first_wait = false;
+        }
+        int32_t* h_counts = reinterpret_cast<int32_t*>(ctx->h_pin);
+        MVO_HIP(hipMemcpyAsync(h_counts, s->d_em_counts + 10 * (size_t)evaluated, (size_t)(end - evaluated) * 40,
+                               hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        s->em_counts.insert(s->em_counts.end(), h_counts, h_counts + (size_t)(end - evaluated) * 10);
+        evaluated = end;
+        for (; it < niters && it < evaluated; ++it)
+            for (int m = 0; m < 10; ++m) {
+                const int good = n == kModel && s->em_counts[(size_t)it * 10 + m] >= 0 ? n : s->em_counts[(size_t)it * 10 + m];
+                if (good < 0) break;
+                if (good > std::max(max_good, kModel - 1)) {
+                    max_good = good;
+                    best_it = it;
+                    best_m = m;
+                    niters = update_num_iters(prob, (double)(n - good) / n, kModel, niters);
+                }
+                if (n == kModel) break;  // count == modelPoints: the first model is the answer
+            }
+    }
+    s->em_info[0] = best_it;
+    s->em_info[1] = best_m;
+    s->em_info[2] = it;
+    s->em_info[3] = evaluated;
+    if (best_it < 0) {
+        if (ctx->prof) mvo_prof_collect(ctx);
+        return MVO_OK;
+    }
+    int cnt = 0;
+    if (n == kModel) {
+        for (int i = 0; i < n; ++i) inliers[cnt++] = i;
+    } else {
+        if ((r = track_launch_em_mask(ctx, d_q1, d_q2, n, s->d_em_E + 90 * (size_t)best_it + 9 * (size_t)best_m, thr2,
+                                      s->d_em_mask)))
+            return r;
+        MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_em_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n; ++i)
+            if (ctx->h_pin[i]) inliers[cnt++] = i;
+    }
+    if (ctx->prof) mvo_prof_collect(ctx);
+    *n_inliers = cnt;
+    return MVO_OK;
+}
+
+int mvo_debug_get_essential(mvo_ctx* ctx, int32_t* counts, int cap_iters, int32_t* info) {
+    if (!ctx || !ctx->track) return mvo_set_err(ctx, MVO_ERR_STATE, "no essential-matrix call on this ctx yet", hipSuccess);
+    const mvo_track_state* s = ctx->track;
+    const int iters = (int)(s->em_counts.size() / 10);
+    if (info) std::memcpy(info, s->em_info, sizeof(s->em_info));
+    if (iters > cap_iters) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "mvo_debug_get_essential: buffer too small", hipSuccess);
+    if (counts && iters) std::memcpy(counts, s->em_counts.data(), s->em_counts.size() * 4);
+    return iters;
 }
 
 int mvo_retain_good_triangulation(const float* pts3d_in_curr, int n, const double* T_w_c_curr, const double* T_w_c_ref,

@@ -5,6 +5,8 @@
 //                      hypothesis runs the 5-point EPnP kernel (one wave per beta variant) and scores every pair.
 //   k_pnp_refine       the final cv::solvePnP(SOLVEPNP_ITERATIVE) on the inliers: DLT start + Levenberg-Marquardt.
 //   k_triangulate      geometry::helperTriangulatePoints (motion_estimation.cpp:214-247) on a keyframe's matches.
+//   k_em_hypotheses    the RANSAC loop of cv::findEssentialMat (epipolar_geometry.cpp:36-39): one wave per five-point
+//   k_em_mask          hypothesis; the inlier mask of the selected candidate.
 // The arithmetic lives in pnp_wave.h (wave-level SPMD code); this file binds it to threads and LDS.
 #include "mvo_internal.h"
 
@@ -13,7 +15,7 @@
 #define PW_WAVES(w, NW) for (int w = (int)(threadIdx.x >> 6), pw_once_ = 1; pw_once_; pw_once_ = 0)
 #define PW_SYNC() __syncthreads()
 #define PW_UNROLL _Pragma("unroll")
-#include "pnp_wave.h"
+#include "em_wave.h"
 
 // ------------------------------------------------------------------------------------------------ map in view
 // One workgroup walks the map in chunks of 1024 points and appends the survivors in map order (the reference
@@ -177,6 +179,50 @@ int track_launch_triangulate(mvo_ctx* ctx, const float* d_kp1, const float* d_kp
     ProfScope ps(ctx, "k_triangulate");
     hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const float2*)d_kp1,
                        (const float2*)d_kp2, n, cam, pose, d_prev, d_curr);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ essential matrix
+// cv::findEssentialMat's RANSAC loop (epipolar_geometry.cpp:36-39): one wave per hypothesis solves the five-point
+// problem and counts the Sampson inliers of each of its (<= 10) candidates.
+__global__ __launch_bounds__(pw::kEmLanes) void k_em_hypotheses(const double* __restrict__ q1, const double* __restrict__ q2,
+                                                               int n, const int32_t* __restrict__ subsets, float thr2,
+                                                               double* __restrict__ E, int32_t* __restrict__ n_models,
+                                                               int32_t* __restrict__ counts) {
+    __shared__ pw::EmLds lds;
+    const size_t h = blockIdx.x;
+    const int nm = pw::five_point_hypothesis(lds, q1, q2, subsets + 5 * h, E + 90 * h);
+    __threadfence_block();
+    __syncthreads();  // the candidates were written by lanes 0..8, every lane reads them for the scoring
+    pw::score_essentials(lds, q1, q2, n, E + 90 * h, nm, thr2, counts + 10 * h);
+    if (threadIdx.x == 0) n_models[h] = nm;
+}
+
+// inlier mask of the selected candidate (the bestMask of RANSACPointSetRegistrator::run)
+__global__ __launch_bounds__(256) void k_em_mask(const double* __restrict__ q1, const double* __restrict__ q2, int n,
+                                                 const double* __restrict__ E, float thr2, uint8_t* __restrict__ mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double e[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] = E[k];
+    mask[i] = pw::sampson_inlier(e, q1[2 * i], q1[2 * i + 1], q2[2 * i], q2[2 * i + 1], thr2) ? 1 : 0;
+}
+
+int track_launch_em_hypotheses(mvo_ctx* ctx, const double* d_q1, const double* d_q2, int n, const int32_t* d_subsets,
+                               int n_hyp, float thr2, double* d_E, int32_t* d_nm, int32_t* d_counts) {
+    ProfScope ps(ctx, "k_em_hypotheses");
+    hipLaunchKernelGGL(k_em_hypotheses, dim3(n_hyp), dim3(pw::kEmLanes), 0, ctx->stream, d_q1, d_q2, n, d_subsets, thr2,
+                       d_E, d_nm, d_counts);
+    MVO_HIP(hipGetLastError());
+    return MVO_OK;
+}
+
+int track_launch_em_mask(mvo_ctx* ctx, const double* d_q1, const double* d_q2, int n, const double* d_E, float thr2,
+                         uint8_t* d_mask) {
+    ProfScope ps(ctx, "k_em_mask");
+    hipLaunchKernelGGL(k_em_mask, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_q1, d_q2, n, d_E, thr2, d_mask);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

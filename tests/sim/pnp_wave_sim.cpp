@@ -12,7 +12,7 @@
 #define PW_WAVES(w, NW) for (int w = 0; w < (NW); ++w)
 #define PW_SYNC() ((void)0)
 #define PW_UNROLL
-#include "../../monocular-visual-odometry_amd/csrc/pnp_wave.h"
+#include "../../monocular-visual-odometry_amd/csrc/em_wave.h"
 
 extern "C" {
 
@@ -47,6 +47,19 @@ int sim_epnp_debug(const float* p3, const float* p2, const int32_t* idx, const d
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[i][j];
         Rt[9 + i] = t[i];
+    }
+    return 0;
+}
+
+// essential-matrix hypotheses: E candidates [n_hyp x 10 x 9], their number [n_hyp], inlier counts [n_hyp x 10]
+int sim_em_hypotheses(const double* q1, const double* q2, int n, const int32_t* subsets, int n_hyp, float thr2, double* E,
+                      int32_t* n_models, int32_t* counts) {
+    for (int h = 0; h < n_hyp; h++) {
+        static pw::EmLds lds;
+        memset(&lds, 0xff, sizeof(lds));
+        const int nm = pw::five_point_hypothesis(lds, q1, q2, subsets + 5 * h, E + 90 * (size_t)h);
+        n_models[h] = nm;
+        pw::score_essentials(lds, q1, q2, n, E + 90 * (size_t)h, nm, thr2, counts + 10 * (size_t)h);
     }
     return 0;
 }

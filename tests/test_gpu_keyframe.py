@@ -43,3 +43,61 @@ def test_retain_good_triangulation_matches_oracle(mvo, O, ctx):
             assert 0.5 * 900 < len(keep) < 900
     k0, a0 = mvo.retain_good_triangulation(np.zeros((0, 3), np.float32), kf["T_w_cur"], kf["T_w_ref"])
     assert len(k0) == 0 and len(a0) == 0
+
+
+@pytest.mark.parametrize("n,seed,kw", [(500, 8, {}), (500, 9, dict(outlier_frac=0.5)), (300, 10, dict(outlier_frac=0.0)),
+                                        (2000, 11, dict(outlier_frac=0.3)), (40, 12, dict(outlier_frac=0.7)),
+                                        (800, 13, dict(outlier_frac=0.85))])
+def test_find_essential_inliers_matches_the_oracle(mvo, O, ctx, n, seed, kw):
+    """helperFindInlierMatchesByEpipolarCons: every evaluated hypothesis' candidate counts, the chosen candidate, the
+    loop length and the inlier list are bit-exact (the device evaluates 64 / 256 / 1000 iterations, the sequential
+    loop stops inside that range)."""
+    kf = mvo.synth.keyframe_problem(n=n, seed=seed, **kw)
+    got = ctx.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], kf["K"], 0.999, 1.0)
+    dbg = ctx.debug_essential()
+    ref = O.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], kf["K"], 0.999, 1.0)
+    run = ref["iters_run"]
+    assert dbg["iters_run"] == run and dbg["evaluated"] in (64, 256, 1000) and dbg["evaluated"] >= run
+    assert (dbg["evaluated"] == 64) == (run <= 64)
+    assert np.array_equal(dbg["counts"][:run], ref["counts"][:run])
+    assert (dbg["best_iter"], dbg["best_model"]) == (ref["best_iter"], ref["best_model"])
+    assert np.array_equal(got, ref["inliers"])
+    if kw.get("outlier_frac", 0.2) <= 0.5 and n >= 300:
+        gt = kf["inlier_gt"]
+        assert gt[got].mean() > 0.9 and len(got) > 0.9 * gt.sum()
+
+
+def test_find_essential_inliers_edge_cases(mvo, O, ctx):
+    kf = mvo.synth.keyframe_problem(n=60, seed=14, outlier_frac=0.0)
+    a, b, K = kf["kp_ref"], kf["kp_cur"], kf["K"]
+    assert len(ctx.find_essential_inliers(a[:4], b[:4], K)) == 0
+    assert len(ctx.find_essential_inliers(a[:0], b[:0], K)) == 0
+    five = ctx.find_essential_inliers(a[:5], b[:5], K)
+    assert np.array_equal(five, O.find_essential_inliers(a[:5], b[:5], K)["inliers"])
+    rng = np.random.RandomState(3)
+    junk = rng.uniform(0, 480, (60, 2)).astype(np.float32)
+    assert np.array_equal(ctx.find_essential_inliers(a, junk, K), O.find_essential_inliers(a, junk, K)["inliers"])
+    same = ctx.find_essential_inliers(a, a, K)                      # no motion at all: degenerate five-point systems
+    assert np.array_equal(same, O.find_essential_inliers(a, a, K)["inliers"])
+    for prob, thr in [(0.5, 1.0), (0.999, 0.05), (0.9999999, 3.0)]:
+        assert np.array_equal(ctx.find_essential_inliers(a, b, K, prob, thr), O.find_essential_inliers(a, b, K, prob, thr)["inliers"])
+    with pytest.raises(mvo.MvoError):
+        ctx.find_essential_inliers(a, b, K, prob=1.0)
+
+
+def test_keyframe_insertion_end_to_end(mvo, O, ctx):
+    """vo_addFrame.cpp:104-118 in one piece: epipolar inlier filter -> triangulation -> angle culling."""
+    kf = mvo.synth.keyframe_problem(n=900, seed=15, outlier_frac=0.25)
+    K, T = kf["K"], kf["T_curr_to_prev"]
+    inl = ctx.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], K)
+    _, p_cur = ctx.triangulate_points(kf["kp_ref"][inl], kf["kp_cur"][inl], K, T[:3, :3], T[:3, 3])
+    keep, ang = mvo.retain_good_triangulation(p_cur, kf["T_w_cur"], kf["T_w_ref"])
+    inl_o = O.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], K)["inliers"]
+    _, p_cur_o = O.triangulate_points(kf["kp_ref"][inl_o], kf["kp_cur"][inl_o], K, T[:3, :3], T[:3, 3])
+    keep_o, ang_o = O.retain_good_triangulation(p_cur_o, kf["T_w_cur"], kf["T_w_ref"])
+    assert np.array_equal(inl, inl_o) and np.array_equal(p_cur, p_cur_o, equal_nan=True)
+    assert np.array_equal(keep, keep_o) and np.array_equal(ang, ang_o, equal_nan=True)
+    good = kf["inlier_gt"][inl][keep]
+    assert good.mean() > 0.95 and len(keep) > 0.5 * kf["inlier_gt"].sum()
+    err = np.linalg.norm(p_cur[keep][good] - kf["p_cur"][inl][keep][good], axis=1) / kf["p_cur"][inl][keep][good][:, 2]
+    assert np.median(err) < 0.03

@@ -12,12 +12,13 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "sim", "pnp_wave_sim.cpp")
 HDR = os.path.join(HERE, "..", "monocular-visual-odometry_amd", "csrc", "pnp_wave.h")
+HDR2 = os.path.join(HERE, "..", "monocular-visual-odometry_amd", "csrc", "em_wave.h")
 OUT = os.path.join(HERE, "sim", "_build", "libpnp_wave_sim.so")
 
 
 @pytest.fixture(scope="module")
 def sim():
-    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR)):
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(HDR), os.path.getmtime(HDR2)):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.check_call(["g++", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared",
                                "-Wno-unknown-pragmas", "-o", OUT, SRC])
@@ -89,3 +90,37 @@ def test_triangulation_matches_the_oracle_bit_for_bit(O, S, sim):
     sim.sim_triangulate(_dp(kf["kp_ref"]), _dp(kf["kp_cur"]), 700, _dp(k4), _dp(R), _dp(t), _dp(pp), _dp(pc))
     po, co = O.triangulate_points(kf["kp_ref"], kf["kp_cur"], kf["K"], R, t)
     assert np.array_equal(pp, po, equal_nan=True) and np.array_equal(pc, co, equal_nan=True)
+
+
+def _normalised(kf):
+    """findEssentialMat's normalisation: focal = (fx + fy) / 2, principal point through cv::Point2f."""
+    K = kf["K"]
+    focal = (K["fx"] + K["fy"]) / 2
+    c = np.array([np.float64(np.float32(K["cx"])), np.float64(np.float32(K["cy"]))])
+    q1 = (kf["kp_ref"].astype(np.float64) - c) / focal
+    q2 = (kf["kp_cur"].astype(np.float64) - c) / focal
+    return np.ascontiguousarray(q1), np.ascontiguousarray(q2), focal
+
+
+@pytest.mark.parametrize("seed,kw", [(8, {}), (9, dict(outlier_frac=0.5)), (10, dict(outlier_frac=0.0, pix_noise=0.0))])
+def test_essential_hypotheses_match_the_oracle_bit_for_bit(O, S, sim, seed, kw):
+    kf = S.keyframe_problem(n=400, seed=seed, **kw)
+    q1, q2, focal = _normalised(kf)
+    n, H = len(q1), 60
+    sub = O.pnp_subsets(n, H)                           # the same cv::RNG(-1) / getSubset stream
+    E = np.zeros((H, 10, 9))
+    nm = np.zeros(H, np.int32)
+    counts = np.zeros((H, 10), np.int32)
+    thr = 1.0 / focal
+    thr2 = np.float32(thr * thr)
+    sim.sim_em_hypotheses.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+    sim.sim_em_hypotheses(_dp(q1), _dp(q2), n, _dp(sub), H, thr2, _dp(E), _dp(nm), _dp(counts))
+    ref = O.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], kf["K"], 0.999, 1.0, max_iters=H)
+    run = ref["iters_run"]
+    assert np.array_equal(counts[:run], ref["counts"][:run])
+    for h in range(H):
+        Eo = O.five_point(q1[sub[h]], q2[sub[h]])
+        assert nm[h] == len(Eo), h
+        assert np.array_equal(E[h, :nm[h]].reshape(-1, 3, 3), Eo, equal_nan=True), h
+    assert nm.max() >= 2 and counts.max() > 0.4 * n
