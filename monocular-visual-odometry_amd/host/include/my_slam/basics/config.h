@@ -24,7 +24,9 @@ public:
             {"kpts_uniform_selection_grid_size", "16"}, {"kpts_uniform_selection_max_pts_per_grid", "8"},
             {"is_enable_ba", "true"}, {"num_prev_frames_to_opti_by_ba", "5"}, {"information_matrix", "1.0 0.0 0.0 1.0"},
             {"is_ba_fix_map_points", "true"}, {"feature_match_method_index_pnp", "1"},
-            {"max_matching_pixel_dist_in_pnp", "50"}, {"max_possible_dist_to_prev_keyframe", "0.3"}};
+            {"max_matching_pixel_dist_in_pnp", "50"}, {"max_possible_dist_to_prev_keyframe", "0.3"}, {"max_matching_pixel_dist_in_triangulation", "100"},
+            {"findEssentialMat_prob", "0.999"}, {"findEssentialMat_threshold", "1.0"}, {"min_triang_angle", "1.0"},
+            {"max_ratio_between_max_angle_and_median_angle", "20"}};
         return t;
     }
     static void set(const string& key, const string& value) { table()[key] = value; }

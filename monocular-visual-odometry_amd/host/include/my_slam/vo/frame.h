@@ -36,6 +36,7 @@ public:
     vector<cv::DMatch> inliers_matches_with_ref_;
     vector<cv::DMatch> inliers_matches_for_3d_;
     vector<cv::Point3f> inliers_pts3d_;
+    vector<double> triangulation_angles_of_inliers_;
     std::unordered_map<int, PtConn> inliers_to_mappt_connections_;  // curr idx -> idx in ref, and map
     vector<cv::DMatch> matches_with_map_;
 

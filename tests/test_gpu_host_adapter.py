@@ -135,3 +135,61 @@ def test_cpp_tracking_mirror_matches_oracle(mvo, O, tmp_path):
     # -- the literal cv::solvePnPRansac / cv::Rodrigues call on 5 pairs
     five = O.solve_pnp_ransac(pr["map_pos"][ids[:5]], px[:5], K)
     assert np.abs(R5 - O.rodrigues(five["rvec"])).max() < 1e-12 and np.abs(t5 - five["tvec"]).max() < 1e-12
+
+
+KEY_BIN = os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "tests", "test_keyframe")
+
+
+def test_keyframe_binary_is_built_and_links_only_the_hip_library():
+    assert os.path.exists(KEY_BIN), "run __graft_entry__.build()"
+    ldd = subprocess.run(["ldd", KEY_BIN], capture_output=True, text=True).stdout
+    assert "libmvo_hip.so" in ldd and "liboracle" not in ldd and "opencv" not in ldd.lower()
+
+
+@pytest.mark.gpu
+def test_cpp_keyframe_mirror_matches_oracle(mvo, O, tmp_path):
+    """my_slam/vo/keyframe.h run as vo_addFrame.cpp:96-118 runs: matchFeatures -> helperFindInlierMatchesByEpipolarCons
+    -> helperTriangulatePoints -> retainGoodTriangulationResult_."""
+    kf = mvo.synth.keyframe_problem(n=700, seed=51, outlier_frac=0.0)
+    rng = np.random.RandomState(4)
+    n = len(kf["kp_ref"])
+    d_ref = rng.randint(0, 256, (n, 32)).astype(np.uint8)
+    # the current keyframe sees 80 % of the points (descriptors with a few flipped bits, shuffled) plus clutter
+    seen = rng.permutation(n)[: int(0.8 * n)]
+    bits = np.unpackbits(d_ref[seen], axis=1)
+    bits ^= (rng.uniform(size=bits.shape) < 0.03).astype(np.uint8)
+    d_cur = np.concatenate([np.packbits(bits, axis=1), rng.randint(0, 256, (150, 32)).astype(np.uint8)])
+    kp_cur = np.concatenate([kf["kp_cur"][seen], rng.uniform(0, 480, (150, 2)).astype(np.float32)]).astype(np.float32)
+    scene, out = tmp_path / "kscene.bin", tmp_path / "kout.bin"
+    K = kf["K"]
+    with open(scene, "wb") as f:
+        f.write(np.array([n, len(kp_cur)], "<i4").tobytes())
+        f.write(np.array([K["fx"], K["fy"], K["cx"], K["cy"]], "<f8").tobytes())
+        f.write(np.ascontiguousarray(kf["T_w_ref"], "<f8").tobytes())
+        f.write(np.ascontiguousarray(kf["T_w_cur"], "<f8").tobytes())
+        f.write(kf["kp_ref"].tobytes())
+        f.write(d_ref.tobytes())
+        f.write(kp_cur.tobytes())
+        f.write(d_cur.tobytes())
+    r = subprocess.run([KEY_BIN, str(scene), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with open(out, "rb") as f:
+        matches = _read(f, O.DMATCH_DTYPE)
+        inl_matches = _read(f, O.DMATCH_DTYPE)
+        kept_matches = _read(f, O.DMATCH_DTYPE)
+        pts3d = _read(f, "<f4").reshape(-1, 3)
+        angles = _read(f, "<f8")
+        T = _read(f, "<f8").reshape(4, 4)
+    m_o = O.match_features(d_ref, d_cur, 1, 2.0, 1.0)
+    assert_struct_equal(matches, m_o, "matches_with_ref_")
+    a, b = kf["kp_ref"][m_o["queryIdx"]], kp_cur[m_o["trainIdx"]]
+    inl = O.find_essential_inliers(a, b, K)["inliers"]
+    assert np.array_equal(inl_matches["queryIdx"], m_o["queryIdx"][inl]) and np.array_equal(inl_matches["trainIdx"], m_o["trainIdx"][inl])
+    assert np.array_equal(inl_matches["distance"], m_o["distance"][inl])
+    T_o = np.linalg.inv(kf["T_w_cur"]) @ kf["T_w_ref"]
+    assert np.abs(T - T_o).max() < 1e-12
+    _, p_cur = O.triangulate_points(a[inl], b[inl], K, T[:3, :3], T[:3, 3])      # same T as the adapter used
+    keep, ang = O.retain_good_triangulation(p_cur, kf["T_w_cur"], kf["T_w_ref"])
+    assert np.array_equal(pts3d, p_cur[keep]) and np.array_equal(angles, ang[keep])
+    assert np.array_equal(kept_matches["queryIdx"], m_o["queryIdx"][inl][keep])
+    assert len(keep) > 0.5 * len(seen)
