@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--track", action="store_true",
                     help="also run the tracking rows every frame (map points in view -> match against the map -> "
                          "solvePnPRansac, vo.cpp:270-357); off by default: BASELINE.json's metric is extract+match+BA")
+    ap.add_argument("--keyframe-every", type=int, default=10,
+                    help="with --track: run the keyframe row (findEssentialMat inlier filter + triangulation + culling, "
+                         "vo_addFrame.cpp:93-118) on every N-th frame")
     ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=150)
@@ -95,6 +98,8 @@ class Shard:
             self.map = self.ctx.map_create()
             self.ctx.map_upload(self.map, tp["map_pos"], tp["map_desc"])
             self.n_inliers = 0
+            self.kf = mvo.synth.keyframe_problem(n=1000, seed=21 + shard_id, width=args.width, height=args.height, K=K)
+            self.n_tri = 0
         self.prev = None          # (device ptr, n) of the previous frame's descriptors
         self.traj = []
         self.n_kp = self.n_match = 0
@@ -120,6 +125,14 @@ class Shard:
             self.n_inliers = len(pose["inliers"])
         ctx.ba_solve_resident(self.ba)
         P, _, st = ctx.ba_fetch(self.ba, want_points=False)
+        if self.track is not None and self.frame_no % a.keyframe_every == 0:
+            # keyframe insertion after BA (vo_addFrame.cpp:93-118): epipolar inlier filter, triangulation, culling
+            kf = self.kf
+            inl = ctx.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], kf["K"])
+            Tk = kf["T_curr_to_prev"]
+            _, pc = ctx.triangulate_points(kf["kp_ref"][inl], kf["kp_cur"][inl], kf["K"], Tk[:3, :3], Tk[:3, 3])
+            keep, _ = self.mvo.retain_good_triangulation(pc, kf["T_w_cur"], kf["T_w_ref"])
+            self.n_tri = len(keep)
         self.n_kp = len(k)
         self.last_stats = st
         # trajectory row like vo_io.cpp:58-75: x y z then R column-major (newest frame of the window)
@@ -305,8 +318,11 @@ def main():
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
                        "keypoints": s0.n_kp, "matches": s0.n_match,
                        "ba_trials_per_solve": trials0 / nprof,
-                       "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers)"
-                                         % (len(s0.track["pts3d"]), s0.n_inliers)) if args.track else "off"},
+                       "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers) every "
+                                         "frame; keyframe row (findEssentialMat filter on 1000 matches + triangulation + "
+                                         "culling -> %d points) every %d frames"
+                                         % (len(s0.track["pts3d"]), s0.n_inliers, s0.n_tri, args.keyframe_every))
+                       if args.track else "off"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_baseline_all_threads": cpu_mt,
