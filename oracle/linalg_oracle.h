@@ -1,7 +1,7 @@
 // oracle/linalg_oracle.h -- small dense linear algebra shared by the tracking / keyframe oracles (pnp_oracle.cpp,
 // keyframe_oracle.cpp).  TEST INFRASTRUCTURE ONLY (see oracle.h).  This is OUR canonical arithmetic wherever OpenCV
 // calls cv::SVD / cv::solve(DECOMP_SVD) / cv::invert: a one-sided (Hestenes) Jacobi with OpenCV's rotation formulas
-// and 10*DBL_EPSILON test, round-robin pair order for 6, 10 and 12 rows, cyclic order otherwise, right singular vectors
+// and 10*DBL_EPSILON test, round-robin pair order for 6 and 12 rows, cyclic order otherwise, right singular vectors
 // from the accumulated rotations, stable descending order.
 #ifndef MVO_ORACLE_LINALG_H
 #define MVO_ORACLE_LINALG_H
@@ -99,7 +99,7 @@ inline void jacobi_svd(double* At, int n, int m, double* Vt, double* W) {
     const int max_iter = m > 30 ? m : 30;
     for (int it = 0; it < max_iter; it++) {
         bool changed = false;
-        if (n == 12 || n == 10 || n == 6) {
+        if (n == 12 || n == 6) {
             for (int r = 0; r < n - 1; r++)
                 for (int k = 0; k < n / 2; k++) {
                     int i, j;

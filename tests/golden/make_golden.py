@@ -54,6 +54,17 @@ def main():
                         view_px=vis_px, pts3d=tp["pts3d"], pts2d=tp["pts2d"], subsets=O.pnp_subsets(len(tp["pts3d"]), 40),
                         models=res["models"], counts=res["counts"], best_iter=res["best_iter"], iters_run=res["iters_run"],
                         inliers=res["inliers"], rvec=res["rvec"], tvec=res["tvec"])
+    # ---- keyframe row: 120 matches with 30 % wrong ones
+    kf = S.keyframe_problem(n=120, seed=77, outlier_frac=0.3)
+    kk4 = np.array([kf["K"][k] for k in ("fx", "fy", "cx", "cy")])
+    er = O.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], kf["K"])
+    Tk = kf["T_curr_to_prev"]
+    pp, pc = O.triangulate_points(kf["kp_ref"][er["inliers"]], kf["kp_cur"][er["inliers"]], kf["K"], Tk[:3, :3], Tk[:3, 3])
+    keep, ang = O.retain_good_triangulation(pc, kf["T_w_cur"], kf["T_w_ref"])
+    np.savez_compressed(os.path.join(HERE, "keyframe_120.npz"), kp_ref=kf["kp_ref"], kp_cur=kf["kp_cur"], K4=kk4,
+                        T_w_ref=kf["T_w_ref"], T_w_cur=kf["T_w_cur"], T_curr_to_prev=Tk, inliers=er["inliers"],
+                        counts=er["counts"][:er["iters_run"]], best=np.array([er["best_iter"], er["best_model"]]),
+                        pts_prev=pp, pts_curr=pc, keep=keep, angles=ang)
     print("golden fixtures written to", HERE)
 
 

@@ -56,6 +56,34 @@ def test_oracle_reproduces_tracking_golden(O):
     assert np.abs(res["rvec"] - t["rvec"]).max() < 1e-13 and np.abs(res["tvec"] - t["tvec"]).max() < 1e-13
 
 
+def test_oracle_reproduces_keyframe_golden(O):
+    g = _load("keyframe_120.npz")
+    K = _track_K(g)
+    er = O.find_essential_inliers(g["kp_ref"], g["kp_cur"], K)
+    assert np.array_equal(er["inliers"], g["inliers"]) and np.array_equal(er["counts"][:er["iters_run"]], g["counts"])
+    assert [er["best_iter"], er["best_model"]] == g["best"].tolist()
+    T = g["T_curr_to_prev"]
+    pp, pc = O.triangulate_points(g["kp_ref"][g["inliers"]], g["kp_cur"][g["inliers"]], K, T[:3, :3], T[:3, 3])
+    assert np.array_equal(pp, g["pts_prev"]) and np.array_equal(pc, g["pts_curr"])
+    keep, ang = O.retain_good_triangulation(pc, g["T_w_cur"], g["T_w_ref"])
+    assert np.array_equal(keep, g["keep"]) and np.abs(ang - g["angles"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_keyframe_golden(mvo, ctx):
+    g = _load("keyframe_120.npz")
+    K = _track_K(g)
+    inl = ctx.find_essential_inliers(g["kp_ref"], g["kp_cur"], K)
+    dbg = ctx.debug_essential()
+    assert np.array_equal(inl, g["inliers"]) and np.array_equal(dbg["counts"][:dbg["iters_run"]], g["counts"])
+    assert [dbg["best_iter"], dbg["best_model"]] == g["best"].tolist()
+    T = g["T_curr_to_prev"]
+    pp, pc = ctx.triangulate_points(g["kp_ref"][inl], g["kp_cur"][inl], K, T[:3, :3], T[:3, 3])
+    assert np.array_equal(pp, g["pts_prev"]) and np.array_equal(pc, g["pts_curr"])
+    keep, ang = mvo.retain_good_triangulation(pc, g["T_w_cur"], g["T_w_ref"])
+    assert np.array_equal(keep, g["keep"]) and np.abs(ang - g["angles"]).max() < 1e-12
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_tracking_golden(mvo, ctx):
     t = _load("track_300.npz")
