@@ -30,26 +30,35 @@ public:
         return t;
     }
     static void set(const string& key, const string& value) { table()[key] = value; }
-    // flat YAML subset: "key: value" lines, '#' comments, quotes stripped (nested dataset sections are ignored)
+    // YAML subset of config/config.yaml: "key: value" lines, '#' comments, quotes stripped; one level of nesting
+    // (the dataset sections "matlab:" / "fr1_desk:", config.yaml:12-47) is stored as "section.key".
     static void setParameterFile(const string& filename) {
         std::ifstream f(filename);
         if (!f) throw std::runtime_error("parameter file " + filename + " does not exist.");
-        string line;
+        string line, section;
+        auto trim = [](string& s) {
+            size_t a = s.find_first_not_of(" \t\""), b = s.find_last_not_of(" \t\"\r");
+            s = a == string::npos ? "" : s.substr(a, b - a + 1);
+        };
         while (std::getline(f, line)) {
             size_t h = line.find('#');
             if (h != string::npos) line.erase(h);
             size_t c = line.find(':');
-            if (c == string::npos || line.empty() || line[0] == ' ' || line[0] == '%') continue;
+            if (c == string::npos || line.empty() || line[0] == '%') continue;
+            const bool nested = line[0] == ' ' || line[0] == '\t';
             string k = line.substr(0, c), v = line.substr(c + 1);
-            auto trim = [](string& s) {
-                size_t a = s.find_first_not_of(" \t\""), b = s.find_last_not_of(" \t\"\r");
-                s = a == string::npos ? "" : s.substr(a, b - a + 1);
-            };
             trim(k);
             trim(v);
-            if (!k.empty() && !v.empty()) table()[k] = v;
+            if (k.empty()) continue;
+            if (!nested) section.clear();
+            if (v.empty()) {  // "matlab:" opens a section
+                if (!nested) section = k;
+                continue;
+            }
+            table()[nested && !section.empty() ? section + "." + k : k] = v;
         }
     }
+    static bool has(const string& key) { return table().find(key) != table().end(); }
     template <typename T>
     static T get(const string& key);
     static bool getBool(const string& key) {
