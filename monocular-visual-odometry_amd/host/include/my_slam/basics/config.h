@@ -26,7 +26,7 @@ public:
             {"is_ba_fix_map_points", "true"}, {"feature_match_method_index_pnp", "1"},
             {"max_matching_pixel_dist_in_pnp", "50"}, {"max_possible_dist_to_prev_keyframe", "0.3"}, {"max_matching_pixel_dist_in_triangulation", "100"},
             {"findEssentialMat_prob", "0.999"}, {"findEssentialMat_threshold", "1.0"}, {"min_triang_angle", "1.0"},
-            {"max_ratio_between_max_angle_and_median_angle", "20"}};
+            {"max_ratio_between_max_angle_and_median_angle", "20"}, {"min_dist_between_two_keyframes", "0.03"}};
         return t;
     }
     static void set(const string& key, const string& value) { table()[key] = value; }

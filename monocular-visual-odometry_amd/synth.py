@@ -232,3 +232,37 @@ def keyframe_problem(n=600, seed=21, width=640, height=480, K=FR1_K, pix_noise=0
     T_cur_to_ref = np.linalg.inv(T_cur) @ T_ref          # getMotionFromFrame1to2(curr, ref) = T_w_curr^-1 T_w_ref
     return dict(kp_ref=kp_ref.astype(np.float32), kp_cur=kp_cur.astype(np.float32), T_w_ref=T_ref, T_w_cur=T_cur,
                 T_curr_to_prev=T_cur_to_ref, K=K, p_ref=p_ref, p_cur=q_cur, inlier_gt=~bad, cols=width, rows=height)
+
+
+# ---------------------------------------------------------------- feature-level sequence (vo_addFrame.cpp:70-124)
+def feature_sequence(n_frames=30, n_points=5000, seed=61, width=640, height=480, K=FR1_K, step=0.03, pix_noise=0.3,
+                     bit_flip=0.02, clutter=150, max_kp=1200):
+    """A 3-D scene seen from a moving camera, as per-frame keypoints + descriptors (what Frame::calcKeyPoints /
+    calcDescriptors would deliver), with ground-truth poses.  Returns dict(K, cols, rows, frames=[dict(T_w_c, xy
+    [N,2] f32, desc [N,32] u8, point_id [N] (-1 = clutter))], points [P,3])."""
+    rng = np.random.RandomState(seed)
+    f, cx, cy = K["fx"], K["cx"], K["cy"]
+    pts = np.stack([rng.uniform(-3.0, 4.5, n_points), rng.uniform(-2.0, 2.0, n_points), rng.uniform(1.2, 5.0, n_points)], 1)
+    pdesc = rng.randint(0, 256, (n_points, 32)).astype(np.uint8)
+    frames = []
+    for i in range(n_frames):
+        T = np.eye(4)
+        T[:3, :3] = _rot([0.05, 1.0, 0.02], np.deg2rad(0.4 * i))
+        T[:3, 3] = [step * i, 0.004 * np.sin(0.5 * i), 0.006 * i]
+        Tcw = np.linalg.inv(T)
+        q = pts @ Tcw[:3, :3].T + Tcw[:3, 3]
+        u = f * q[:, 0] / q[:, 2] + cx
+        v = K["fy"] * q[:, 1] / q[:, 2] + cy
+        vis = np.nonzero((q[:, 2] > 0.3) & (u > 8) & (v > 8) & (u < width - 8) & (v < height - 8))[0]
+        vis = vis[rng.permutation(len(vis))][:max_kp]
+        xy = np.stack([u[vis], v[vis]], 1) + rng.normal(0, pix_noise, (len(vis), 2))
+        bits = np.unpackbits(pdesc[vis], axis=1)
+        bits ^= (rng.uniform(size=bits.shape) < bit_flip).astype(np.uint8)
+        d = np.packbits(bits, axis=1)
+        cxy = np.stack([rng.uniform(8, width - 8, clutter), rng.uniform(8, height - 8, clutter)], 1)
+        cd = rng.randint(0, 256, (clutter, 32)).astype(np.uint8)
+        order = rng.permutation(len(vis) + clutter)
+        frames.append(dict(T_w_c=T, xy=np.concatenate([xy, cxy])[order].astype(np.float32),
+                           desc=np.ascontiguousarray(np.concatenate([d, cd])[order]),
+                           point_id=np.concatenate([vis, -np.ones(clutter, int)])[order]))
+    return dict(K=K, cols=width, rows=height, frames=frames, points=pts)
