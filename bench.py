@@ -14,6 +14,7 @@ The only collective is one all_gather of the per-shard trajectories (frames x 12
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=12, help="sequence shards in flight per GPU")
     ap.add_argument("--ba", default="full", choices=["full", "full_fix0", "pose_only"],
                     help="full = points + poses free (reference is_fix_map_pts=false branch, no vertex fixed)")
+    ap.add_argument("--python-loop", action="store_true",
+                    help="drive the per-frame C-ABI calls from Python threads instead of the native frame loop "
+                         "(host/driver/frame_loop.cpp); the same calls, but serialised by the interpreter lock")
     ap.add_argument("--track", action="store_true",
                     help="also run the tracking rows every frame (map points in view -> match against the map -> "
                          "solvePnPRansac, vo.cpp:270-357); off by default: BASELINE.json's metric is extract+match+BA")
@@ -70,6 +74,38 @@ def ba_kwargs(kind, n_poses):
         f[0] = 1
         return dict(fix_points=False, pose_fixed=f)
     return dict(fix_points=False)
+
+
+class FrameLoopCfg(C.Structure):  # host/driver/frame_loop.cpp: struct frame_loop_cfg
+    _fields_ = [("ctx", C.c_void_p), ("d_frames", C.POINTER(C.c_void_p)), ("n_frames", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("stride", C.c_int32), ("channels", C.c_int32), ("max_kp", C.c_int32),
+                ("ba", C.c_void_p), ("n_poses", C.c_int32), ("track", C.c_int32), ("keyframe_every", C.c_int32),
+                ("map", C.c_void_p), ("n_map", C.c_int32), ("T_w_c", C.c_void_p), ("K4", C.c_double * 4),
+                ("pts3d", C.c_void_p), ("pts2d", C.c_void_p), ("n_pairs", C.c_int32), ("kf_ref", C.c_void_p),
+                ("kf_cur", C.c_void_p), ("kf_n", C.c_int32), ("kf_T_curr_to_prev", C.c_void_p),
+                ("kf_T_w_cur", C.c_void_p), ("kf_T_w_ref", C.c_void_p)]
+
+
+class FrameLoopState(C.Structure):
+    _fields_ = [("prev_desc", C.c_void_p), ("prev_n", C.c_int32), ("frame_no", C.c_int32), ("n_kp", C.c_int32),
+                ("n_match", C.c_int32), ("n_inliers", C.c_int32), ("n_tri", C.c_int32), ("ba_trials", C.c_int32),
+                ("ba_iterations", C.c_int32)]
+
+
+_frame_loop = None
+
+
+def frame_loop_lib():
+    """host/driver/libmvo_frame_loop.so (built by __graft_entry__.build()); fails loudly when missing."""
+    global _frame_loop
+    if _frame_loop is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "monocular-visual-odometry_amd", "host", "driver",
+                            "libmvo_frame_loop.so")
+        if not os.path.exists(path):
+            raise SystemExit("native frame loop %s is missing -- run __graft_entry__.build()" % path)
+        _frame_loop = C.CDLL(path)
+        _frame_loop.frame_loop_run.argtypes = [C.POINTER(FrameLoopCfg), C.POINTER(FrameLoopState), C.c_int, C.c_void_p]
+    return _frame_loop
 
 
 class Shard:
@@ -104,6 +140,55 @@ class Shard:
         self.traj = []
         self.n_kp = self.n_match = 0
         self.frame_no = 0
+        self.native = None
+        if not args.python_loop:
+            self._setup_native(K)
+
+    def _setup_native(self, K):
+        """Everything the native frame loop needs, as plain pointers (kept alive on self)."""
+        a = self.args
+        c = FrameLoopCfg()
+        c.ctx = self.ctx.h
+        self._fr = (C.c_void_p * len(self.dev_frames))(*[t.data_ptr() for t in self.dev_frames])
+        c.d_frames = C.cast(self._fr, C.POINTER(C.c_void_p))
+        c.n_frames, c.width, c.height, c.stride, c.channels, c.max_kp = len(self.dev_frames), a.width, a.height, a.width * 3, 3, a.max_kp
+        c.ba = self.ba[0]
+        c.n_poses = self.ba[1]
+        c.track = 1 if self.track is not None else 0
+        c.keyframe_every = a.keyframe_every
+        for i, k in enumerate(("fx", "fy", "cx", "cy")):
+            c.K4[i] = K[k]
+        if self.track is not None:
+            tp, kf = self.track, self.kf
+            self._keep = [np.ascontiguousarray(tp["T_w_c"], np.float64), np.ascontiguousarray(tp["pts3d"], np.float32),
+                          np.ascontiguousarray(tp["pts2d"], np.float32), np.ascontiguousarray(kf["kp_ref"], np.float32),
+                          np.ascontiguousarray(kf["kp_cur"], np.float32), np.ascontiguousarray(kf["T_curr_to_prev"], np.float64),
+                          np.ascontiguousarray(kf["T_w_cur"], np.float64), np.ascontiguousarray(kf["T_w_ref"], np.float64)]
+            ptr = [x.ctypes.data_as(C.c_void_p) for x in self._keep]
+            c.map, c.n_map = self.map, len(tp["map_pos"])
+            c.T_w_c, c.pts3d, c.pts2d, c.n_pairs = ptr[0], ptr[1], ptr[2], len(tp["pts3d"])
+            c.kf_ref, c.kf_cur, c.kf_n = ptr[3], ptr[4], len(kf["kp_ref"])
+            c.kf_T_curr_to_prev, c.kf_T_w_cur, c.kf_T_w_ref = ptr[5], ptr[6], ptr[7]
+        self.native = c
+        self.nstate = FrameLoopState()
+
+    def run(self, n):
+        """n frames: one call into the native loop (or n Python-driven steps with --python-loop)."""
+        if self.native is None:
+            for _ in range(n):
+                self.step()
+            return
+        out = np.zeros((n, 12))
+        t0, i0 = self.nstate.ba_trials, self.nstate.ba_iterations
+        r = frame_loop_lib().frame_loop_run(C.byref(self.native), C.byref(self.nstate), n, out.ctypes.data_as(C.c_void_p))
+        if r != 0:
+            raise RuntimeError("frame loop failed (%d): %s" % (r, (self.ctx.lib.mvo_last_error(self.ctx.h) or b"").decode()))
+        self.traj.extend(list(out))
+        st = self.nstate
+        self.n_kp, self.n_match, self.frame_no = st.n_kp, st.n_match, st.frame_no
+        if self.track is not None:
+            self.n_inliers, self.n_tri = st.n_inliers, st.n_tri
+        self.last_stats = {"trials": (st.ba_trials - t0) / max(n, 1), "iterations": (st.ba_iterations - i0) / max(n, 1)}
 
     def step(self):
         a = self.args
@@ -169,13 +254,13 @@ def gather_trajectories(dist, traj, device):
 
 
 def run_steps(shards, n):
-    """Every shard advances n frames on its own thread (ctypes releases the GIL inside the library)."""
+    """Every shard advances n frames on its own thread: one call into the native frame loop each (the GIL is
+    released for its whole duration), or Python-driven steps with --python-loop."""
     errs = []
 
     def work(s):
         try:
-            for _ in range(n):
-                s.step()
+            s.run(n)
         except Exception as e:  # noqa: BLE001
             errs.append(e)
 
@@ -267,7 +352,7 @@ def main():
         nprof = min(20, max(args.steps, 5))
         trials0 = 0
         for _ in range(nprof):
-            s0.step()
+            s0.run(1)
             trials0 += s0.last_stats["trials"]
         prof = s0.ctx.profile_get()
         s0.ctx.profile_enable(False)
@@ -316,6 +401,7 @@ def main():
                                                           args.ba_poses, args.ba, args.ba_poses, args.ba_points,
                                                           len(s0.pb["edge_pose"])),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
+                       "frame_loop": "python threads" if args.python_loop else "native (host/driver/frame_loop.cpp)",
                        "keypoints": s0.n_kp, "matches": s0.n_match,
                        "ba_trials_per_solve": trials0 / nprof,
                        "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers) every "
