@@ -542,10 +542,10 @@ int mvo_find_essential_inliers(mvo_ctx* ctx, const float* kp_prev, const float* 
     const double* d_q2 = s->d_emq + 2 * (size_t)n;
     // The hypotheses are evaluated in growing chunks; after each chunk the sequential bookkeeping of
     // RANSACPointSetRegistrator::run is advanced over the new counts until the loop's own stopping rule is met.
-    const int chunk_end[3] = {64, 256, kMaxIters};
+    const int chunk_end[2] = {256, kMaxIters};  // a chunk costs ~0.25 ms whatever its size (one wave per hypothesis)
     int evaluated = 0, niters = total, max_good = 0, it = 0, best_it = -1, best_m = -1;
     bool first_wait = true;
-    for (int c = 0; c < 3 && it < niters; ++c) {
+    for (int c = 0; c < 2 && it < niters; ++c) {
         const int end = std::min(chunk_end[c], total);
         if (end <= evaluated) continue;
         if ((r = track_launch_em_hypotheses(ctx, d_q1, d_q2, n, s->d_em_subsets + 5 * (size_t)evaluated, end - evaluated, thr2,
