@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=12, help="sequence shards in flight per GPU")
     ap.add_argument("--ba", default="full", choices=["full", "full_fix0", "pose_only"],
                     help="full = points + poses free (reference is_fix_map_pts=false branch, no vertex fixed)")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="diagnostic: HIP-event profiling on every shard DURING the timed region; prints the average "
+                         "k_ba_lm duration under load to stderr (adds event overhead to the measured value)")
     ap.add_argument("--python-loop", action="store_true",
                     help="drive the per-frame C-ABI calls from Python threads instead of the native frame loop "
                          "(host/driver/frame_loop.cpp); the same calls, but serialised by the interpreter lock")
@@ -325,6 +328,10 @@ def main():
             dist.barrier()
 
     run_steps(shards, args.warmup)
+    if args.profile_all:
+        for s in shards:
+            s.ctx.profile_enable(True)
+            s.ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     run_steps(shards, args.steps)
@@ -332,6 +339,17 @@ def main():
         s.ctx.synchronize()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    if args.profile_all:
+        tot = {}
+        for s in shards:
+            for k, (n_, ms) in s.ctx.profile_get().items():
+                a = tot.setdefault(k, [0, 0.0])
+                a[0] += n_
+                a[1] += ms
+            s.ctx.profile_enable(False)
+        print("under load (%d shards): " % len(shards) + ", ".join("%s %.1f us" % (k, 1e3 * v[1] / max(v[0], 1))
+                                                                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])),
+              file=sys.stderr)
     elapsed = max_over_ranks(dist, t1 - t0, "cuda")
     frames_total = world * args.streams * args.steps
     value = frames_total / elapsed
