@@ -218,3 +218,47 @@ def test_tracking_properties_full_size(mvo, ctx):
     for o in outs:
         assert o is not None and np.array_equal(o["inliers"], res["inliers"])
         assert np.array_equal(o["rvec"], res["rvec"]) and np.array_equal(o["tvec"], res["tvec"])
+
+
+@settings(max_examples=20, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), yaw=st.floats(-0.2, 0.2), tx=st.floats(0.05, 0.5), tz=st.floats(-0.2, 0.2))
+def test_five_point_candidates_are_essential_matrices(seed, yaw, tx, tz):
+    """Whatever the motion: every candidate of the five-point kernel satisfies the five epipolar constraints, has
+    singular values (s, s, 0) and unit Frobenius norm; for exact data one of them is [t]x R up to sign."""
+    from conftest import graft
+    O = graft.load_oracle()
+    rng = np.random.RandomState(seed)
+    c, s = np.cos(yaw), np.sin(yaw)
+    R = np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    t = np.array([tx, 0.02, tz])
+    X = np.stack([rng.uniform(-1, 1, 5), rng.uniform(-0.7, 0.7, 5), rng.uniform(1.5, 5, 5)], 1)
+    Y = X @ R.T + t
+    x1, x2 = X[:, :2] / X[:, 2:], Y[:, :2] / Y[:, 2:]
+    E = O.five_point(x1, x2)
+    Et = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+    Et /= np.linalg.norm(Et)
+    best = 1.0
+    for e in E:
+        assert abs(np.linalg.norm(e) - 1) < 1e-12
+        res = np.abs(np.einsum("ni,ij,nj->n", np.c_[x2, np.ones(5)], e, np.c_[x1, np.ones(5)])).max()
+        sv = np.linalg.svd(e, compute_uv=False)
+        assert res < 1e-7 and abs(sv[0] - sv[1]) < 1e-5 and sv[2] < 1e-5
+        best = min(best, np.abs(e - Et).max(), np.abs(e + Et).max())
+    assert len(E) <= 10 and (len(E) == 0 or best < 1.0)    # (ill-conditioned samples may miss the true root)
+
+
+@settings(max_examples=20, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), n=st.integers(1, 60), baseline=st.floats(0.05, 0.6))
+def test_triangulation_reprojects_onto_the_measurements(seed, n, baseline):
+    """helperTriangulatePoints: for noise-free matches the triangulated point reprojects onto both pixels."""
+    from conftest import graft
+    O = graft.load_oracle()
+    S = graft.load_package().synth
+    kf = S.keyframe_problem(n=n, seed=seed, pix_noise=0.0, outlier_frac=0.0, baseline=baseline)
+    T, K = kf["T_curr_to_prev"], kf["K"]
+    pp, pc = O.triangulate_points(kf["kp_ref"], kf["kp_cur"], K, T[:3, :3], T[:3, 3])
+    for p, kp in ((pp, kf["kp_ref"]), (pc, kf["kp_cur"])):
+        u = K["fx"] * p[:, 0] / p[:, 2] + K["cx"]
+        v = K["fy"] * p[:, 1] / p[:, 2] + K["cy"]
+        assert np.abs(np.stack([u, v], 1) - kp).max() < 0.05       # float32 pixels / points
+    assert (pp[:, 2] > 0).all() and (pc[:, 2] > 0).all()
