@@ -81,6 +81,10 @@ struct BaDev {
     double* xSc;              // G x 4: initial chi2 (slot 0) and landmark max diagonal (slot 2), counter-barrier phases
     unsigned* barrier;        // monotonically increasing arrival counter (zeroed before every launch)
     BaStatsDev* stats;
+    // pinned host mirrors of stats / poses_out (written next to the device copies at the end of the solve, so that
+    // fetching the result needs a synchronisation but no copy dispatch); may be null
+    BaStatsDev* h_stats;
+    double* h_poses;
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -1140,6 +1144,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
         }
         o[12] = o[13] = o[14] = 0;
         o[15] = 1;
+        if (B.h_poses) {
+            double* ho = B.h_poses + 16 * tid;
+            for (int k = 0; k < 16; ++k) ho[k] = o[k];
+        }
     }
     for (int i = tid; i < 3 * Lg; i += BA_THREADS) B.pts_out[3 * (size_t)pt_lo + i] = W.pts[i];
     if (g == 0 && tid == 0) {
@@ -1152,6 +1160,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ 
         B.stats->lambda_final = lambda;
         ph[11] = (long long)__builtin_amdgcn_s_memtime() - ph_start;
         for (int i = 0; i < BA_NPHASE; ++i) B.stats->phase[i] = ph[i];
+        if (B.h_stats) *B.h_stats = *B.stats;
     }
 }
 
@@ -1219,6 +1228,8 @@ struct mvo_ba_handle {
     size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0, o_desc = 0, zero_bytes = 64;
     size_t lds = 16;
     bool fix_points = false;
+    char* pin = nullptr;       // pinned host memory: BaStatsDev, then F x 16 doubles
+    int uploaded_mfma = -1;    // value of B.use_mfma in the device copy of the descriptor
 };
 
 int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out) {
@@ -1434,6 +1445,19 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     B.xSc = (double*)(D + o_xs);
     B.barrier = (unsigned*)(D + o_bar);
     B.stats = (BaStatsDev*)(D + o_stats);
+    {
+        const size_t pin_bytes = ((sizeof(BaStatsDev) + 255) & ~(size_t)255) + (size_t)std::max(F, 1) * 128;
+        hipError_t pe = hipHostMalloc((void**)&H->pin, pin_bytes, hipHostMallocDefault);
+        if (pe != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(H->dev);
+            delete H;
+            return mvo_set_err(ctx, MVO_ERR_HIP, "hipHostMalloc (BA result mirror)", pe);
+        }
+        std::memset(H->pin, 0, pin_bytes);
+        B.h_stats = (BaStatsDev*)H->pin;
+        B.h_poses = (double*)(H->pin + ((sizeof(BaStatsDev) + 255) & ~(size_t)255));
+    }
     H->F = F;
     H->L = L;
     H->o_stats = o_stats;
@@ -1469,7 +1493,11 @@ int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
         }
     }
     if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, H->zero_bytes, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc, &H->B, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+    if (H->uploaded_mfma != H->B.use_mfma) {  // the descriptor is constant but for the debug knob: upload it once
+        MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc, &H->B, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));  // (&H->B is pageable: the copy must not outlive a change)
+        H->uploaded_mfma = H->B.use_mfma;
+    }
     {
         ProfScope ps(ctx, "k_ba_lm");
         hipLaunchKernelGGL(k_ba_lm, dim3(H->B.G), dim3(BA_THREADS), H->lds, ctx->stream,
@@ -1480,20 +1508,15 @@ int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
 }
 
 int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* points, mvo_ba_stats* st) {
-    const size_t need = sizeof(BaStatsDev) + (size_t)H->F * 128 + (size_t)H->L * 24 + 768;
-    int r = mvo_ensure_pinned(ctx, need);
-    if (r) return r;
-    uint8_t* h = ctx->h_pin;
-    uint8_t* hp = h + 256;
-    uint8_t* hx = hp + (((size_t)H->F * 128 + 255) & ~(size_t)255);
     const bool ran = !(H->F == 0 && (H->L == 0 || H->fix_points));
     if (st) std::memset(st, 0, sizeof(*st));
-    if (ran) {
-        MVO_HIP(hipMemcpyAsync(h, H->dev + H->o_stats, sizeof(BaStatsDev), hipMemcpyDeviceToHost, ctx->stream));
-        if (poses && H->F)
-            MVO_HIP(hipMemcpyAsync(hp, H->dev + H->o_pout, (size_t)H->F * 128, hipMemcpyDeviceToHost, ctx->stream));
-        if (points && H->L && !H->fix_points)
-            MVO_HIP(hipMemcpyAsync(hx, H->dev + H->o_pts, (size_t)H->L * 24, hipMemcpyDeviceToHost, ctx->stream));
+    const bool want_pts = ran && points && H->L && !H->fix_points;
+    uint8_t* hx = nullptr;
+    if (want_pts) {  // landmarks are the only part that still travels by copy
+        int r = mvo_ensure_pinned(ctx, (size_t)H->L * 24 + 256);
+        if (r) return r;
+        hx = ctx->h_pin;
+        MVO_HIP(hipMemcpyAsync(hx, H->dev + H->o_pts, (size_t)H->L * 24, hipMemcpyDeviceToHost, ctx->stream));
     }
     hipError_t sync_err = hipStreamSynchronize(ctx->stream);
     if (H->tokens) {
@@ -1501,6 +1524,8 @@ int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* point
         H->tokens = 0;
     }
     MVO_HIP(sync_err);
+    const uint8_t* h = (const uint8_t*)H->B.h_stats;   // stats and poses were written by the kernel itself
+    const uint8_t* hp = (const uint8_t*)H->B.h_poses;
     if (!ran) return MVO_OK;
     const BaStatsDev* s = (const BaStatsDev*)h;
     for (int i = 0; i < BA_NPHASE && i < 16; ++i) ctx->ba_phase[i] = s->phase[i];
@@ -1523,6 +1548,7 @@ void ba_release_device(mvo_ba_handle* H) {
     if (!H) return;
     if (H->tokens) budget_release(H->device, H->tokens);  // (the caller has synchronised the stream)
     if (H->dev) (void)hipFree(H->dev);
+    if (H->pin) (void)hipHostFree(H->pin);
     delete H;
 }
 

@@ -142,7 +142,10 @@ __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__
     }
 }
 
-int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out) {
+// d_out: device scratch (partials behind nq x 4 int32); final (optional): where the merged (idx, dist) block goes --
+// a pinned host buffer lets the merge kernel deliver the result itself (no copy dispatch on the frame's critical path)
+int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out,
+                      int32_t* final_out) {
     if (nq <= 0) return MVO_OK;
     // d_part: MK_SLICES x nq int4 partials live behind the nq x 4 int32 result block
     int4* d_part = reinterpret_cast<int4*>(d_out + 4 * (size_t)nq);
@@ -153,8 +156,9 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
     }
     {
         ProfScope ps(ctx, "k_knn2_merge");
-        hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 7) / 8), dim3(256), 0, ctx->stream, d_part, nq, d_out,
-                           d_out + 2 * (size_t)nq);
+        int32_t* dst = final_out ? final_out : d_out;
+        hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 7) / 8), dim3(256), 0, ctx->stream, d_part, nq, dst,
+                           dst + 2 * (size_t)nq);
     }
     MVO_HIP(hipGetLastError());
     return MVO_OK;

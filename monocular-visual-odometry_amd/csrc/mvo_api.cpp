@@ -288,10 +288,10 @@ static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
 
 static int knn2_common(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* idx,
                        int32_t* dist) {
-    int r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout);
+    // the merge kernel writes the nq x (idx[2], dist[2]) block straight into the pinned staging buffer
+    int r = mvo_ensure_pinned(ctx, (size_t)nq * 16);
     if (r) return r;
-    if ((r = mvo_ensure_pinned(ctx, (size_t)nq * 16))) return r;
-    MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_mout, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if ((r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout, reinterpret_cast<int32_t*>(ctx->h_pin)))) return r;
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) mvo_prof_collect(ctx);
     std::memcpy(idx, ctx->h_pin, (size_t)nq * 8);

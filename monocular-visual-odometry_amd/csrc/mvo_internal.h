@@ -156,9 +156,10 @@ int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes);
 int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int channels, int nlevels);
 int orb_launch_detect(mvo_ctx* ctx);
 int orb_launch_blur(mvo_ctx* ctx, int nlevels);
-int orb_launch_brief(mvo_ctx* ctx, int n);
+int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps);
 // match_kernels.hip
-int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out);
+int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out,
+                      int32_t* final_out);
 int match_launch_radius_l1(mvo_ctx* ctx, const uint8_t* d_q, const float* d_qxy, int nq, const uint8_t* d_t,
                            const float* d_txy, int nt, float max_px, int32_t* d_out);
 // track_kernels.hip

@@ -284,13 +284,16 @@ int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int
         if (hk[i].cx < -12 || hk[i].cx > L.w + 11 || hk[i].cy < -12 || hk[i].cy > L.h + 11)
             return mvo_set_err(ctx, MVO_ERR_INVALID, "keypoint outside its pyramid level", hipSuccess);
     }
-    MVO_HIP(hipMemcpyAsync(ctx->d_kp, hk, (size_t)n * sizeof(DevDescKp), hipMemcpyHostToDevice, ctx->stream));
-    if ((r = orb_launch_brief(ctx, n))) return r;
+    // the kernel reads the 16-byte keypoint records straight from the pinned staging buffer (one load per wave): no
+    // upload dispatch on the frame's critical path; the buffer is not touched again before the synchronisation below
+    if ((r = orb_launch_brief(ctx, n, hk))) return r;
     if (desc_host) {
         uint8_t* hd = ctx->h_pin + (size_t)n * sizeof(DevDescKp);
         MVO_HIP(hipMemcpyAsync(hd, ctx->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
         MVO_HIP(hipStreamSynchronize(ctx->stream));
         std::memcpy(desc_host, hd, (size_t)n * 32);
+    } else {
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
     }
     (void)w;
     (void)h;

@@ -559,11 +559,10 @@ int orb_launch_blur(mvo_ctx* ctx, int nlevels) {
     return MVO_OK;
 }
 
-int orb_launch_brief(mvo_ctx* ctx, int n) {
+int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps) {
     if (n <= 0) return MVO_OK;
     ProfScope ps(ctx, "k_brief");
-    hipLaunchKernelGGL(k_brief, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_blur, ctx->d_kp, ctx->d_desc,
-                       ctx->pyr, n);
+    hipLaunchKernelGGL(k_brief, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_blur, kps, ctx->d_desc, ctx->pyr, n);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }
