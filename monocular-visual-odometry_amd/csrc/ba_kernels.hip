@@ -85,6 +85,11 @@ struct BaDev {
     // fetching the result needs a synchronisation but no copy dispatch); may be null
     BaStatsDev* h_stats;
     double* h_poses;
+    // The exchange region (barrier counter | summed-entry granules | chi2 granules | partial granules) must be zero
+    // when a launch starts.  There are two of them, used by alternate launches: every launch clears the OTHER one
+    // in its prologue (nobody reads it meanwhile), so no memset dispatch precedes the kernel.
+    u64* zero_other;
+    unsigned zero_words;
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -591,6 +596,8 @@ __device__ void schur_valu(const BaDev& B, const WgLds& W, int Lg) {
 
 __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(const BaDev* __restrict__ Bp) {
     const BaDev& B = *Bp;
+    for (unsigned i = blockIdx.x * BA_THREADS + threadIdx.x; i < B.zero_words; i += gridDim.x * BA_THREADS)
+        B.zero_other[i] = 0;  // the other launch parity's exchange region (see BaDev::zero_other)
     extern __shared__ __attribute__((aligned(16))) double dyn[];
     __shared__ double sP[BA_MAX_POSES * 8], sPbak[BA_MAX_POSES * 8];  // q[4] t[3] pad
     __shared__ double sR[BA_MAX_POSES * 9], sT[BA_MAX_POSES * 3];
@@ -1225,7 +1232,8 @@ struct mvo_ba_handle {
     size_t bytes = 0;
     BaDev B{};
     int F = 0, L = 0;
-    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0, o_desc = 0, zero_bytes = 64;
+    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_bar = 0, o_desc = 0, zero_bytes = 64, o_region1 = 0;
+    int parity = 0;  // which exchange region / descriptor the next launch uses
     size_t lds = 16;
     bool fix_points = false;
     char* pin = nullptr;       // pinned host memory: BaStatsDev, then F x 16 doubles
@@ -1353,12 +1361,13 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     const size_t o_pout = cv.take((size_t)F * 128), o_pts = cv.take((size_t)L * 24);
     const size_t o_xh = cv.take((size_t)G * F * 49 * 8 + 8);
 
-    const size_t o_xs = cv.take((size_t)G * 32), o_desc = cv.take(sizeof(BaDev));
+    const size_t o_xs = cv.take((size_t)G * 32), o_desc = cv.take(2 * ((sizeof(BaDev) + 255) & ~(size_t)255));
     // zeroed before every launch: barrier counter | summed-entry granules | chi2 granules (contiguous)
     const size_t npk_h = ((size_t)n * (n + 1) / 2 + n + 15) & ~(size_t)15;
     const size_t o_bar = cv.take(256), o_xr = cv.take(npk_h * 16), o_xc = cv.take((size_t)2 * G * 4 * 8);
     const size_t o_xg = cv.take((size_t)G * npk_h * 16);
     const size_t zero_bytes = cv.off - o_bar;
+    const size_t o_region1 = cv.take(zero_bytes);  // the second exchange region (same layout)
     const size_t total = cv.off;
     mvo_ba_handle* H = new mvo_ba_handle();
     hipError_t he = hipMalloc((void**)&H->dev, total);
@@ -1466,6 +1475,13 @@ int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out
     H->o_bar = o_bar;
     H->o_desc = o_desc;
     H->zero_bytes = zero_bytes;
+    H->o_region1 = o_region1;
+    B.zero_other = (u64*)(D + o_region1);
+    B.zero_words = (unsigned)(zero_bytes / 8);
+    // both regions start out clean
+    MVO_HIP(hipMemsetAsync(D + o_bar, 0, zero_bytes, ctx->stream));
+    MVO_HIP(hipMemsetAsync(D + o_region1, 0, zero_bytes, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
     H->fix_points = p->fix_points != 0;
     H->lds = wg_lds_bytes(n, ntile, nfree, maxEg, maxLg, p->fix_points);
     H->device = ctx->device;
@@ -1492,16 +1508,25 @@ int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
             attr_done[H->device & 15] = true;
         }
     }
-    if (H->B.G > 1) MVO_HIP(hipMemsetAsync(H->dev + H->o_bar, 0, H->zero_bytes, ctx->stream));
-    if (H->uploaded_mfma != H->B.use_mfma) {  // the descriptor is constant but for the debug knob: upload it once
+    const size_t desc_stride = (sizeof(BaDev) + 255) & ~(size_t)255;
+    if (H->uploaded_mfma != H->B.use_mfma) {  // the descriptors are constant but for the debug knob: upload them once
+        BaDev other = H->B;  // parity 1: the exchange pointers moved into the second region, clears the first
+        const ptrdiff_t shift = (ptrdiff_t)H->o_region1 - (ptrdiff_t)H->o_bar;
+        other.barrier = (unsigned*)((char*)H->B.barrier + shift);
+        other.xRg = (u64*)((char*)H->B.xRg + shift);
+        other.xCg = (u64*)((char*)H->B.xCg + shift);
+        other.xGg = (u64*)((char*)H->B.xGg + shift);
+        other.zero_other = (u64*)(H->dev + H->o_bar);
         MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc, &H->B, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
-        MVO_HIP(hipStreamSynchronize(ctx->stream));  // (&H->B is pageable: the copy must not outlive a change)
+        MVO_HIP(hipMemcpyAsync(H->dev + H->o_desc + desc_stride, &other, sizeof(BaDev), hipMemcpyHostToDevice, ctx->stream));
+        MVO_HIP(hipStreamSynchronize(ctx->stream));  // (pageable sources)
         H->uploaded_mfma = H->B.use_mfma;
     }
+    const char* d_desc = H->dev + H->o_desc + (H->parity ? desc_stride : 0);
+    H->parity ^= 1;
     {
         ProfScope ps(ctx, "k_ba_lm");
-        hipLaunchKernelGGL(k_ba_lm, dim3(H->B.G), dim3(BA_THREADS), H->lds, ctx->stream,
-                           (const BaDev*)(H->dev + H->o_desc));
+        hipLaunchKernelGGL(k_ba_lm, dim3(H->B.G), dim3(BA_THREADS), H->lds, ctx->stream, (const BaDev*)d_desc);
     }
     MVO_HIP(hipGetLastError());
     return MVO_OK;
