@@ -144,6 +144,18 @@ typedef struct {
  * src/vo/vo.cpp:458-462). */
 int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
 
+/* The same call in two halves, so that the host thread can do other work (e.g. extract the next frame on another
+ * ctx) while the window is being solved: _begin builds the window, uploads it and queues the launch, _end blocks
+ * until it is done and writes poses / points / stats back like mvo_bundle_adjustment.  One solve in flight per ctx;
+ * `problem` must stay valid between the two calls. */
+int mvo_bundle_adjustment_begin(mvo_ctx* ctx, const mvo_ba_problem* problem);
+int mvo_bundle_adjustment_end(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
+/* n independent windows (e.g. the windows of n sequences) solved in one grid (8 windows x 32 workgroups fill the 256
+ * CUs; more than 8 are split over consecutive launches).  Same results as n mvo_bundle_adjustment calls.
+ * Concurrency note: every BA launch of the process is issued by one service thread per device, which also batches
+ * windows submitted by different ctx / host threads at the same time -- callers need no co-ordination. */
+int mvo_ba_solve_batch(mvo_ctx* ctx, mvo_ba_problem* problems, int n, mvo_ba_stats* stats);
+
 /* The same solve with the window resident in HBM: mvo_ba_prepare uploads the graph once (inputs + the
  * pose / point adjacency the kernels need), mvo_ba_solve_resident runs one full optimize(50) from the
  * resident initial state (asynchronous on the ctx stream; may be repeated), mvo_ba_fetch copies the
@@ -211,6 +223,9 @@ int mvo_rodrigues(const double* rvec, double* R);
 int mvo_invert_pose(const double* T, double* T_inv);
 
 /* ---- measurement --------------------------------------------------------------------------- */
+/* BA launches issued on `device` by this process since the last reset: number of launches, windows solved by them,
+ * and the sum of the launch durations (HIP events on the launch stream, milliseconds). */
+int mvo_ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset);
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per
  * kernel name until reset. */
 int mvo_profile_enable(mvo_ctx* ctx, int on);
@@ -229,6 +244,14 @@ int mvo_profile_get(mvo_ctx* ctx, mvo_kernel_time* out, int cap);
  * key "pnp_replay_skew": 1 = the device replays the RANSAC loop with a wrong confidence, so that the host's
  * verification of the selected hypothesis has something to correct (tests only). */
 int mvo_debug_set(const char* key, int value);
+/* LM trace of the last solve on this ctx (handle == NULL: mvo_bundle_adjustment; else that resident window), after
+ * mvo_debug_ba_trace_enable(ctx, 1): one row {lambda the trial was solved with, robust chi2 it reached, gain ratio,
+ * accepted} per trial. */
+int mvo_debug_ba_trace_enable(mvo_ctx* ctx, int on);
+int mvo_debug_get_ba_trace(mvo_ctx* ctx, mvo_ba_handle* handle, double* rows, int cap, int* n);
+/* Summation plan of that window: number of landmark ranges (workgroups), column splits of a Schur chain, and the
+ * first landmark of every range (wgs + 1 entries) -- what the oracle needs to restate the device sums bit for bit. */
+int mvo_debug_get_ba_plan(mvo_ctx* ctx, mvo_ba_handle* handle, int* wgs, int* nsplit, int32_t* wg_pt_start, int cap);
 /* Shader-clock cycles the last fetched BA solve spent per phase (ids in csrc/ba_kernels.hip), and the number
  * of workgroups it ran on. */
 int mvo_debug_get_ba_phases(mvo_ctx* ctx, long long* cycles, int n, int* wgs);

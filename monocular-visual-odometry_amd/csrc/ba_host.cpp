@@ -1,0 +1,716 @@
+// csrc/ba_host.cpp -- host side of the bundle adjustment: what optimization::bundleAdjustment does before and after
+// optimizer.optimize(50) (reference src/optimization/g2o_ba.cpp:193-271 graph construction, :298-316 read-back),
+// turned into a flat, landmark-partitioned window that k_ba_lm (ba_kernels.hip) consumes:
+//   plan      -- active edges, G landmark ranges balanced by edge count, edges sorted by (range, pose), adjacency tables
+//   workspace -- pooled device + pinned memory per ctx (grow-only): a window is (re)built per frame with no hipMalloc,
+//                no hipHostMalloc and ONE host-to-device copy; results come back through pinned mirrors the kernel
+//                writes itself
+//   service   -- one launch thread per device: the workgroups of a window meet at in-kernel hand-offs, so two BA grids
+//                must never be half-resident at the same time; every BA launch of the process goes through this thread,
+//                which batches up to BA_MAX_BATCH pending windows (of any ctx) into one grid.
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "ba_types.h"
+#include "mvo_internal.h"
+
+int ba_kernel_set_lds_limit();
+hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr);
+int ba_solver_class(int n);
+
+int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
+int g_ba_wgs = 0;       // 0 = automatic
+int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
+int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
+
+namespace {
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        size_t o = off;
+        off = (off + bytes + 255) / 256 * 256;
+        return o;
+    }
+};
+
+// Everything the host computes for one window; offsets are relative to the start of the device block.
+struct BaPlan {
+    int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, ldu = 16,
+        nhp = 1, maxEg = 0, maxLg = 0, has_dups = 0, fix_points = 0;
+    size_t lds = 0;
+    std::vector<int> wg_pt;
+    // device block layout
+    size_t o_desc = 0, o_pin = 0, o_ptsin = 0, o_wpt = 0, o_wed = 0, o_wps = 0, o_ep = 0, o_el = 0, o_uv = 0, o_ptstart = 0,
+           o_ptl = 0, o_eof = 0, o_dup = 0, o_slot = 0, o_sp = 0, o_pkt = 0, upload_end = 0;
+    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_xp = 0, o_xr = 0, o_xh = 0, o_xc = 0, total = 0;
+    // pinned mirror layout (behind the upload staging)
+    size_t m_stats = 0, m_poses = 0, m_pts = 0, m_trace = 0, pin_total = 0;
+    bool runnable = true;  // false: nothing to optimise (no free vertex)
+};
+
+struct BaWorkspace {
+    int device = 0;
+    char* dev = nullptr;
+    size_t dev_cap = 0;
+    char* pin = nullptr;
+    size_t pin_cap = 0;
+    unsigned seq = 0;  // launch sequence number (tags)
+    hipEvent_t ready = nullptr;
+    BaPlan plan;
+    bool in_flight = false;
+};
+
+int ws_reserve(mvo_ctx* ctx, BaWorkspace& ws, size_t dev_bytes, size_t pin_bytes) {
+    ws.device = ctx->device;
+    if (!ws.ready) MVO_HIP(hipEventCreateWithFlags(&ws.ready, hipEventDisableTiming));
+    if (dev_bytes > ws.dev_cap) {
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        if (ws.dev) (void)hipFree(ws.dev);
+        ws.dev = nullptr;
+        ws.dev_cap = 0;
+        const size_t cap = dev_bytes + dev_bytes / 4 + 65536;
+        MVO_HIP(hipMalloc((void**)&ws.dev, cap));
+        ws.dev_cap = cap;
+        // exchange granules are matched by tag: fresh memory must not hold a plausible one
+        MVO_HIP(hipMemsetAsync(ws.dev, 0, cap, ctx->stream));
+        ws.seq = 0;
+    }
+    if (pin_bytes > ws.pin_cap) {
+        MVO_HIP(hipStreamSynchronize(ctx->stream));
+        if (ws.pin) (void)hipHostFree(ws.pin);
+        ws.pin = nullptr;
+        ws.pin_cap = 0;
+        const size_t cap = pin_bytes + pin_bytes / 4 + 65536;
+        MVO_HIP(hipHostMalloc((void**)&ws.pin, cap, hipHostMallocDefault));
+        ws.pin_cap = cap;
+    }
+    return MVO_OK;
+}
+void ws_free(BaWorkspace& ws) {
+    if (ws.dev) (void)hipFree(ws.dev);
+    if (ws.pin) (void)hipHostFree(ws.pin);
+    if (ws.ready) (void)hipEventDestroy(ws.ready);
+    ws = BaWorkspace();
+}
+
+// ------------------------------------------------------------------------------------------------ launch service
+struct BaJob {
+    BaWorkspace* ws = nullptr;
+    int use_mfma = 1;
+    bool done = false;
+    hipError_t err = hipSuccess;
+    float ms = 0;   // duration of the launch this window was part of
+    int batch = 0;  // windows in that launch
+};
+struct BaService {
+    int device = 0;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::deque<BaJob*> q;
+    std::thread th;
+    bool started = false;
+    // statistics (mvo_ba_launch_stats)
+    long long launches = 0, windows = 0;
+    double ms = 0;
+    void run();
+};
+// heap-allocated and never destroyed: the detached launch threads wait on these condition variables until the
+// process ends (destroying a condition variable with a waiter would block exit)
+BaService* g_service[16] = {nullptr};
+std::mutex* g_service_start = new std::mutex();
+
+void BaService::run() {
+    (void)hipSetDevice(device);
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    (void)ba_kernel_set_lds_limit();
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+    for (;;) {
+        BaJob* jobs[BA_MAX_BATCH];
+        int nj = 0;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_work.wait(lk, [&] { return !q.empty(); });
+            // one workgroup per CU (the LDS slice is > 80 KB): a launch may not hold more workgroups than the device has
+            // CUs, or its hand-offs would wait for workgroups that cannot become resident
+            int sum_wgs = 0;
+            while (nj < BA_MAX_BATCH && !q.empty()) {
+                const int G = q.front()->ws->plan.G;
+                if (nj && sum_wgs + G > cus) break;
+                if (nj && ba_solver_class(q.front()->ws->plan.n) != ba_solver_class(jobs[0]->ws->plan.n)) break;
+                sum_wgs += G;
+                jobs[nj++] = q.front();
+                q.pop_front();
+            }
+        }
+        BaBatch b{};
+        b.nwin = nj;
+        int maxG = 1;
+        size_t lds = 16;
+        for (int i = 0; i < nj; ++i) {
+            BaWorkspace* ws = jobs[i]->ws;
+            (void)hipStreamWaitEvent(stream, ws->ready, 0);  // the window's upload (queued on its ctx stream)
+            b.win[i] = (const BaDev*)(ws->dev + ws->plan.o_desc);
+            b.tag_base[i] = ws->seq << 12;
+            maxG = std::max(maxG, ws->plan.G);
+            lds = std::max(lds, ws->plan.lds);
+        }
+        b.stride = maxG <= 32 && cus >= 256 ? BA_MAX_BATCH : nj;
+        b.use_mfma = jobs[0]->use_mfma;
+        b.same_l2_ok = g_ba_same_l2;
+        (void)hipEventRecord(e0, stream);
+        hipError_t le = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, ba_solver_class(jobs[0]->ws->plan.n));
+        (void)hipEventRecord(e1, stream);
+        hipError_t se = hipStreamSynchronize(stream);
+        float t = 0;
+        if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&t, e0, e1);
+        else (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lk(m);
+            ++launches;
+            windows += nj;
+            ms += t;
+            for (int i = 0; i < nj; ++i) {
+                jobs[i]->err = le != hipSuccess ? le : se;
+                jobs[i]->ms = t;
+                jobs[i]->batch = nj;
+                jobs[i]->done = true;
+            }
+        }
+        cv_done.notify_all();
+    }
+}
+BaService& service_for(int device) {
+    std::lock_guard<std::mutex> lk(*g_service_start);
+    if (!g_service[device & 15]) g_service[device & 15] = new BaService();
+    BaService& s = *g_service[device & 15];
+    if (!s.started) {
+        s.device = device;
+        s.started = true;
+        s.th = std::thread([&s] { s.run(); });
+        s.th.detach();  // lives as long as the process; blocks on its queue when idle
+    }
+    return s;
+}
+void service_submit(BaService& s, BaJob* jobs, int n) {
+    {
+        std::lock_guard<std::mutex> lk(s.m);
+        for (int i = 0; i < n; ++i) s.q.push_back(&jobs[i]);
+    }
+    s.cv_work.notify_one();
+}
+void service_wait(BaService& s, BaJob* jobs, int n) {
+    std::unique_lock<std::mutex> lk(s.m);
+    s.cv_done.wait(lk, [&] {
+        for (int i = 0; i < n; ++i)
+            if (!jobs[i].done) return false;
+        return true;
+    });
+}
+
+// ------------------------------------------------------------------------------------------------ planning + staging
+// Builds the plan of a window and writes the upload image (descriptor included) into the pinned staging buffer.
+int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_trace) {
+    BaPlan& P = ws.plan;
+    P = BaPlan();
+    const int F = p->n_poses, L = p->n_points;
+    if (F > BA_MAX_POSES) return mvo_set_err(ctx, MVO_ERR_INVALID, "more than 20 poses in the window (vo.h kBuffSize_)", hipSuccess);
+    // information matrix must be symmetric positive definite: Omega = Lc^T Lc
+    const double a = p->info[0], b = p->info[1], c = p->info[2], d = p->info[3];
+    if (!(a > 0) || std::fabs(b - c) > 1e-12 * (std::fabs(a) + std::fabs(d)) || !(a * d - b * b > 0))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "information matrix must be symmetric positive definite", hipSuccess);
+    const double lc00 = std::sqrt(a), lc01 = b / lc00, lc11 = std::sqrt(d - lc01 * lc01);
+    std::vector<int> pose_slot(F, -1), slot_pose;
+    for (int i = 0; i < F; ++i)
+        if (!(p->pose_fixed && p->pose_fixed[i])) {
+            pose_slot[i] = (int)slot_pose.size();
+            slot_pose.push_back(i);
+        }
+    const int nfree = (int)slot_pose.size();
+    // active edges: SparseOptimizer::initializeOptimization drops edges whose vertices are all fixed
+    std::vector<int> act;
+    act.reserve(p->n_edges);
+    std::vector<int> deg(L, 0);
+    for (int e = 0; e < p->n_edges; ++e) {
+        if (pose_slot[p->edge_pose[e]] < 0 && p->fix_points) continue;
+        act.push_back(e);
+        deg[p->edge_point[e]]++;
+    }
+    const int E = (int)act.size();
+    const int n = 6 * nfree;
+    const int NT = (n + 1 + 15) / 16, npair = NT * (NT + 1) / 2;
+    const int nlow = n * (n + 1) / 2 + n, npk = std::max(16, (nlow + 15) & ~15);
+    const int ldu = 16 * NT, nhp = BA_HP * nfree + 1;
+    const bool do_schur = !p->fix_points && n > 0;
+    const int nsplit = do_schur ? std::max(1, BA_WAVES / npair) : 1;
+    P.F = F;
+    P.L = L;
+    P.E = E;
+    P.nfree = nfree;
+    P.n = n;
+    P.NT = NT;
+    P.npair = npair;
+    P.nlow = nlow;
+    P.npk = npk;
+    P.nsplit = nsplit;
+    P.ldu = ldu;
+    P.nhp = nhp;
+    P.fix_points = p->fix_points ? 1 : 0;
+    P.runnable = !(F == 0 && (L == 0 || p->fix_points)) && (nfree > 0 || !p->fix_points);
+    // ---- choose G and the landmark ranges (balanced by edge count); the slice of every workgroup must fit in LDS
+    int G = 1;
+    while (G < 32 && E > 160 * G) G *= 2;  // aim at 160-320 edges per workgroup
+    if (g_ba_wgs > 0) G = g_ba_wgs;
+    if (const char* env = std::getenv("MVO_BA_WGS")) G = std::max(1, std::atoi(env));
+    G = std::max(1, std::min(G, BA_MAX_WGS));
+    std::vector<int>& wg_pt = P.wg_pt;
+    std::vector<int> wg_edge;
+    int maxEg = 0, maxLg = 0;
+    for (;;) {
+        wg_pt.assign(G + 1, 0);
+        wg_edge.assign(G + 1, 0);
+        int l = 0, eacc = 0;
+        for (int g = 0; g < G; ++g) {
+            wg_pt[g] = l;
+            wg_edge[g] = eacc;
+            const long target = (long)E * (g + 1) / G;
+            while (l < L && (g == G - 1 || eacc < target)) eacc += deg[l++];
+        }
+        wg_pt[G] = L;
+        wg_edge[G] = E;
+        maxEg = maxLg = 0;
+        for (int g = 0; g < G; ++g) {
+            maxEg = std::max(maxEg, wg_edge[g + 1] - wg_edge[g]);
+            maxLg = std::max(maxLg, wg_pt[g + 1] - wg_pt[g]);
+        }
+        P.lds = ba_lds_bytes(n, nlow, nhp, G, npair, nsplit, ldu, nfree, maxEg, maxLg, p->fix_points);
+        if (P.lds <= BA_LDS_BUDGET && maxEg < 32000 && maxLg < 32000) break;
+        if (G >= BA_MAX_WGS)
+            return mvo_set_err(ctx, MVO_ERR_CAPACITY, "BA window too large for the LDS-resident solver", hipSuccess);
+        G = std::min(2 * G, BA_MAX_WGS);
+    }
+    P.G = G;
+    P.maxEg = maxEg;
+    P.maxLg = maxLg;
+    P.slice = (nlow + G - 1) / G;
+    // ---- edges sorted by (owner workgroup, pose); adjacency tables
+    std::vector<int> owner(L, 0);
+    for (int g = 0; g < G; ++g)
+        for (int l = wg_pt[g]; l < wg_pt[g + 1]; ++l) owner[l] = g;
+    std::vector<int> wg_pose((size_t)G * (F + 1), 0);
+    {
+        std::vector<int> cnt((size_t)G * std::max(F, 1), 0);
+        for (int e : act) cnt[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
+        int acc = 0;
+        for (int g = 0; g < G; ++g) {
+            for (int q = 0; q < F; ++q) {
+                wg_pose[(size_t)g * (F + 1) + q] = acc;
+                acc += cnt[(size_t)g * F + q];
+            }
+            wg_pose[(size_t)g * (F + 1) + F] = acc;
+        }
+    }
+    std::vector<int> e_pose(E), e_point(E), ptstart(L + 1, 0), ptlist(E);
+    std::vector<double> e_uv(2 * (size_t)E);
+    {
+        std::vector<int> cur((size_t)G * std::max(F, 1));
+        for (int g = 0; g < G; ++g)
+            for (int q = 0; q < F; ++q) cur[(size_t)g * F + q] = wg_pose[(size_t)g * (F + 1) + q];
+        for (int e : act) {
+            const int k = cur[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
+            e_pose[k] = p->edge_pose[e];
+            e_point[k] = p->edge_point[e];
+            e_uv[2 * (size_t)k] = p->edge_uv[2 * (size_t)e];
+            e_uv[2 * (size_t)k + 1] = p->edge_uv[2 * (size_t)e + 1];
+        }
+    }
+    for (int k = 0; k < E; ++k) ptstart[e_point[k] + 1]++;
+    for (int i = 0; i < L; ++i) ptstart[i + 1] += ptstart[i];
+    {
+        std::vector<int> cur(ptstart.begin(), ptstart.end() - 1);
+        for (int k = 0; k < E; ++k) ptlist[cur[e_point[k]]++] = k;
+    }
+    std::vector<short> eof((size_t)std::max(L, 1) * std::max(nfree, 1), -1), dup(std::max(E, 1), -1);
+    int has_dups = 0;
+    for (int k = E - 1; k >= 0; --k) {  // descending so that the chains run in ascending edge order
+        const int sl = pose_slot[e_pose[k]];
+        if (sl < 0) continue;
+        const int lk = k - wg_edge[owner[e_point[k]]];
+        short& head = eof[(size_t)e_point[k] * nfree + sl];
+        dup[k] = head;
+        if (head >= 0) has_dups = 1;
+        head = (short)lk;
+    }
+    P.has_dups = has_dups;
+    // ---- packed order of the reduced system and its place inside the 16 x 16 tile pairs
+    std::vector<short> pkt((size_t)npair * 256, -1);
+    {
+        int pr = 0;
+        for (int ti = 0; ti < NT; ++ti)
+            for (int tj = ti; tj < NT; ++tj, ++pr)
+                for (int r = 0; r < 16; ++r)
+                    for (int cidx = 0; cidx < 16; ++cidx) {
+                        const int j = 16 * ti + r, i = 16 * tj + cidx;  // entry (smaller, larger) index
+                        if (j > i || i > n || (i == n && j >= n)) continue;
+                        pkt[(size_t)pr * 256 + r * 16 + cidx] = (short)(i < n ? i * (i + 1) / 2 + j : n * (n + 1) / 2 + j);
+                    }
+    }
+
+    // ---- layout
+    Carver cv;
+    P.o_desc = cv.take(sizeof(BaDev));
+    P.o_pin = cv.take((size_t)F * 128);
+    P.o_ptsin = cv.take((size_t)L * 24);
+    P.o_wpt = cv.take((size_t)(G + 1) * 4);
+    P.o_wed = cv.take((size_t)(G + 1) * 4);
+    P.o_wps = cv.take((size_t)G * (F + 1) * 4);
+    P.o_ep = cv.take((size_t)E * 4 + 4);
+    P.o_el = cv.take((size_t)E * 4 + 4);
+    P.o_uv = cv.take((size_t)E * 16 + 16);
+    P.o_ptstart = cv.take((size_t)(L + 1) * 4);
+    P.o_ptl = cv.take((size_t)E * 4 + 4);
+    P.o_eof = cv.take(eof.size() * 2);
+    P.o_dup = cv.take(dup.size() * 2);
+    P.o_slot = cv.take((size_t)F * 4 + 4);
+    P.o_sp = cv.take((size_t)nfree * 4 + 4);
+    P.o_pkt = cv.take(pkt.size() * 2);
+    P.upload_end = cv.off;
+    P.o_stats = cv.take(sizeof(BaStatsDev));
+    P.o_pout = cv.take((size_t)F * 128);
+    P.o_pts = cv.take((size_t)L * 24);
+    P.o_xp = cv.take((size_t)G * npk * 16);
+    P.o_xr = cv.take((size_t)npk * 16);
+    P.o_xh = cv.take((size_t)G * nhp * 16);
+    P.o_xc = cv.take((size_t)2 * G * 4 * 8);
+    P.total = cv.off;
+    Carver pc;
+    pc.off = P.upload_end;
+    P.m_stats = pc.take(sizeof(BaStatsDev));
+    P.m_poses = pc.take((size_t)std::max(F, 1) * 128);
+    P.m_pts = pc.take((size_t)std::max(L, 1) * 24);
+    P.m_trace = pc.take(sizeof(BaTraceRow) * BA_TRACE_MAX);
+    P.pin_total = pc.off;
+    int r = ws_reserve(ctx, ws, P.total, P.pin_total);
+    if (r) return r;
+    if (++ws.seq >= (1u << 20)) {  // tag space exhausted: start over on clean exchange memory
+        MVO_HIP(hipMemsetAsync(ws.dev + P.upload_end, 0, ws.dev_cap - P.upload_end, ctx->stream));
+        ws.seq = 1;
+    }
+
+    // ---- upload image
+    char* h = ws.pin;
+    char* D = ws.dev;
+    if (F) std::memcpy(h + P.o_pin, p->pose_T_w_c, (size_t)F * 128);
+    if (L) std::memcpy(h + P.o_ptsin, p->points, (size_t)L * 24);
+    std::memcpy(h + P.o_wpt, wg_pt.data(), (size_t)(G + 1) * 4);
+    std::memcpy(h + P.o_wed, wg_edge.data(), (size_t)(G + 1) * 4);
+    std::memcpy(h + P.o_wps, wg_pose.data(), wg_pose.size() * 4);
+    if (E) {
+        std::memcpy(h + P.o_ep, e_pose.data(), (size_t)E * 4);
+        std::memcpy(h + P.o_el, e_point.data(), (size_t)E * 4);
+        std::memcpy(h + P.o_uv, e_uv.data(), (size_t)E * 16);
+        std::memcpy(h + P.o_ptl, ptlist.data(), (size_t)E * 4);
+    }
+    std::memcpy(h + P.o_ptstart, ptstart.data(), (size_t)(L + 1) * 4);
+    std::memcpy(h + P.o_eof, eof.data(), eof.size() * 2);
+    std::memcpy(h + P.o_dup, dup.data(), dup.size() * 2);
+    if (F) std::memcpy(h + P.o_slot, pose_slot.data(), (size_t)F * 4);
+    if (nfree) std::memcpy(h + P.o_sp, slot_pose.data(), (size_t)nfree * 4);
+    std::memcpy(h + P.o_pkt, pkt.data(), pkt.size() * 2);
+    BaDev B{};
+    B.F = F;
+    B.L = L;
+    B.E = E;
+    B.G = G;
+    B.nfree = nfree;
+    B.n = n;
+    B.NT = NT;
+    B.npair = npair;
+    B.fix_points = P.fix_points;
+    B.max_it = p->max_iterations;
+    B.maxEg = maxEg;
+    B.maxLg = maxLg;
+    B.has_dups = has_dups;
+    B.nlow = nlow;
+    B.npk = npk;
+    B.slice = P.slice;
+    B.nsplit = nsplit;
+    B.ldu = ldu;
+    B.nhp = nhp;
+    B.f = p->focal;
+    B.cx = p->cx;
+    B.cy = p->cy;
+    B.delta = p->huber_delta;
+    B.lc00 = lc00;
+    B.lc01 = lc01;
+    B.lc11 = lc11;
+    B.poses_in = (const double*)(D + P.o_pin);
+    B.poses_out = (double*)(D + P.o_pout);
+    B.pts_in = (const double*)(D + P.o_ptsin);
+    B.pts_out = (double*)(D + P.o_pts);
+    B.wg_pt_start = (const int*)(D + P.o_wpt);
+    B.wg_edge_start = (const int*)(D + P.o_wed);
+    B.wg_pose_start = (const int*)(D + P.o_wps);
+    B.e_pose = (const int*)(D + P.o_ep);
+    B.e_point = (const int*)(D + P.o_el);
+    B.e_uv = (const double*)(D + P.o_uv);
+    B.pt_edge_start = (const int*)(D + P.o_ptstart);
+    B.pt_edge_list = (const int*)(D + P.o_ptl);
+    B.eof = (const short*)(D + P.o_eof);
+    B.dup_next = (const short*)(D + P.o_dup);
+    B.pose_slot = (const int*)(D + P.o_slot);
+    B.slot_pose = (const int*)(D + P.o_sp);
+    B.pk_of_tile = (const short*)(D + P.o_pkt);
+    B.xP = (ba_u64*)(D + P.o_xp);
+    B.xR = (ba_u64*)(D + P.o_xr);
+    B.xH = (ba_u64*)(D + P.o_xh);
+    B.xC = (ba_u64*)(D + P.o_xc);
+    B.stats = (BaStatsDev*)(D + P.o_stats);
+    B.h_stats = (BaStatsDev*)(ws.pin + P.m_stats);
+    B.h_poses = (double*)(ws.pin + P.m_poses);
+    B.h_pts = (L && !p->fix_points) ? (double*)(ws.pin + P.m_pts) : nullptr;
+    B.trace = want_trace ? (BaTraceRow*)(ws.pin + P.m_trace) : nullptr;
+    std::memcpy(h + P.o_desc, &B, sizeof(B));
+    std::memset(ws.pin + P.m_stats, 0, sizeof(BaStatsDev));
+    return MVO_OK;
+}
+
+int ba_upload(mvo_ctx* ctx, BaWorkspace& ws) {
+    MVO_HIP(hipMemcpyAsync(ws.dev, ws.pin, ws.plan.upload_end, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipEventRecord(ws.ready, ctx->stream));
+    return MVO_OK;
+}
+
+// after the launch completed: pinned mirrors -> caller buffers
+int ba_collect(mvo_ctx* ctx, BaWorkspace& ws, const BaJob& job, double* poses, double* points, mvo_ba_stats* st) {
+    const BaPlan& P = ws.plan;
+    if (st) std::memset(st, 0, sizeof(*st));
+    if (!P.runnable) return MVO_OK;
+    if (job.err != hipSuccess) return mvo_set_err(ctx, MVO_ERR_HIP, "k_ba_lm launch", job.err);
+    const BaStatsDev* s = (const BaStatsDev*)(ws.pin + P.m_stats);
+    for (int i = 0; i < BA_NPHASE && i < 16; ++i) ctx->ba_phase[i] = s->phase[i];
+    ctx->ba_wgs = P.G;
+    ctx->ba_trials = s->trials;
+    if (ctx->prof) {
+        ProfEntry& pe = ctx->prof_acc["k_ba_lm"];
+        pe.launches += 1;
+        pe.ms += job.ms;
+    }
+    if (s->error) return mvo_set_err(ctx, MVO_ERR_HIP, "BA hand-off timed out (workgroups not co-resident)", hipSuccess);
+    if (poses && P.F) std::memcpy(poses, ws.pin + P.m_poses, (size_t)P.F * 128);
+    if (points && P.L && !P.fix_points) std::memcpy(points, ws.pin + P.m_pts, (size_t)P.L * 24);
+    if (st) {
+        st->iterations = s->iterations;
+        st->trials = s->trials;
+        st->terminated = s->terminated;
+        st->chi2_initial = s->chi2_initial;
+        st->chi2_final = s->chi2_final;
+        st->lambda_final = s->lambda_final;
+    }
+    return MVO_OK;
+}
+
+}  // namespace
+
+// ctx-owned pool of workspaces (index 0: mvo_bundle_adjustment; more for mvo_ba_solve_batch) + the pending job of the
+// begin / end pair
+struct mvo_ba_pool {
+    std::vector<BaWorkspace*> ws;
+    BaJob pending;
+    bool has_pending = false;
+    int want_trace = 0;
+};
+static mvo_ba_pool* pool_of(mvo_ctx* ctx) {
+    if (!ctx->ba_pool) ctx->ba_pool = new mvo_ba_pool();
+    return ctx->ba_pool;
+}
+static BaWorkspace* pool_ws(mvo_ctx* ctx, size_t i) {
+    mvo_ba_pool* p = pool_of(ctx);
+    while (p->ws.size() <= i) p->ws.push_back(new BaWorkspace());
+    return p->ws[i];
+}
+void ba_pool_release(mvo_ctx* ctx) {
+    if (!ctx->ba_pool) return;
+    for (BaWorkspace* w : ctx->ba_pool->ws) {
+        ws_free(*w);
+        delete w;
+    }
+    delete ctx->ba_pool;
+    ctx->ba_pool = nullptr;
+}
+void ba_set_trace(mvo_ctx* ctx, int on) { pool_of(ctx)->want_trace = on; }
+
+// optimization::bundleAdjustment, first half: graph -> window -> upload -> launch (asynchronous)
+int ba_begin_device(mvo_ctx* ctx, const mvo_ba_problem* p) {
+    mvo_ba_pool* pool = pool_of(ctx);
+    if (pool->has_pending) return mvo_set_err(ctx, MVO_ERR_STATE, "a bundle adjustment is already in flight on this ctx", hipSuccess);
+    BaWorkspace* ws = pool_ws(ctx, 0);
+    int r = ba_stage(ctx, p, *ws, pool->want_trace != 0);
+    if (r) return r;
+    pool->pending = BaJob();
+    pool->pending.ws = ws;
+    pool->pending.use_mfma = g_ba_use_mfma;
+    pool->has_pending = true;
+    if (!ws->plan.runnable) {
+        pool->pending.done = true;
+        return MVO_OK;
+    }
+    if ((r = ba_upload(ctx, *ws))) {
+        pool->has_pending = false;
+        return r;
+    }
+    service_submit(service_for(ctx->device), &pool->pending, 1);
+    return MVO_OK;
+}
+// second half: wait, read back (g2o_ba.cpp:298-316)
+int ba_end_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
+    mvo_ba_pool* pool = pool_of(ctx);
+    if (!pool->has_pending) return mvo_set_err(ctx, MVO_ERR_STATE, "no bundle adjustment in flight on this ctx", hipSuccess);
+    BaWorkspace* ws = pool->pending.ws;
+    if (ws->plan.runnable) service_wait(service_for(ctx->device), &pool->pending, 1);
+    pool->has_pending = false;
+    return ba_collect(ctx, *ws, pool->pending, p ? p->pose_T_w_c : nullptr, p ? p->points : nullptr, st);
+}
+int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
+    int r = ba_begin_device(ctx, p);
+    if (r) return r;
+    return ba_end_device(ctx, p, st);
+}
+
+// n independent windows in ONE launch (up to BA_MAX_BATCH per grid; more are split over consecutive launches)
+int ba_solve_batch_device(mvo_ctx* ctx, mvo_ba_problem* ps, int n, mvo_ba_stats* sts) {
+    mvo_ba_pool* pool = pool_of(ctx);
+    if (pool->has_pending) return mvo_set_err(ctx, MVO_ERR_STATE, "a bundle adjustment is already in flight on this ctx", hipSuccess);
+    std::vector<BaJob> jobs(n);
+    std::vector<BaJob*> run;
+    for (int i = 0; i < n; ++i) {
+        BaWorkspace* ws = pool_ws(ctx, (size_t)i);
+        int r = ba_stage(ctx, &ps[i], *ws, false);
+        if (r) return r;
+        jobs[i].ws = ws;
+        jobs[i].use_mfma = g_ba_use_mfma;
+        if (!ws->plan.runnable) {
+            jobs[i].done = true;
+            continue;
+        }
+        if ((r = ba_upload(ctx, *ws))) return r;
+    }
+    BaService& S = service_for(ctx->device);
+    {
+        std::lock_guard<std::mutex> lk(S.m);
+        for (int i = 0; i < n; ++i)
+            if (!jobs[i].done) S.q.push_back(&jobs[i]);
+    }
+    S.cv_work.notify_one();
+    service_wait(S, jobs.data(), n);
+    int first = MVO_OK;
+    for (int i = 0; i < n; ++i) {
+        int r = ba_collect(ctx, *jobs[i].ws, jobs[i], ps[i].pose_T_w_c, ps[i].points, sts ? &sts[i] : nullptr);
+        if (r && !first) first = r;
+    }
+    return first;
+}
+
+// ---- resident windows: upload once (mvo_ba_prepare), solve any number of times from the same initial state
+struct mvo_ba_handle {
+    BaWorkspace ws;
+    BaJob job;
+    bool launched = false;
+    bool uploaded = false;
+};
+int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out) {
+    *out = nullptr;
+    mvo_ba_handle* H = new mvo_ba_handle();
+    int r = ba_stage(ctx, p, H->ws, pool_of(ctx)->want_trace != 0);
+    if (!r && H->ws.plan.runnable) r = ba_upload(ctx, H->ws);
+    if (!r) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) r = mvo_set_err(ctx, MVO_ERR_HIP, "BA upload", e);
+    }
+    if (r) {
+        ws_free(H->ws);
+        delete H;
+        return r;
+    }
+    H->uploaded = true;
+    *out = H;
+    return MVO_OK;
+}
+int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H) {
+    if (!H->ws.plan.runnable) return MVO_OK;
+    if (H->launched) return mvo_set_err(ctx, MVO_ERR_STATE, "mvo_ba_fetch must follow every mvo_ba_solve_resident", hipSuccess);
+    if (++H->ws.seq >= (1u << 20)) H->ws.seq = 1;  // (one window: at most 2^20 re-solves between clean-ups is plenty)
+    H->job = BaJob();
+    H->job.ws = &H->ws;
+    H->job.use_mfma = g_ba_use_mfma;
+    MVO_HIP(hipEventRecord(H->ws.ready, ctx->stream));
+    service_submit(service_for(ctx->device), &H->job, 1);
+    H->launched = true;
+    return MVO_OK;
+}
+int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* points, mvo_ba_stats* st) {
+    if (H->ws.plan.runnable) {
+        if (!H->launched) return mvo_set_err(ctx, MVO_ERR_STATE, "mvo_ba_fetch without mvo_ba_solve_resident", hipSuccess);
+        service_wait(service_for(ctx->device), &H->job, 1);
+        H->launched = false;
+    }
+    return ba_collect(ctx, H->ws, H->job, poses, points, st);
+}
+void ba_release_device(mvo_ctx* ctx, mvo_ba_handle* H) {
+    if (!H) return;
+    if (H->launched) service_wait(service_for(ctx ? ctx->device : H->ws.device), &H->job, 1);
+    ws_free(H->ws);
+    delete H;
+}
+
+// ---- debug / measurement hooks
+int ba_get_trace(mvo_ctx* ctx, mvo_ba_handle* H, double* rows, int cap, int* n) {
+    BaWorkspace* ws = H ? &H->ws : (ctx->ba_pool && !ctx->ba_pool->ws.empty() ? ctx->ba_pool->ws[0] : nullptr);
+    if (!ws || !ws->pin) return mvo_set_err(ctx, MVO_ERR_STATE, "no bundle adjustment has run", hipSuccess);
+    const BaStatsDev* s = (const BaStatsDev*)(ws->pin + ws->plan.m_stats);
+    const int m = std::min(std::min(s->trials, BA_TRACE_MAX), cap);
+    if (rows) std::memcpy(rows, ws->pin + ws->plan.m_trace, (size_t)m * sizeof(BaTraceRow));
+    if (n) *n = m;
+    return MVO_OK;
+}
+int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg_pt, int cap) {
+    BaWorkspace* ws = H ? &H->ws : (ctx->ba_pool && !ctx->ba_pool->ws.empty() ? ctx->ba_pool->ws[0] : nullptr);
+    if (!ws) return mvo_set_err(ctx, MVO_ERR_STATE, "no bundle adjustment has been planned", hipSuccess);
+    if (G) *G = ws->plan.G;
+    if (nsplit) *nsplit = ws->plan.nsplit;
+    if (wg_pt)
+        for (int i = 0; i <= ws->plan.G && i < cap; ++i) wg_pt[i] = ws->plan.wg_pt[i];
+    return MVO_OK;
+}
+void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
+    if (launches) *launches = 0;
+    if (windows) *windows = 0;
+    if (ms) *ms = 0;
+    BaService* sp;
+    {
+        std::lock_guard<std::mutex> lk(*g_service_start);
+        sp = g_service[device & 15];
+    }
+    if (!sp) return;
+    BaService& s = *sp;
+    std::lock_guard<std::mutex> lk(s.m);
+    if (launches) *launches = s.launches;
+    if (windows) *windows = s.windows;
+    if (ms) *ms = s.ms;
+    if (reset) {
+        s.launches = s.windows = 0;
+        s.ms = 0;
+    }
+}

@@ -1,0 +1,126 @@
+// csrc/ba_types.h -- data shared by the bundle-adjustment kernel (ba_kernels.hip) and its host side (ba_host.cpp):
+// the device-resident window descriptor, the LDS carve-up and the summation plan.
+//
+// Canonical arithmetic: every cross-edge / cross-landmark sum of the solver has ONE defined order, so
+// that a run is bit-reproducible and can be restated bit for bit on the CPU (oracle/ba_oracle.cpp, blocked mode):
+//   * the window is cut into G contiguous landmark ranges ("workgroup ranges", balanced by edge count);
+//   * inside a range a Gram-type sum (pose blocks M^T M, Schur blocks U^T U) is ONE chain of fused multiply-adds over
+//     its rows / columns in storage order (this is what a sequence of v_mfma_f64_16x16x4_f64 computes: the matrix
+//     core adds the four k-slots of an instruction as IEEE FMAs in k order), optionally split into `nsplit`
+//     consecutive column ranges whose chain results are added in range order;
+//   * range results are added in range order g = 0 .. G-1;
+//   * scalar sums (chi2, predicted decrease) are per-thread partials (thread = edge / landmark index mod 512),
+//     a 64-lane xor butterfly (32, 16, .. 1), the 8 waves in order, the ranges in order.
+#ifndef MVO_BA_TYPES_H
+#define MVO_BA_TYPES_H
+#include <stddef.h>
+#include <stdint.h>
+
+typedef unsigned long long ba_u64;
+
+#define BA_THREADS 512
+#define BA_WAVES 8
+#define BA_MAX_POSES 20
+#define BA_MSTRIDE 14               // doubles per edge in M: two rows [A~ (6) | e~]
+#define BA_LDS_BUDGET (142 * 1024)  // dynamic part; the static part (~17.5 KB) comes on top (160 KB per CU)
+#define BA_MAX_WGS 256
+#define BA_MAX_BATCH 8              // windows per launch (8 x 32 workgroups = one workgroup per CU)
+#define BA_NPHASE 16
+#define BA_TRACE_MAX 512            // LM trials recorded per solve (50 iterations x at most 10 trials)
+#define BA_HP 28                    // packed lower triangle of the 7 x 7 pose block [H_pp | -b_p; . | e^T e]
+
+struct BaStatsDev {
+    int iterations, trials, terminated, error;
+    double chi2_initial, chi2_final, lambda_final;
+    long long phase[BA_NPHASE];  // shader-clock cycles per phase as seen by thread 0 of workgroup 0
+};
+// phase ids: 0 LIN, 1 pose-block chains, 2 landmark blocks + pose-block exchange, 3 T1 + U, 4 Schur chains,
+// 5 publish + slice reduction + gather, 6 assemble, 7 reduced solve, 8 back-substitution + update, 9 chi2,
+// 10 chi2 exchange + decision, 11 whole kernel
+
+// One LM trial as recorded for the parity tests: the damping it was solved with, the robust chi2 it reached, the gain
+// ratio and whether the step was accepted.
+struct BaTraceRow {
+    double lambda, chi2, rho, accepted;
+};
+
+struct BaDev {
+    int F, L, E, G, nfree, n, NT, npair, fix_points, max_it, maxEg, maxLg, has_dups;
+    int nlow;    // packed entries of the reduced system: lower triangle (i >= j, i < n) then the rhs row (n, j)
+    int npk;     // nlow rounded up to 16: row pitch of the partial exchange
+    int slice;   // packed entries every workgroup reduces in stage 1
+    int nsplit;  // consecutive column ranges of a Schur chain (more waves busy; results added in range order)
+    int ldu;     // rows of the U buffer = 16 NT
+    int nhp;     // pose-block exchange entries per workgroup = BA_HP nfree + 1 (last: max |diag H_ll|)
+    double f, cx, cy, delta;
+    double lc00, lc01, lc11;  // upper Cholesky factor of the information matrix: Omega = Lc^T Lc
+    const double* poses_in;   // F x 16
+    double* poses_out;        // F x 16
+    const double* pts_in;     // L x 3
+    double* pts_out;          // L x 3
+    const int* wg_pt_start;   // G + 1   (landmark ranges)
+    const int* wg_edge_start; // G + 1   (edges sorted by owner workgroup, then pose)
+    const int* wg_pose_start; // G x (F + 1): absolute edge index where pose p starts inside workgroup g
+    const int* e_pose;        // E
+    const int* e_point;       // E (global landmark index)
+    const double* e_uv;       // E x 2
+    const int* pt_edge_start; // L + 1 -> pt_edge_list
+    const int* pt_edge_list;  // E absolute edge indices, grouped by landmark
+    const short* eof;         // L x nfree: LOCAL index of the first edge (landmark, pose slot), -1 if none
+    const short* dup_next;    // E: next LOCAL edge with the same (landmark, pose), -1 if none
+    const int* pose_slot;     // F
+    const int* slot_pose;     // nfree
+    const short* pk_of_tile;  // npair x 256: packed index of tile entry (pair, r, c), -1 if not needed
+    // cross-workgroup exchange: 8-byte granules {tag : 32 | half a double : 32}, two per value
+    ba_u64* xP;  // G x npk x 2   Schur partials
+    ba_u64* xR;  // npk x 2       the same entries summed over the workgroups
+    ba_u64* xH;  // G x nhp x 2   pose-block partials (+ max diagonal)
+    ba_u64* xC;  // 2 (parity) x G x 2 x 2   chi2 / predicted-decrease partials
+    BaStatsDev* stats;
+    // pinned host mirrors written by the kernel itself at the end of the solve (fetching needs no copy dispatch)
+    BaStatsDev* h_stats;
+    double* h_poses;  // F x 16
+    double* h_pts;    // L x 3 (null when the landmarks are fixed)
+    BaTraceRow* trace;  // BA_TRACE_MAX rows in pinned host memory, or null
+};
+
+struct BaBatch {  // kernel argument: the windows of one launch
+    const BaDev* win[BA_MAX_BATCH];
+    unsigned tag_base[BA_MAX_BATCH];  // launch sequence number of the window << 12: exchange tags never repeat
+    int nwin;
+    int stride;      // blockIdx -> (window = b % stride, workgroup = b / stride); 8 when every window has <= 32 workgroups
+    int use_mfma;    // 0: validation path (the same fma chains on the vector ALU)
+    int same_l2_ok;  // 0: always publish write-through (test hook); 1: plain stores when a window sits on one XCD
+};
+
+// ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner
+__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int nsplit) {
+    // the solver area also stages the split-chain tiles and the slice reduction (never live together)
+    // register solvers: the system is embedded into 32 / 64 rows (ba_kernels.hip: solve_wave)
+    size_t a = n + 1 <= 32 ? 32 * 33 : (n + 1 <= 64 ? 64 * 65 : (size_t)(n + 1) * (size_t)(n + 2));
+    const size_t sp = (size_t)npair * (size_t)(nsplit > 1 ? nsplit - 1 : 0) * 256;
+    const size_t sl = (size_t)((nlow + G - 1) / (G > 0 ? G : 1)) * (size_t)G;
+    if (sp > a) a = sp;
+    if (sl > a) a = sl;
+    return a + 3 * 64;  // + two column-broadcast buffers + scratch
+}
+__host__ __device__ inline size_t ba_lds_bytes(int n, int nlow, int nhp, int G, int npair, int nsplit, int ldu, int nfree,
+                                               int maxEg, int maxLg, int fix_points) {
+    size_t d = ba_solver_doubles(n, nlow, G, npair, nsplit) + (size_t)nlow + 16 + (size_t)maxEg * (BA_MSTRIDE + 2) +
+               (size_t)maxLg * 3;
+    size_t hrows = 4096 / (size_t)(nhp > 0 ? nhp : 1);  // pose-block exchange staging: <= 4096 values at a time
+    if (hrows < 1) hrows = 1;
+    if (hrows > (size_t)G) hrows = (size_t)G;
+    const size_t stage = (size_t)nhp * hrows;
+    if (!fix_points) {
+        d += (size_t)maxEg * 6 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3 + 3);
+        const size_t u = ((size_t)3 * maxLg + 3) * ldu;  // the pose-block staging lives inside the U buffer (rebuilt per trial)
+        d += u > stage ? u : stage;
+    } else {
+        d += stage;
+    }
+    size_t shorts = (size_t)maxEg * 4 + (size_t)maxLg + 1 + (size_t)maxLg * (nfree > 0 ? nfree : 1);
+    return d * 8 + ((shorts * 2 + 15) & ~(size_t)15) + 64;
+}
+
+#endif

@@ -118,7 +118,8 @@ struct mvo_ctx {
     mvo_track_state* track = nullptr;
     // --- BA diagnostics of the last fetched solve
     long long ba_phase[16] = {0};
-    int ba_wgs = 0;
+    int ba_wgs = 0, ba_trials = 0;
+    struct mvo_ba_pool* ba_pool = nullptr;  // pooled BA workspaces (ba_host.cpp)
     // --- profiling
     bool prof = false;
     std::map<std::string, ProfEntry> prof_acc;
@@ -181,12 +182,20 @@ int track_launch_em_mask(mvo_ctx* ctx, const double* d_q1, const double* d_q2, i
 extern int g_pnp_replay_skew;  // test hook: the device replays the RANSAC loop with a wrong confidence
 // track_host.cpp
 void track_release(mvo_ctx* ctx);
-// ba_kernels.hip
+// ba_host.cpp (planning, pooled workspaces, launch service) + ba_kernels.hip (k_ba_lm)
 struct mvo_ba_handle;
 int ba_solve_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st);
+int ba_begin_device(mvo_ctx* ctx, const mvo_ba_problem* p);
+int ba_end_device(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st);
+int ba_solve_batch_device(mvo_ctx* ctx, mvo_ba_problem* ps, int n, mvo_ba_stats* sts);
 int ba_prepare_device(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** out);
 int ba_run_device(mvo_ctx* ctx, mvo_ba_handle* H);
 int ba_fetch_device(mvo_ctx* ctx, mvo_ba_handle* H, double* poses, double* points, mvo_ba_stats* st);
-void ba_release_device(mvo_ba_handle* H);
+void ba_release_device(mvo_ctx* ctx, mvo_ba_handle* H);
+void ba_pool_release(mvo_ctx* ctx);
+void ba_set_trace(mvo_ctx* ctx, int on);
+int ba_get_trace(mvo_ctx* ctx, mvo_ba_handle* H, double* rows, int cap, int* n);
+int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg_pt, int cap);
+void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset);
 
 #endif

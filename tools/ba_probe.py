@@ -3,8 +3,10 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, __graft_entry__ as g
 mvo = g.load_package(); ctx = mvo.Context(0)
-for kind, kw in (("full", dict(fix_points=False)), ("pose_only", dict(fix_points=True))):
-  for wgs in (0, 8, 16, 32, 64):
+kinds = (("full", dict(fix_points=False)), ("pose_only", dict(fix_points=True)))
+wgs_list = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
+for kind, kw in kinds:
+  for wgs in wgs_list:
     mvo.debug_set("ba_wgs", wgs)
     pb = mvo.synth.ba_problem(5, 2000, 7)
     a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
@@ -12,11 +14,25 @@ for kind, kw in (("full", dict(fix_points=False)), ("pose_only", dict(fix_points
         h = ctx.ba_prepare(*a, **kw)
     except Exception as e:
         print(kind, wgs, "prepare failed", e); continue
-    for _ in range(3): ctx.ba_solve_resident(h); ctx.ba_fetch(h)
-    t0=time.perf_counter(); N=10
-    for _ in range(N): ctx.ba_solve_resident(h); P,X,st = ctx.ba_fetch(h)
-    dt=(time.perf_counter()-t0)/N
-    ph = ctx.debug_ba_phases()
-    tot = ph["total"]; 
-    print(kind, "wgs", ph["wgs"], "ms/solve %.3f trials %d" % (dt*1e3, st["trials"]), "cyc/us %.0f" % (tot/ (dt*1e6)), {k: round(v/max(st["trials"],1)) for k,v in ph.items() if k!="wgs"})
+    for prof in (0, 1):
+        mvo.debug_set("ba_profile", prof)
+        for _ in range(3): ctx.ba_solve_resident(h); ctx.ba_fetch(h)
+        t0=time.perf_counter(); N=10
+        for _ in range(N): ctx.ba_solve_resident(h); P,X,st = ctx.ba_fetch(h)
+        dt=(time.perf_counter()-t0)/N
+        ph = ctx.debug_ba_phases()
+        if not prof:
+            print(kind, "wgs", ph["wgs"], "ms/solve %.3f (wall, production kernel) trials %d same_l2 %d" % (dt*1e3, st["trials"], ph["x15"]))
+        else:
+            tot = ph["total"]
+            print("   instrumented: ms/solve %.3f" % (dt*1e3), "cyc/us %.0f" % (tot/ (dt*1e6)), {k: round(v/max(st["trials"],1)) for k,v in ph.items() if k not in ("wgs", "x15", "schur.loop", "schur.wait", "schur.acc")})
+    mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
+# one-shot path (window rebuilt per call) and batches
+pb = mvo.synth.ba_problem(5, 2000, 7)
+a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+mvo.debug_set("ba_wgs", 0)
+for _ in range(3): ctx.bundle_adjustment(*a, fix_points=False)
+t0=time.perf_counter(); N=20
+for _ in range(N): ctx.bundle_adjustment(*a, fix_points=False)
+print("mvo_bundle_adjustment (plan + upload + solve + fetch) ms/call %.3f" % ((time.perf_counter()-t0)/N*1e3))
