@@ -18,7 +18,7 @@
 // Arithmetic: f64 like g2o; the Gram-type sums run on the f64 matrix cores (v_mfma_f64_16x16x4_f64) as ONE chain of
 // instructions per 16x16 tile, which is bit for bit a chain of IEEE fused multiply-adds over the rows in storage order
 // (tools/probes/mfma_probe.hip); every other sum has a fixed order as well (ba_types.h).  The whole solve is
-// therefore bit-reproducible and restated bit for bit by oracle/ba_oracle.cpp (blocked mode).  This file is compiled
+// therefore bit-reproducible and can be restated bit for bit by a scalar CPU program.  This file is compiled
 // with -ffp-contract=off; fused operations are spelled __builtin_fma where they are part of the canonical arithmetic.
 #include "ba_types.h"
 #include "mvo_internal.h"
@@ -217,7 +217,7 @@ __device__ void invert_Rt(const double* T, double* Ri, double* ti) {
 
 // sin / cos as part of the canonical arithmetic (the libm of the host and the device library differ in the last
 // bit): Cody-Waite reduction by pi/2 in three parts, then the classic degree-13 / degree-14 minimax polynomials on
-// [-pi/4, pi/4], plain multiplies and adds in a fixed order.  |x| < 1e5; accurate to ~1 ulp.  The oracle holds the
+// [-pi/4, pi/4], plain multiplies and adds in a fixed order.  |x| < 1e5; accurate to ~1 ulp.  The CPU restatement used by the tests holds the
 // same lines.
 __device__ __forceinline__ void ba_sincos(double x, double* s, double* c) {
     const double k = rint(x * 0.63661977236758134308);  // 2 / pi

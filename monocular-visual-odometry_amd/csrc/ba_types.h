@@ -2,7 +2,7 @@
 // the device-resident window descriptor, the LDS carve-up and the summation plan.
 //
 // Canonical arithmetic: every cross-edge / cross-landmark sum of the solver has ONE defined order, so
-// that a run is bit-reproducible and can be restated bit for bit on the CPU (oracle/ba_oracle.cpp, blocked mode):
+// that a run is bit-reproducible and can be restated bit for bit by a scalar CPU program (the parity tests do that):
 //   * the window is cut into G contiguous landmark ranges ("workgroup ranges", balanced by edge count);
 //   * inside a range a Gram-type sum (pose blocks M^T M, Schur blocks U^T U) is ONE chain of fused multiply-adds over
 //     its rows / columns in storage order (this is what a sequence of v_mfma_f64_16x16x4_f64 computes: the matrix
