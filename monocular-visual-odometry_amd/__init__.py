@@ -107,6 +107,7 @@ class Context:
         if r != MVO_OK:
             raise MvoError(r, "mvo_create failed (no usable HIP device?) -- there is no CPU fallback")
         self.h = h
+        self.device = int(device)
         self.params = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500,
                            grid_size=16, grid_max_per_cell=8)  # config/config.yaml:65-69,94-95
         if orb_params:
@@ -302,6 +303,40 @@ class Context:
         self._chk(self.lib.mvo_bundle_adjustment(self.h, C.byref(pr), C.byref(st)))
         return poses.reshape(-1, 4, 4), points, {k: getattr(st, k) for k, _ in BaStats._fields_}
 
+    def ba_solve_batch(self, problems, **kw):
+        """mvo_ba_solve_batch: `problems` = list of argument tuples of bundle_adjustment(); the windows are solved in one
+        grid (8 per launch).  Returns a list of (poses, points, stats)."""
+        prs = (BaProblem * len(problems))()
+        keeps = []
+        for i, a in enumerate(problems):
+            d = dict(info=(1, 0, 0, 1), huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50)
+            d.update(kw)
+            pr, keep = self._ba_problem(*a, d["info"], d["huber_delta"], d["fix_points"], d["pose_fixed"], d["max_iterations"])
+            prs[i] = pr
+            keeps.append(keep)
+        sts = (BaStats * len(problems))()
+        self._chk(self.lib.mvo_ba_solve_batch(self.h, prs, len(problems), sts))
+        return [(k["poses"].reshape(-1, 4, 4), k["points"], {f: getattr(sts[i], f) for f, _ in BaStats._fields_})
+                for i, k in enumerate(keeps)]
+
+    def ba_trace_enable(self, on=True):
+        self._chk(self.lib.mvo_debug_ba_trace_enable(self.h, int(on)))
+
+    def ba_trace(self, handle=None, raw_rows=0):
+        """LM trace of the last solve: rows {lambda, chi2, rho, accepted} per trial (raw_rows > 0: that many raw rows)."""
+        out = np.zeros((512, 4))
+        n = C.c_int()
+        self._chk(self.lib.mvo_debug_get_ba_trace(self.h, handle[0] if handle else None, _p(out),
+                                                  -int(raw_rows) if raw_rows else 512, C.byref(n)))
+        return out[:n.value].copy()
+
+    def ba_plan(self, handle=None):
+        """Summation plan of the last window: dict(wgs, nsplit, wg_pt_start)."""
+        g, ns = C.c_int(), C.c_int()
+        pt = np.zeros(257, np.int32)
+        self._chk(self.lib.mvo_debug_get_ba_plan(self.h, handle[0] if handle else None, C.byref(g), C.byref(ns), _p(pt), 257))
+        return dict(wgs=g.value, nsplit=ns.value, wg_pt_start=pt[:g.value + 1].copy())
+
     # ---- tracking rows (vo.cpp:16-49, 270-357)
     def map_create(self):
         m = C.c_void_p()
@@ -408,6 +443,11 @@ class Context:
         arr = (KernelTime * 64)()
         n = self.lib.mvo_profile_get(self.h, arr, 64)
         return {arr[i].name.decode(): (arr[i].launches, arr[i].total_ms) for i in range(min(n, 64))}
+
+    def ba_launch_stats(self, reset=False):
+        a, b, ms = C.c_longlong(), C.c_longlong(), C.c_double()
+        self.lib.mvo_ba_launch_stats(self.device, C.byref(a), C.byref(b), C.byref(ms), int(reset))
+        return dict(launches=a.value, windows=b.value, ms=ms.value)
 
     def debug_ba_phases(self):
         arr = (C.c_longlong * 16)()

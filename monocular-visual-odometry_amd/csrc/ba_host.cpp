@@ -680,7 +680,7 @@ int ba_get_trace(mvo_ctx* ctx, mvo_ba_handle* H, double* rows, int cap, int* n) 
     BaWorkspace* ws = H ? &H->ws : (ctx->ba_pool && !ctx->ba_pool->ws.empty() ? ctx->ba_pool->ws[0] : nullptr);
     if (!ws || !ws->pin) return mvo_set_err(ctx, MVO_ERR_STATE, "no bundle adjustment has run", hipSuccess);
     const BaStatsDev* s = (const BaStatsDev*)(ws->pin + ws->plan.m_stats);
-    const int m = std::min(std::min(s->trials, BA_TRACE_MAX), cap);
+    const int m = cap < 0 ? std::min(-cap, BA_TRACE_MAX) : std::min(std::min(s->trials, BA_TRACE_MAX), cap);  // cap < 0: raw rows
     if (rows) std::memcpy(rows, ws->pin + ws->plan.m_trace, (size_t)m * sizeof(BaTraceRow));
     if (n) *n = m;
     return MVO_OK;

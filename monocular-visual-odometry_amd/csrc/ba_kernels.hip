@@ -38,6 +38,14 @@ typedef ba_u64 u64;
         }                                                                \
     } while (0)
 
+// timeline of one LM trial (instrumented kernel only): shader-clock stamps of thread 0 of workgroup 0 during trial
+// BA_STAMP_TRIAL, left in the rows behind the LM trace (tools/ba_probe.py prints them)
+#define BA_STAMP_TRIAL 6
+#define STAMP(k)                                                                                      \
+    do {                                                                                              \
+        if (PROF && tid == 0 && trials == BA_STAMP_TRIAL) sStamp[k] = (long long)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------ small helpers
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -99,7 +107,8 @@ __device__ __forceinline__ bool gtry_d(const u64* g, unsigned tag, double& v) {
 // Every thread fetches its share of `count` tagged values into LDS: item q comes from the granule pair
 // src[2 * (q / per * stride + q % per)] (per = values per producer row, stride = row pitch in values).  Four
 // independent loads in flight per thread and pass; bounded retries.
-__device__ bool gather_tagged(const u64* src, int count, int per, size_t stride, unsigned tag, double* dst) {
+__device__ bool gather_tagged(const u64* src, int count, int per, size_t stride, unsigned tag, double* dst,
+                              long long* spins = nullptr) {
     bool fine = true;
     for (int q0 = threadIdx.x; q0 < count; q0 += 4 * BA_THREADS) {
         unsigned pending = 0;
@@ -129,6 +138,7 @@ __device__ bool gather_tagged(const u64* src, int count, int per, size_t stride,
                     fine = false;
                     break;
                 }
+                if (spins) ++*spins;
                 __builtin_amdgcn_s_sleep(1);
             }
         }
@@ -548,14 +558,27 @@ __device__ __forceinline__ v4d schur_chain(const double* U, int ldu, int ti, int
     const double* pb = U + (size_t)(4 * m0 + k) * ldu + ((16 * tj + i) ^ swz);
     const int st = 4 * ldu;
     int m = m0;
-    for (; m + 4 <= m1; m += 4) {
-        const double a0 = pa[0], b0 = pb[0], a1 = pa[st], b1 = pb[st], a2 = pa[2 * st], b2 = pb[2 * st], a3 = pa[3 * st], b3 = pb[3 * st];
+    if (m + 4 <= m1) {
+        double a0 = pa[0], b0 = pb[0], a1 = pa[st], b1 = pb[st], a2 = pa[2 * st], b2 = pb[2 * st], a3 = pa[3 * st], b3 = pb[3 * st];
+        pa += 4 * st;
+        pb += 4 * st;
+        m += 4;
+        for (; m + 4 <= m1; m += 4) {  // the next four operand pairs are in flight while the matrix core works
+            const double c0 = pa[0], d0 = pb[0], c1 = pa[st], d1 = pb[st], c2 = pa[2 * st], d2 = pb[2 * st], c3 = pa[3 * st], d3 = pb[3 * st];
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = c0, b0 = d0, a1 = c1, b1 = d1, a2 = c2, b2 = d2, a3 = c3, b3 = d3;
+            pa += 4 * st;
+            pb += 4 * st;
+        }
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
-        pa += 4 * st;
-        pb += 4 * st;
     }
     for (; m < m1; ++m) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
@@ -595,6 +618,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     __shared__ double sX[BA_MAX_WGS * 2];
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ int sFlag[4];
+    __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
     if (threadIdx.x == 0) sFlag[2] = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -860,8 +884,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     const int nr = min(hrows, G - w0);
                     if (!gather_tagged(B.xH + 2 * (size_t)w0 * nhp, nr * nhp, nhp, nhp, tag0 + tagH, stage)) sFlag[2] = 1;
                     __syncthreads();
-                    if (tid < nhp - 1)
+                    if (tid < nhp - 1) {
+#pragma unroll 8
                         for (int w = 0; w < nr; ++w) hsum += stage[w * nhp + tid];
+                    }
                     if (tid < nr) mm = fmax(mm, stage[tid * nhp + nhp - 1]);
                     __syncthreads();
                 }
@@ -895,6 +921,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         double rho = 0;
         int qmax = 0;
         do {
+            STAMP(0);
             // ============= T1: (H_ll + lambda I)^-1 = C C^T, C^T b_l; U_l = [W_l C_l ; (C_l^T b_l)^T ; 0]
             if (!B.fix_points) {
                 for (int l = tid; l < Lg; l += BA_THREADS) {
@@ -925,34 +952,46 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                             for (int k = 0; k < 3; ++k) W.U[u_index(3 * l + k, row, ldu)] = 0.0;
                     }
                 }
+                STAMP(1);
                 if (do_schur)
                     for (int q = ncol * ldu + tid; q < 4 * msteps * ldu; q += BA_THREADS) W.U[q] = 0.0;  // pad columns
                 __syncthreads();
+                STAMP(2);
                 if (do_schur) {
-                    for (int q = tid; q < Lg * nfree; q += BA_THREADS) {
-                        const int l = q / nfree, sl = q - l * nfree;
+                    // U rows of the pose blocks: one item per (landmark, pose slot, k): Y_k = (X~ C)[., k] of every edge of the
+                    // pair (normally one), u = A~^T Y_k (six values, contiguous in column 3 l + k)
+                    const int n3 = 3 * nfree;
+                    for (int q = tid; q < Lg * n3; q += BA_THREADS) {
+                        const int l = q / n3, rem = q - l * n3, sl = rem / 3, k = rem - 3 * sl;
                         const double* cc = W.Cc + 6 * l;
-                        double acc[18];
-#pragma unroll
-                        for (int i = 0; i < 18; ++i) acc[i] = 0;
-                        for (int el = W.eof[q]; el >= 0; el = W.dup[el]) {
+                        // column k of the lower-triangular C: C[c][k] for c = k .. 2
+                        const double ck0 = k == 0 ? cc[0] : 0.0, ck1 = k == 0 ? cc[1] : (k == 1 ? cc[2] : 0.0),
+                                     ck2 = k == 0 ? cc[3] : (k == 1 ? cc[4] : cc[5]);
+                        double acc[6] = {0, 0, 0, 0, 0, 0};
+                        for (int el = W.eof[l * nfree + sl]; el >= 0; el = W.dup[el]) {
                             const double* X = W.X + 6 * el;
                             const double* A = W.M + BA_MSTRIDE * el;
-                            const double Y[6] = {X[0] * cc[0] + X[1] * cc[1] + X[2] * cc[3], X[1] * cc[2] + X[2] * cc[4], X[2] * cc[5],
-                                                 X[3] * cc[0] + X[4] * cc[1] + X[5] * cc[3], X[4] * cc[2] + X[5] * cc[4], X[5] * cc[5]};
+                            double y0, y1;
+                            if (k == 0) {
+                                y0 = X[0] * ck0 + X[1] * ck1 + X[2] * ck2;
+                                y1 = X[3] * ck0 + X[4] * ck1 + X[5] * ck2;
+                            } else if (k == 1) {
+                                y0 = X[1] * ck1 + X[2] * ck2;
+                                y1 = X[4] * ck1 + X[5] * ck2;
+                            } else {
+                                y0 = X[2] * ck2;
+                                y1 = X[5] * ck2;
+                            }
 #pragma unroll
-                            for (int c = 0; c < 6; ++c)
-#pragma unroll
-                                for (int k = 0; k < 3; ++k) acc[3 * c + k] = acc[3 * c + k] + (A[c] * Y[k] + A[7 + c] * Y[3 + k]);
+                            for (int c = 0; c < 6; ++c) acc[c] = acc[c] + (A[c] * y0 + A[7 + c] * y1);
                         }
 #pragma unroll
-                        for (int c = 0; c < 6; ++c)
-#pragma unroll
-                            for (int k = 0; k < 3; ++k) W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = acc[3 * c + k];
+                        for (int c = 0; c < 6; ++c) W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = acc[c];
                     }
                     __syncthreads();
                 }
             }
+            STAMP(3);
             PH_END(3);
             // ============= T2: partial Schur system of the own landmarks: one MFMA chain per (tile pair, split)
             if (do_schur) {
@@ -971,6 +1010,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                             ++ti;
                         }
                         v4d acc = schur_chain(W.U, ldu, ti, ti + rem, min(sp * msplit, msteps), min((sp + 1) * msplit, msteps), lane);
+                        STAMP(4);
                         if (sp > 0) {
                             double* dst = split_stage + ((size_t)pr * (B.nsplit - 1) + (sp - 1)) * 256;
 #pragma unroll
@@ -1012,28 +1052,36 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                         else W.Rl[pk] = tot;
                     }
                 }
+                STAMP(5);
                 PH_END(4);
                 if (G > 1) {
                     __syncthreads();  // the split tiles in the solver area are dead: it now stages the slice reduction
+                    STAMP(6);
                     // stage 1: this workgroup reduces its SLICE of the packed entries over all G partials, in workgroup
                     // order, and republishes the slice
                     const int sl0 = g * slice, sln = max(0, min(slice, nlow - sl0));
                     if (sln > 0) {
                         // item q = (w, el): partial of workgroup w, entry sl0 + el
-                        if (!gather_tagged(B.xP + 2 * (size_t)sl0, sln * G, sln, npk, tag0 + tagA, W.SL)) sFlag[2] = 1;
+                        if (!gather_tagged(B.xP + 2 * (size_t)sl0, sln * G, sln, npk, tag0 + tagA, W.SL, PROF ? &ph[PROF ? 12 : 0] : nullptr)) sFlag[2] = 1;
                     }
+                    STAMP(7);
                     __syncthreads();
+                    STAMP(8);
                     for (int el = tid; el < sln; el += BA_THREADS) {
                         double sum = 0;
+#pragma unroll 8
                         for (int w = 0; w < G; ++w) sum += W.SL[w * sln + el];
                         gstore_d(B.xR + 2 * (size_t)(sl0 + el), tag0 + tagA, sum, same_l2);
                     }
+                    STAMP(9);
                     // stage 2: everybody reads the summed entries
-                    if (!gather_tagged(B.xR, nlow, nlow, 0, tag0 + tagA, W.Rl)) sFlag[2] = 1;
+                    if (!gather_tagged(B.xR, nlow, nlow, 0, tag0 + tagA, W.Rl, PROF ? &ph[PROF ? 13 : 0] : nullptr)) sFlag[2] = 1;
+                    STAMP(10);
                 }
                 __syncthreads();
                 if (sFlag[2]) error = 1;
             }
+            STAMP(11);
             PH_END(5);
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n] and solves it
             if (NR != 0) {
@@ -1076,6 +1124,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 }
             }
             __syncthreads();
+            STAMP(12);
             PH_END(6);
             if (wave == 0 && n > 0) {
                 int ok;
@@ -1101,12 +1150,22 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 sDx[tid] = (ok2 && sl >= 0) ? sSol[6 * sl + tid % 6] : 0.0;
             }
             __syncthreads();
+            STAMP(13);
             PH_END(7);
             const double lambda_used = lambda;
             ++trials;
             // ============= T4/T5: back-substitute the own landmarks, computeScale, push + apply the update
             double scale = 0;
             if (g == 0 && tid < 6 * B.F && sSlot[tid / 6] >= 0) scale += sDx[tid] * (lambda * sDx[tid] + sBp[tid]);
+            if (tid >= BA_THREADS - 64 && tid - (BA_THREADS - 64) < B.F) {  // push + oplus of the poses: last wave
+                const int p = tid - (BA_THREADS - 64);
+                for (int i = 0; i < 8; ++i) sPbak[8 * p + i] = sP[8 * p + i];
+                if (sSlot[p] >= 0) {
+                    pose_oplus(sP + 8 * p, sDx + 6 * p);
+                    quat_to_R(sP + 8 * p, sR + 9 * p);
+                    for (int i = 0; i < 3; ++i) sT[3 * p + i] = sP[8 * p + 4 + i];
+                }
+            }
             if (!B.fix_points) {
                 // r = C^T (b_l - W^T dx_p) = cl - U^T dx: one thread per (landmark, k), fma chain over the rows
                 for (int q = tid; q < 3 * Lg; q += BA_THREADS) {
@@ -1114,7 +1173,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     if (do_schur) {
                         const int swz = (ldu & 31) == 0 ? ((q & 1) << 4) : 0;
                         const double* up = W.U + (size_t)q * ldu;
-                        for (int row = 0; row < n; row += 6) {  // (n = 6 x free poses; a block of 6 never straddles 16)
+                        for (int row = 0; row < n; row += 6) {  // (n = 6 x free poses)
                             double u6[6], x6[6];
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
@@ -1127,7 +1186,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     }
                     W.rr[q] = r;
                 }
+                STAMP(14);
                 __syncthreads();
+                STAMP(15);
                 for (int l = tid; l < Lg; l += BA_THREADS) {
                     const double* r = W.rr + 3 * l;
                     const double* cc = W.Cc + 6 * l;
@@ -1141,19 +1202,15 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     }
                 }
             }
-            if (tid < B.F) {
-                for (int i = 0; i < 8; ++i) sPbak[8 * tid + i] = sP[8 * tid + i];
-                if (sSlot[tid] >= 0) {
-                    pose_oplus(sP + 8 * tid, sDx + 6 * tid);
-                    quat_to_R(sP + 8 * tid, sR + 9 * tid);
-                    for (int i = 0; i < 3; ++i) sT[3 * tid + i] = sP[8 * tid + 4 + i];
-                }
-            }
+            STAMP(16);
+            STAMP(17);
             scale = block_sum(scale, sScr);
             __syncthreads();
+            STAMP(18);
             PH_END(8);
             // ============= T6/T7: robust chi2 at the trial state, identical accept / reject decision everywhere
             double tempChi = robust_chi2_local(B, W, Eg, sR, sT, sScr);
+            STAMP(19);
             PH_END(9);
             if (G > 1) {
                 ++tagB;
@@ -1165,16 +1222,20 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 // every workgroup waits for the tagged partials of ALL workgroups: this is also the barrier that
                 // keeps a fast workgroup from overwriting exchange buffers a slow one still reads (a workgroup can
                 // be at most one chi2 exchange ahead, hence the two parity slots)
-                if (!gather_tagged(slot, 2 * G, 2, 2, tag0 + tagB, sX)) sFlag[2] = 1;
+                STAMP(20);
+                if (!gather_tagged(slot, 2 * G, 2, 2, tag0 + tagB, sX, PROF ? &ph[PROF ? 14 : 0] : nullptr)) sFlag[2] = 1;
+                STAMP(21);
                 __syncthreads();
                 if (sFlag[2]) error = 1;
                 tempChi = 0;
                 scale = 0;
+#pragma unroll 8
                 for (int w = 0; w < G; ++w) {
                     tempChi += sX[2 * w];
                     scale += sX[2 * w + 1];
                 }
             }
+            STAMP(22);
             scale += 1e-3;
             if (!ok2) tempChi = 1.7976931348623157e308;
             rho = (currentChi - tempChi) / scale;
@@ -1202,6 +1263,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = W.bak[i];
             }
             __syncthreads();
+            STAMP(23);
             PH_END(10);
             ++qmax;
         } while (rho < 0 && qmax < 10 && !error);
@@ -1252,6 +1314,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             for (int i = 0; i < BA_NPHASE; ++i) st.phase[i] = ph[PROF ? i : 0];
         }
         st.phase[15] = same_l2 ? 1 : 0;
+        if (PROF && B.trace)
+            for (int i = 0; i < 32; ++i) reinterpret_cast<double*>(B.trace + 400)[i] = (double)sStamp[PROF ? i : 0];
         *B.stats = st;
         if (B.h_stats) *B.h_stats = st;
     }

@@ -10,6 +10,7 @@ for kind, kw in kinds:
     mvo.debug_set("ba_wgs", wgs)
     pb = mvo.synth.ba_problem(5, 2000, 7)
     a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+    ctx.ba_trace_enable(True)
     try:
         h = ctx.ba_prepare(*a, **kw)
     except Exception as e:
@@ -25,7 +26,9 @@ for kind, kw in kinds:
             print(kind, "wgs", ph["wgs"], "ms/solve %.3f (wall, production kernel) trials %d same_l2 %d" % (dt*1e3, st["trials"], ph["x15"]))
         else:
             tot = ph["total"]
-            print("   instrumented: ms/solve %.3f" % (dt*1e3), "cyc/us %.0f" % (tot/ (dt*1e6)), {k: round(v/max(st["trials"],1)) for k,v in ph.items() if k not in ("wgs", "x15", "schur.loop", "schur.wait", "schur.acc")})
+            raw = ctx.ba_trace(h, raw_rows=412)[400:406].ravel()
+            print("   timeline of trial 6 (cycles between stamps 0..23):", [int(raw[i + 1] - raw[i]) for i in range(23)])
+            print("   instrumented: ms/solve %.3f" % (dt*1e3), "cyc/us %.0f" % (tot/ (dt*1e6)), {k: round(v/max(st["trials"],1)) for k,v in ph.items() if k not in ("wgs", "x15")})
     mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
 # one-shot path (window rebuilt per call) and batches
