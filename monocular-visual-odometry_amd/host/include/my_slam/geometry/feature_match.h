@@ -1,6 +1,8 @@
-// my_slam/geometry/feature_match.h -- drop-in for the reference's include/my_slam/geometry/feature_match.h:12-46
-// (implementation src/geometry/feature_match.cpp:11-260): the same free functions, same argument meaning, same
+// my_slam/geometry/feature_match.h -- drop-in for the reference's include/my_slam/geometry/feature_match.h:12-54
+// (implementation src/geometry/feature_match.cpp:11-303): the same free functions, same argument meaning, same
 // latching of the parameters on first call, same exception on a wrong method index -- executed by libmvo_hip.so.
+// Every function the reference header declares is defined here, so that src/geometry/feature_match.cpp can be
+// dropped from the build and the callers in src/vo/vo.cpp:139,277,283 and vo_addFrame.cpp still link.
 #ifndef MY_SLAM_FEATURE_MATCH_H
 #define MY_SLAM_FEATURE_MATCH_H
 #include "my_slam/basics/config.h"
@@ -12,7 +14,9 @@ namespace geometry {
 namespace detail {
 // feature_match.cpp:16-19, 42-45, 56-59: parameters are read once (function-local statics in the reference)
 inline void latch_orb_params() {
-    static bool done = false;
+    // per host thread, like the ctx the parameters are latched into (hot_path_ctx() is thread_local): a second host
+    // thread gets its own ctx and must configure it too
+    static thread_local bool done = false;
     if (done) return;
     mvo_orb_params p;
     p.nfeatures = basics::Config::get<int>("number_of_keypoints_to_extract");
@@ -31,16 +35,17 @@ inline bool& reuse_pyramid_flag() {
     static thread_local bool f = false;
     return f;
 }
-// who owns the pyramid cached in the ctx (nullptr after any direct call of the free function)
-inline const void*& pyramid_token() {
-    static thread_local const void* t = nullptr;
+// who owns the pyramid cached in the ctx: the Frame's unique id + 1 (ids are never reused, unlike addresses), 0 after
+// any direct call of the free functions
+inline long long& pyramid_token() {
+    static thread_local long long t = 0;
     return t;
 }
 }  // namespace detail
 
 inline void calcKeyPoints(const cv::Mat& image, vector<cv::KeyPoint>& keypoints) {
     detail::latch_orb_params();
-    detail::pyramid_token() = nullptr;
+    detail::pyramid_token() = 0;
     const int cap = basics::Config::get<int>("max_number_of_keypoints") + 16;
     keypoints.resize(cap);
     int n = 0;
@@ -53,6 +58,8 @@ inline void calcKeyPoints(const cv::Mat& image, vector<cv::KeyPoint>& keypoints)
 /* Compute the descriptors of keypoints. Meanwhile, keypoints might be changed (feature_match.h:15-17). */
 inline void calcDescriptors(const cv::Mat& image, vector<cv::KeyPoint>& keypoints, cv::Mat& descriptors) {
     detail::latch_orb_params();
+    // without the reuse flag this call rebuilds the ctx pyramid from `image`: whoever owned the cached one lost it
+    if (!detail::reuse_pyramid_flag()) detail::pyramid_token() = 0;
     int n = (int)keypoints.size();
     descriptors.create(n > 0 ? n : 1, 32, CV_8UC1);
     mvo_check(mvo_calc_descriptors(hot_path_ctx(), image.data, image.cols, image.rows, (int)image.step,
@@ -115,6 +122,61 @@ inline void matchFeatures(const cv::Mat1b& descriptors_1, const cv::Mat1b& descr
         printf("Using method %d\n", method_index);
         printf("Number of matches: %d\n", int(matches.size()));
     }
+}
+
+// feature_match.cpp:86-124: per keypoint of image 1 the first minimum of the mean absolute descriptor difference
+// among the keypoints of image 2 within max_matching_pixel_dist pixels (the device returns the byte sum: / 32 here).
+inline vector<cv::DMatch> matchByRadiusAndBruteForce(const vector<cv::KeyPoint>& keypoints_1,
+                                                     const vector<cv::KeyPoint>& keypoints_2,
+                                                     const cv::Mat1b& descriptors_1, const cv::Mat1b& descriptors_2,
+                                                     float max_matching_pixel_dist) {
+    const int N1 = (int)keypoints_1.size(), N2 = (int)keypoints_2.size();
+    if (N1 != descriptors_1.rows || N2 != descriptors_2.rows)  // the reference asserts (:94)
+        throw std::runtime_error("matchByRadiusAndBruteForce: keypoints and descriptors differ in number");
+    vector<float> xy1, xy2;
+    for (const cv::KeyPoint& k : keypoints_1) {
+        xy1.push_back(k.pt.x);
+        xy1.push_back(k.pt.y);
+    }
+    for (const cv::KeyPoint& k : keypoints_2) {
+        xy2.push_back(k.pt.x);
+        xy2.push_back(k.pt.y);
+    }
+    vector<int32_t> idx((size_t)(N1 > 0 ? N1 : 1)), sum((size_t)(N1 > 0 ? N1 : 1));
+    mvo_check(mvo_match_radius_l1(hot_path_ctx(), descriptors_1.data, xy1.data(), N1, descriptors_2.data, xy2.data(), N2,
+                                  max_matching_pixel_dist, idx.data(), sum.data()),
+              "matchByRadiusAndBruteForce");
+    vector<cv::DMatch> matches;
+    for (int i = 0; i < N1; ++i)
+        if (idx[i] >= 0) matches.push_back(cv::DMatch(i, idx[i], static_cast<float>((double)sum[i] / descriptors_1.cols)));
+    return matches;
+}
+
+// --------------------- Other assistant functions (feature_match.cpp:263-278; caller vo.cpp:139) ---------------------
+inline double computeMeanDistBetweenKeypoints(const vector<cv::KeyPoint>& kpts1, const vector<cv::KeyPoint>& kpts2,
+                                              const vector<cv::DMatch>& matches) {
+    vector<double> dists_between_kpts;
+    for (const cv::DMatch& d : matches) {
+        const cv::Point2f p1 = kpts1[d.queryIdx].pt, p2 = kpts2[d.trainIdx].pt;
+        const double dx = p1.x - p2.x, dy = p1.y - p2.y;  // basics::calcDist (opencv_funcs.cpp:132-136)
+        dists_between_kpts.push_back(sqrt(dx * dx + dy * dy));
+    }
+    double mean_dist = 0;
+    for (double d : dists_between_kpts) mean_dist += d;
+    mean_dist /= dists_between_kpts.size();  // (0 / 0 = NaN for an empty list, like the reference)
+    return mean_dist;
+}
+
+// --------------------- Datatype conversion (feature_match.cpp:281-303; caller vo.cpp:277) ---------------------
+inline vector<cv::DMatch> inliers2DMatches(const vector<int> inliers) {
+    vector<cv::DMatch> matches;
+    for (auto idx : inliers) matches.push_back(cv::DMatch(idx, idx, 0.0));
+    return matches;
+}
+inline vector<cv::KeyPoint> pts2Keypts(const vector<cv::Point2f> pts) {
+    vector<cv::KeyPoint> keypts;
+    for (cv::Point2f pt : pts) keypts.push_back(cv::KeyPoint(pt, 10));
+    return keypts;
 }
 
 }  // namespace geometry

@@ -61,11 +61,11 @@ public:
     }
     void calcKeyPoints() {
         geometry::calcKeyPoints(rgb_img_, keypoints_);
-        geometry::detail::pyramid_token() = this;  // the ctx now caches THIS frame's pyramid
+        geometry::detail::pyramid_token() = (long long)id_ + 1;  // the ctx now caches THIS frame's pyramid
     }
     void calcDescriptors() {
         // same image as calcKeyPoints -> the device pyramid is reused (the reference builds it twice)
-        geometry::detail::reuse_pyramid_flag() = geometry::detail::pyramid_token() == this;
+        geometry::detail::reuse_pyramid_flag() = geometry::detail::pyramid_token() == (long long)id_ + 1;
         geometry::calcDescriptors(rgb_img_, keypoints_, descriptors_);
         geometry::detail::reuse_pyramid_flag() = false;
         kpts_colors_.clear();

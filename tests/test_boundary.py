@@ -1,0 +1,58 @@
+"""The drop-in headers define everything the reference headers they replace declare (feature_match.h:12-54,
+g2o_ba.h:16-30), and host/tests/test_callsites.cpp calls every one of them -- a function that goes missing fails the
+build of that program (built by __graft_entry__.build()) instead of a maintainer's link step."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HOST = os.path.join(ROOT, "monocular-visual-odometry_amd", "host")
+# the declarations of the two replaced reference headers (names only; kept in step with /root/reference below)
+FEATURE_MATCH_H = ["calcKeyPoints", "calcDescriptors", "matchFeatures", "matchByRadiusAndBruteForce", "removeDuplicatedMatches",
+                   "selectUniformKptsByGrid", "computeMeanDistBetweenKeypoints", "inliers2DMatches", "pts2Keypts"]
+G2O_BA_H = ["optimizeSingleFrame", "bundleAdjustment"]
+
+
+def _declared(path):
+    src = open(path).read()
+    src = re.sub(r"//[^\n]*|/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"^\s*(?:[A-Za-z_:<>\s\*&]+?)\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src, flags=re.M)))
+
+
+def test_name_lists_match_the_reference_headers_when_present():
+    ref = "/root/reference/include/my_slam"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not on this machine (GPU box)")
+    assert _declared(os.path.join(ref, "geometry", "feature_match.h")) == sorted(FEATURE_MATCH_H)
+    assert _declared(os.path.join(ref, "optimization", "g2o_ba.h")) == sorted(G2O_BA_H)
+
+
+def test_drop_in_headers_define_every_function():
+    fm = open(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h")).read()
+    ba = open(os.path.join(HOST, "include", "my_slam", "optimization", "g2o_ba.h")).read()
+    for name in FEATURE_MATCH_H:
+        assert re.search(r"\binline\b[^;{]*\b%s\s*\(" % name, fm), "feature_match.h lacks %s" % name
+    for name in G2O_BA_H:
+        assert re.search(r"\binline\b[^;{]*\b%s\s*\(" % name, ba), "g2o_ba.h lacks %s" % name
+
+
+def test_callsite_program_uses_every_function_and_links():
+    src = open(os.path.join(HOST, "tests", "test_callsites.cpp")).read()
+    frame = open(os.path.join(HOST, "include", "my_slam", "vo", "frame.h")).read()
+    for name in FEATURE_MATCH_H:
+        assert re.search(r"geometry::%s\s*\(" % name, src + frame), "no call site for geometry::%s" % name
+    for name in G2O_BA_H:
+        assert re.search(r"optimization::%s\s*\(" % name, src), "no call site for optimization::%s" % name
+    exe = os.path.join(HOST, "tests", "test_callsites")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libmvo_hip.so" in ldd and "liboracle" not in ldd
+
+
+def test_orb_parameters_are_latched_per_host_thread():
+    """hot_path_ctx() is thread_local, so must be the 'parameters latched' flag."""
+    fm = open(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h")).read()
+    assert re.search(r"static\s+thread_local\s+bool\s+done", fm)
