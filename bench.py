@@ -5,21 +5,26 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One rank per GPU.  Every rank owns `--streams` independent sequence shards (S640, seed 1234 + shard id), each
-driven by its own host thread + mvo_ctx (= HIP stream): the path is serial inside a sequence and embarrassingly
-parallel across sequences, so this is how one GPU is filled.  A "step" = one frame of every shard
-of the rank: extract (image already resident in HBM) -> descriptors stay in HBM -> match against the previous
-frame's descriptors (2-NN Hamming + Lowe ratio + de-dup) -> one full LM bundle adjustment of a resident BA5
-window (5 poses / 2000 landmarks / ~10k edges, 50 iterations).  Weak scaling: per-GPU work is fixed.
-The only collective is one all_gather of the per-shard trajectories (frames x 12 f64) after the timed region.
-Prints ONE JSON line on rank 0.
+driven by its own host thread through the native frame loop (host/driver/frame_loop.cpp): the path is serial inside
+a sequence and embarrassingly parallel across sequences, so this is how one GPU is filled.  A "step" =
+one frame of every shard of the rank:
+  extract (image already resident in HBM) -> descriptors stay in HBM -> match against the previous frame's descriptors
+  (2-NN Hamming + Lowe ratio + de-dup) -> bundle adjustment of a NEW BA5 window (5 poses / 2000 landmarks / ~10k edges,
+  50 LM iterations): every frame the window is marshalled from Frame / MapPoint objects into pointer lists as
+  src/vo/vo.cpp:408-449 does, flattened, planned, uploaded, solved and written back (g2o_ba.cpp:172-317); a shard
+  rotates through `--windows` distinct windows.
+Weak scaling: per-GPU work is fixed.  The only collective is one all_gather of the per-shard trajectories (frames x 12
+f64, the refined pose of the newest frame of every window) after the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
 
-# one HIP stream per sequence shard: lift the runtime's default of 4 hardware queues BEFORE HIP initialises
+# one HIP stream per sequence shard (+ one per shard for uploads): lift the runtime's default of 4 hardware queues
+# BEFORE HIP initialises
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import threading
 import time
@@ -32,24 +37,26 @@ import __graft_entry__ as graft  # noqa: E402
 
 METRIC = "frames/sec (extract+match+5-kf BA), 640x480 / 2000 kp, 1->8 MI355X"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_PEAK_TFLOPS = 78.6        # datasheet FP64 vector/matrix peak (not in the local guide)
+FP64_PEAK_TFLOPS = 78.6        # FP64 vector = matrix peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; one
+#                                v_mfma_f64_16x16x4_f64 (2048 flop) issues every 64 cycles per SIMD (tools/probes/mfma_probe.hip)
 VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s = 7.86e13
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=12, help="sequence shards in flight per GPU")
-    ap.add_argument("--ba", default="full", choices=["full", "full_fix0", "pose_only"],
+    ap.add_argument("--streams", type=int, default=24, help="sequence shards in flight per GPU")
+    ap.add_argument("--ba", default="full", choices=["full", "pose_only"],
                     help="full = points + poses free (reference is_fix_map_pts=false branch, no vertex fixed)")
-    ap.add_argument("--profile-all", action="store_true",
-                    help="diagnostic: HIP-event profiling on every shard DURING the timed region; prints the average "
-                         "k_ba_lm duration under load to stderr (adds event overhead to the measured value)")
-    ap.add_argument("--python-loop", action="store_true",
-                    help="drive the per-frame C-ABI calls from Python threads instead of the native frame loop "
-                         "(host/driver/frame_loop.cpp); the same calls, but serialised by the interpreter lock")
+    ap.add_argument("--ba-mode", default="rebuild", choices=["rebuild", "resident", "none"],
+                    help="rebuild (the metric): a new window is marshalled, uploaded and solved every frame; resident: one "
+                         "pre-uploaded window re-solved every frame (kernel-side upper bound, round-1 behaviour)")
+    ap.add_argument("--windows", type=int, default=16, help="distinct BA windows per shard (rotated)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1 (default): every shard overlaps extraction+matching of frame i+1 with the BA of frame i (second "
+                         "ctx per shard for the uploads); 0: strictly serial frame loop")
     ap.add_argument("--track", action="store_true",
                     help="also run the tracking rows every frame (map points in view -> match against the map -> "
                          "solvePnPRansac, vo.cpp:270-357); off by default: BASELINE.json's metric is extract+match+BA")
@@ -58,6 +65,7 @@ def parse():
                          "vo_addFrame.cpp:93-118) on every N-th frame")
     ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the single-sequence and resident-window runs")
     ap.add_argument("--cpu-frames", type=int, default=150)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="also time the oracle with this many host threads, one sequence shard each (0 = skip)")
@@ -66,33 +74,23 @@ def parse():
     ap.add_argument("--max-kp", type=int, default=2000)
     ap.add_argument("--ba-poses", type=int, default=5)
     ap.add_argument("--ba-points", type=int, default=2000)
-    return ap.parse_args()
-
-
-def ba_kwargs(kind, n_poses):
-    if kind == "pose_only":
-        return dict(fix_points=True)
-    if kind == "full_fix0":
-        f = np.zeros(n_poses, np.uint8)
-        f[0] = 1
-        return dict(fix_points=False, pose_fixed=f)
-    return dict(fix_points=False)
+    return ap.parse_args(argv)
 
 
 class FrameLoopCfg(C.Structure):  # host/driver/frame_loop.cpp: struct frame_loop_cfg
-    _fields_ = [("ctx", C.c_void_p), ("d_frames", C.POINTER(C.c_void_p)), ("n_frames", C.c_int32), ("width", C.c_int32),
-                ("height", C.c_int32), ("stride", C.c_int32), ("channels", C.c_int32), ("max_kp", C.c_int32),
-                ("ba", C.c_void_p), ("n_poses", C.c_int32), ("track", C.c_int32), ("keyframe_every", C.c_int32),
-                ("map", C.c_void_p), ("n_map", C.c_int32), ("T_w_c", C.c_void_p), ("K4", C.c_double * 4),
-                ("pts3d", C.c_void_p), ("pts2d", C.c_void_p), ("n_pairs", C.c_int32), ("kf_ref", C.c_void_p),
-                ("kf_cur", C.c_void_p), ("kf_n", C.c_int32), ("kf_T_curr_to_prev", C.c_void_p),
-                ("kf_T_w_cur", C.c_void_p), ("kf_T_w_ref", C.c_void_p)]
+    _fields_ = [("ctx", C.c_void_p), ("ctx_ba", C.c_void_p), ("d_frames", C.POINTER(C.c_void_p)), ("n_frames", C.c_int32),
+                ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32), ("channels", C.c_int32),
+                ("max_kp", C.c_int32), ("ba_mode", C.c_int32), ("pipeline", C.c_int32), ("fix_points", C.c_int32),
+                ("K4", C.c_double * 4), ("track", C.c_int32), ("keyframe_every", C.c_int32), ("map", C.c_void_p),
+                ("n_map", C.c_int32), ("T_w_c", C.c_void_p), ("pts3d", C.c_void_p), ("pts2d", C.c_void_p),
+                ("n_pairs", C.c_int32), ("kf_ref", C.c_void_p), ("kf_cur", C.c_void_p), ("kf_n", C.c_int32),
+                ("kf_T_curr_to_prev", C.c_void_p), ("kf_T_w_cur", C.c_void_p), ("kf_T_w_ref", C.c_void_p)]
 
 
 class FrameLoopState(C.Structure):
-    _fields_ = [("prev_desc", C.c_void_p), ("prev_n", C.c_int32), ("frame_no", C.c_int32), ("n_kp", C.c_int32),
-                ("n_match", C.c_int32), ("n_inliers", C.c_int32), ("n_tri", C.c_int32), ("ba_trials", C.c_int32),
-                ("ba_iterations", C.c_int32)]
+    _fields_ = [("frame_no", C.c_int32), ("n_kp", C.c_int32), ("n_match", C.c_int32), ("n_inliers", C.c_int32),
+                ("n_tri", C.c_int32), ("ba_trials", C.c_int64), ("ba_iterations", C.c_int64), ("ba_solves", C.c_int64),
+                ("ba_edges", C.c_int64)]
 
 
 _frame_loop = None
@@ -102,65 +100,68 @@ def frame_loop_lib():
     """host/driver/libmvo_frame_loop.so (built by __graft_entry__.build()); fails loudly when missing."""
     global _frame_loop
     if _frame_loop is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "monocular-visual-odometry_amd", "host", "driver",
-                            "libmvo_frame_loop.so")
+        path = os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "driver", "libmvo_frame_loop.so")
         if not os.path.exists(path):
             raise SystemExit("native frame loop %s is missing -- run __graft_entry__.build()" % path)
-        _frame_loop = C.CDLL(path)
-        _frame_loop.frame_loop_run.argtypes = [C.POINTER(FrameLoopCfg), C.POINTER(FrameLoopState), C.c_int, C.c_void_p]
+        lib = C.CDLL(path)
+        lib.frame_loop_create.restype = C.c_void_p
+        lib.frame_loop_create.argtypes = [C.POINTER(FrameLoopCfg)]
+        lib.frame_loop_add_window.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
+        lib.frame_loop_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.frame_loop_get_state.argtypes = [C.c_void_p, C.POINTER(FrameLoopState)]
+        lib.frame_loop_destroy.argtypes = [C.c_void_p]
+        _frame_loop = lib
     return _frame_loop
 
 
-class Shard:
-    """One sequence: its frames resident in HBM, its own ctx/stream, its resident BA window."""
+def window_pool(mvo, args, shard_id, n):
+    """`n` distinct synthetic BA windows of a shard (SURVEY.md 8d config 3 generator, different seeds)."""
+    K = mvo.synth.FR1_K if args.width == 640 else mvo.synth.KITTI_K
+    return [mvo.synth.ba_problem(args.ba_poses, args.ba_points, seed=7 + 1000 * shard_id + k, width=args.width,
+                                 height=args.height, K=K) for k in range(n)]
 
-    def __init__(self, mvo, torch, device, shard_id, args):
+
+class Shard:
+    """One sequence: its frames resident in HBM, its own ctx/stream(s), its pool of BA windows, its native loop."""
+
+    def __init__(self, mvo, torch, device, shard_id, args, ba_mode, pipeline, frames=None, pool=None):
         self.mvo = mvo
         self.id = shard_id
         self.args = args
         self.ctx = mvo.Context(device, max_keypoints=args.max_kp)
-        seq = mvo.synth.Sequence(args.width, args.height, args.frames, seed=1234 + shard_id, tex_size=1024)
-        self.host_frames = [seq.frame(i) for i in range(args.frames)]
-        self.dev_frames = [torch.from_numpy(f).to("cuda:%d" % device) for f in self.host_frames]
-        K = mvo.synth.FR1_K if args.width == 640 else mvo.synth.KITTI_K
-        self.pb = mvo.synth.ba_problem(args.ba_poses, args.ba_points, seed=7 + shard_id, width=args.width,
-                                       height=args.height, K=K)
-        pb = self.pb
-        self.ba_args = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"],
-                        pb["cx"], pb["cy"])
-        self.ba_kw = ba_kwargs(args.ba, args.ba_poses)
-        self.ba = self.ctx.ba_prepare(*self.ba_args, **self.ba_kw)
+        self.ctx_ba = mvo.Context(device, max_keypoints=args.max_kp) if pipeline else self.ctx
+        if frames is None:
+            seq = mvo.synth.Sequence(args.width, args.height, args.frames, seed=1234 + shard_id, tex_size=1024)
+            host = [seq.frame(i) for i in range(args.frames)]
+            frames = (host, [torch.from_numpy(f).to("cuda:%d" % device) for f in host])
+        self.host_frames, self.dev_frames = frames
+        self.K = mvo.synth.FR1_K if args.width == 640 else mvo.synth.KITTI_K
+        self.pool = pool if pool is not None else window_pool(mvo, args, shard_id, max(1, args.windows))
         self.track = None
         if args.track:            # a resident map + the 3D-2D pairs PnP sees (SURVEY.md 8f ranks 1-2)
-            tp = mvo.synth.tracking_problem(n_map=3000, seed=11 + shard_id, width=args.width, height=args.height, K=K)
+            tp = mvo.synth.tracking_problem(n_map=3000, seed=11 + shard_id, width=args.width, height=args.height, K=self.K)
             self.track = tp
             self.map = self.ctx.map_create()
             self.ctx.map_upload(self.map, tp["map_pos"], tp["map_desc"])
-            self.n_inliers = 0
-            self.kf = mvo.synth.keyframe_problem(n=1000, seed=21 + shard_id, width=args.width, height=args.height, K=K)
-            self.n_tri = 0
-        self.prev = None          # (device ptr, n) of the previous frame's descriptors
+            self.kf = mvo.synth.keyframe_problem(n=1000, seed=21 + shard_id, width=args.width, height=args.height, K=self.K)
         self.traj = []
-        self.n_kp = self.n_match = 0
-        self.frame_no = 0
-        self.native = None
-        if not args.python_loop:
-            self._setup_native(K)
+        self._setup_native(ba_mode, pipeline)
 
-    def _setup_native(self, K):
+    def _setup_native(self, ba_mode, pipeline):
         """Everything the native frame loop needs, as plain pointers (kept alive on self)."""
         a = self.args
         c = FrameLoopCfg()
-        c.ctx = self.ctx.h
+        c.ctx, c.ctx_ba = self.ctx.h, self.ctx_ba.h
         self._fr = (C.c_void_p * len(self.dev_frames))(*[t.data_ptr() for t in self.dev_frames])
         c.d_frames = C.cast(self._fr, C.POINTER(C.c_void_p))
         c.n_frames, c.width, c.height, c.stride, c.channels, c.max_kp = len(self.dev_frames), a.width, a.height, a.width * 3, 3, a.max_kp
-        c.ba = self.ba[0]
-        c.n_poses = self.ba[1]
+        c.ba_mode = {"none": 0, "rebuild": 1, "resident": 2}[ba_mode]
+        c.pipeline = 1 if pipeline else 0
+        c.fix_points = 1 if a.ba == "pose_only" else 0
         c.track = 1 if self.track is not None else 0
         c.keyframe_every = a.keyframe_every
         for i, k in enumerate(("fx", "fy", "cx", "cy")):
-            c.K4[i] = K[k]
+            c.K4[i] = self.K[k]
         if self.track is not None:
             tp, kf = self.track, self.kf
             self._keep = [np.ascontiguousarray(tp["T_w_c"], np.float64), np.ascontiguousarray(tp["pts3d"], np.float32),
@@ -172,61 +173,37 @@ class Shard:
             c.T_w_c, c.pts3d, c.pts2d, c.n_pairs = ptr[0], ptr[1], ptr[2], len(tp["pts3d"])
             c.kf_ref, c.kf_cur, c.kf_n = ptr[3], ptr[4], len(kf["kp_ref"])
             c.kf_T_curr_to_prev, c.kf_T_w_cur, c.kf_T_w_ref = ptr[5], ptr[6], ptr[7]
-        self.native = c
-        self.nstate = FrameLoopState()
+        self.cfg = c
+        lib = frame_loop_lib()
+        self.loop = lib.frame_loop_create(C.byref(c))
+        if ba_mode != "none":
+            for pb in (self.pool if ba_mode == "rebuild" else self.pool[:1]):
+                arrs = [np.ascontiguousarray(pb["poses0"], np.float64), np.ascontiguousarray(pb["points0"], np.float64),
+                        np.ascontiguousarray(pb["edge_pose"], np.int32), np.ascontiguousarray(pb["edge_point"], np.int32),
+                        np.ascontiguousarray(pb["edge_uv"], np.float64)]
+                r = lib.frame_loop_add_window(self.loop, len(arrs[0]), len(arrs[1]), len(arrs[2]), *[x.ctypes.data_as(C.c_void_p) for x in arrs])
+                if r != 0:
+                    raise RuntimeError("frame_loop_add_window failed (%d): %s" % (r, self.ctx_ba.last_error()))
+
+    def state(self):
+        st = FrameLoopState()
+        frame_loop_lib().frame_loop_get_state(self.loop, C.byref(st))
+        return st
 
     def run(self, n):
-        """n frames: one call into the native loop (or n Python-driven steps with --python-loop)."""
-        if self.native is None:
-            for _ in range(n):
-                self.step()
-            return
+        """n frames: one call into the native loop (the GIL is released for its whole duration)."""
         out = np.zeros((n, 12))
-        t0, i0 = self.nstate.ba_trials, self.nstate.ba_iterations
-        r = frame_loop_lib().frame_loop_run(C.byref(self.native), C.byref(self.nstate), n, out.ctypes.data_as(C.c_void_p))
+        r = frame_loop_lib().frame_loop_run(self.loop, n, out.ctypes.data_as(C.c_void_p))
         if r != 0:
-            raise RuntimeError("frame loop failed (%d): %s" % (r, (self.ctx.lib.mvo_last_error(self.ctx.h) or b"").decode()))
+            raise RuntimeError("frame loop failed (%d): %s | %s" % (r, self.ctx.last_error(), self.ctx_ba.last_error()))
         self.traj.extend(list(out))
-        st = self.nstate
-        self.n_kp, self.n_match, self.frame_no = st.n_kp, st.n_match, st.frame_no
-        if self.track is not None:
-            self.n_inliers, self.n_tri = st.n_inliers, st.n_tri
-        self.last_stats = {"trials": (st.ba_trials - t0) / max(n, 1), "iterations": (st.ba_iterations - i0) / max(n, 1)}
 
-    def step(self):
-        a = self.args
-        i = self.frame_no % a.frames
-        t = self.dev_frames[i]
-        ctx = self.ctx
-        k = ctx.calc_keypoints_dev(t.data_ptr(), a.width, a.height, a.width * 3, 3, cap=a.max_kp + 16)
-        k, _, dptr = ctx.calc_descriptors_dev(k, want_host=False)
-        if self.prev is not None and len(k) and self.prev[1]:
-            m = ctx.match_features_dev(self.prev[0], self.prev[1], dptr, len(k), 2, 2.0, 0.8)
-            self.n_match = len(m)
-        self.prev = (dptr, len(k))
-        if self.track is not None:
-            tp = self.track
-            idx, _, d_map = ctx.map_points_in_view(self.map, tp["T_w_c"], tp["K"], a.width, a.height, cap=len(tp["map_pos"]))
-            if len(idx) and len(k):
-                ctx.match_features_dev(d_map, len(idx), dptr, len(k), 1, 2.0, 1.0)
-            pose = ctx.solve_pnp_ransac(tp["pts3d"], tp["pts2d"], tp["K"])
-            self.n_inliers = len(pose["inliers"])
-        ctx.ba_solve_resident(self.ba)
-        P, _, st = ctx.ba_fetch(self.ba, want_points=False)
-        if self.track is not None and self.frame_no % a.keyframe_every == 0:
-            # keyframe insertion after BA (vo_addFrame.cpp:93-118): epipolar inlier filter, triangulation, culling
-            kf = self.kf
-            inl = ctx.find_essential_inliers(kf["kp_ref"], kf["kp_cur"], kf["K"])
-            Tk = kf["T_curr_to_prev"]
-            _, pc = ctx.triangulate_points(kf["kp_ref"][inl], kf["kp_cur"][inl], kf["K"], Tk[:3, :3], Tk[:3, 3])
-            keep, _ = self.mvo.retain_good_triangulation(pc, kf["T_w_cur"], kf["T_w_ref"])
-            self.n_tri = len(keep)
-        self.n_kp = len(k)
-        self.last_stats = st
-        # trajectory row like vo_io.cpp:58-75: x y z then R column-major (newest frame of the window)
-        T = P[0]
-        self.traj.append(np.concatenate([T[:3, 3], T[:3, :3].T.ravel()]))
-        self.frame_no += 1
+    def close(self):
+        frame_loop_lib().frame_loop_destroy(self.loop)
+        self.loop = None
+        if self.ctx_ba is not self.ctx:
+            self.ctx_ba.close()
+        self.ctx.close()
 
 
 def shard_ids(rank, streams):
@@ -257,8 +234,7 @@ def gather_trajectories(dist, traj, device):
 
 
 def run_steps(shards, n):
-    """Every shard advances n frames on its own thread: one call into the native frame loop each (the GIL is
-    released for its whole duration), or Python-driven steps with --python-loop."""
+    """Every shard advances n frames on its own thread: one call into the native frame loop each."""
     errs = []
 
     def work(s):
@@ -276,22 +252,35 @@ def run_steps(shards, n):
         raise errs[0]
 
 
-def algorithmic_work(args, shard):
-    """Per-launch algorithmic bytes / flops of each kernel."""
+def timed_run(shards, steps, sync):
+    sync()
+    t0 = time.perf_counter()
+    run_steps(shards, steps)
+    for s in shards:
+        s.ctx.synchronize()
+    sync()
+    return time.perf_counter() - t0
+
+
+def ba_trial_flops(E, L, F, fix_points):
+    """Algorithmic flops of one LM trial: linearize + pose blocks, landmark blocks + Schur, reduced
+    solve, back-substitution, chi2."""
+    n = E / max(L, 1)
+    return 330 * E + (0 if fix_points else L * (40 + 144 * n + 216 * n * (n + 1) / 2) + 200 * L) + (6 * F) ** 3 / 3 + 60 * E
+
+
+def algorithmic_work(args):
+    """Per-launch algorithmic bytes / lane-ops of the extraction and matching kernels."""
     w, h, K = args.width, args.height, args.max_kp
-    mvo = shard.mvo
     lv = [(w, h)]
     for l in range(1, 4):
         s = np.float32(1.2) ** l
         lv.append((int(np.rint(w / s)), int(np.rint(h / s))))
     P = sum(a * b for a, b in lv)
-    E, L, F = len(shard.pb["edge_pose"]), args.ba_points, args.ba_poses
-    n = E / max(L, 1)
-    ba_trial = 330 * E + (0 if args.ba == "pose_only" else L * (40 + 144 * n + 216 * n * (n + 1) / 2) + 200 * L) \
-        + (6 * F) ** 3 / 3 + 60 * E
     return {
         "k_gray_border": ("hbm", w * h * 3 + w * h),
         "k_resize_border": ("hbm", 2 * (P - w * h) / 3.0),            # per launch (3 launches / frame)
+        "k_pyramid": ("hbm", w * h * 3 + P),
         "k_fast_nms": ("hbm", P),
         "k_scan_cells": ("hbm", 8 * 12400),
         "k_emit_cells": ("hbm", 12 * 12400 + 16 * 8000),
@@ -299,143 +288,205 @@ def algorithmic_work(args, shard):
         "k_blur": ("hbm", 2 * P),
         "k_brief": ("hbm", (961 + 32 + 16) * K),
         "k_knn2_partial": ("valu", 16.0 * K * K),
+        "k_knn2": ("valu", 16.0 * K * K),
         "k_knn2_merge": ("hbm", 32 * 16.0 * K),
-        "k_ba_lm": ("fp64", ba_trial),                               # x trials, filled in by the caller
-    }, mvo
+    }
 
 
-def main():
-    args = parse()
-    import torch
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_*.csv:
+    separate --pmc FETCH_SIZE / WRITE_SIZE passes; columns kernel, fetch_kb, write_kb per dispatch).  None if absent."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_size_per_kernel.csv"))):
+        try:
+            for line in open(path):
+                f = [x.strip().strip('"') for x in line.split(",")]
+                if len(f) >= 3 and f[0].startswith(kernel):
+                    best = ((float(f[1]) + float(f[2])) * 1024.0, os.path.relpath(path, ROOT))
+        except (OSError, ValueError):
+            pass
+    return best
+
+
+class GpuEnv:
+    """What main() needs from the machine: the process group, the device, barriers and shards.  tests/ substitute a CPU
+    stand-in (gloo, stub shards) to execute the N > 1 control flow without a GPU."""
+    backend = "nccl"
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        torch.cuda.set_device(self.local)
+        self.device = "cuda"
+        self.mvo = graft.load_package()
+
+    def init_process_group(self, dist):
+        dist.init_process_group(self.backend, device_id=self.torch.device("cuda", self.local))
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def make_shard(self, shard_id, args, ba_mode, pipeline, **kw):
+        return Shard(self.mvo, self.torch, self.local, shard_id, args, ba_mode, pipeline, **kw)
+
+
+def run_benchmark(args, env):
+    """Warm-up, the timed region (barrier + device sync on both sides, MAX over ranks), the one collective.  Returns what
+    the report needs; identical control flow for 1 and N ranks."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local)
-    mvo = graft.load_package()
-
-    shards = [Shard(mvo, torch, local, sid, args) for sid in shard_ids(rank, args.streams)]
-    torch.cuda.synchronize()
+        env.init_process_group(dist)
+    pipeline = args.pipeline == 1
+    shards = [env.make_shard(sid, args, args.ba_mode, pipeline) for sid in shard_ids(rank, args.streams)]
+    env.sync()
 
     def barrier():
-        torch.cuda.synchronize()
+        env.sync()
         if dist is not None:
             dist.barrier()
 
     run_steps(shards, args.warmup)
-    if args.profile_all:
-        for s in shards:
-            s.ctx.profile_enable(True)
-            s.ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(shards, args.steps)
-    for s in shards:
-        s.ctx.synchronize()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    if args.profile_all:
-        tot = {}
-        for s in shards:
-            for k, (n_, ms) in s.ctx.profile_get().items():
-                a = tot.setdefault(k, [0, 0.0])
-                a[0] += n_
-                a[1] += ms
-            s.ctx.profile_enable(False)
-        print("under load (%d shards): " % len(shards) + ", ".join("%s %.1f us" % (k, 1e3 * v[1] / max(v[0], 1))
-                                                                  for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])),
-              file=sys.stderr)
-    elapsed = max_over_ranks(dist, t1 - t0, "cuda")
+    st_before = [s.state() for s in shards]
+    shards[0].ctx.ba_launch_stats(reset=True)
+    elapsed_local = timed_run(shards, args.steps, barrier)
+    launch = shards[0].ctx.ba_launch_stats()
+    st_after = [s.state() for s in shards]
+    elapsed = max_over_ranks(dist, elapsed_local, env.device)
     frames_total = world * args.streams * args.steps
-    value = frames_total / elapsed
-
     # ---- the one collective: gather the trajectories (frames x 12 f64 per shard)
     traj = np.stack([np.stack(s.traj[-args.steps:]) for s in shards])           # [streams, steps, 12]
-    traj_all = gather_trajectories(dist, traj, "cuda")
+    traj_all = gather_trajectories(dist, traj, env.device)
     assert traj_all.shape == (world, args.streams, args.steps, 12) and np.isfinite(traj_all).all()
-    # every shard re-solves its resident window each frame: the solver is bit-reproducible, so must be the rows
-    assert (traj == traj[:, :1]).all(), "BA results changed between identical solves (race under concurrency?)"
+    return dict(world=world, rank=rank, dist=dist, shards=shards, pipeline=pipeline, elapsed=elapsed, value=frames_total / elapsed,
+                launch=launch, st_before=st_before, st_after=st_after, traj_all=traj_all)
+
+
+def main(argv=None, env=None):
+    args = parse(argv)
+    env = env or GpuEnv(args)
+    R = run_benchmark(args, env)
+    world, rank, dist, shards, pipeline = R["world"], R["rank"], R["dist"], R["shards"], R["pipeline"]
+    elapsed, value, launch, st_before, st_after = R["elapsed"], R["value"], R["launch"], R["st_before"], R["st_after"]
+    s0 = shards[0]
 
     result = None
     if rank == 0:
-        # ---- per-kernel durations: HIP events on the ctx stream around every launch (mvo_profile_*)
-        s0 = shards[0]
+        trials = sum(a.ba_trials - b.ba_trials for a, b in zip(st_after, st_before))
+        solves = sum(a.ba_solves - b.ba_solves for a, b in zip(st_after, st_before))
+        edges = sum(a.ba_edges - b.ba_edges for a, b in zip(st_after, st_before))
+        E_avg = edges / max(solves, 1)
+        fix = args.ba == "pose_only"
+        # ---- dominant kernel: k_ba_lm.  Duration = HIP events around every launch on the stream it is launched on
+        # (the library's launch thread); algorithmic flops = trials solved in the timed region x flops per trial.
+        per_kernel = {}
+        if solves:
+            flops = trials * ba_trial_flops(E_avg, args.ba_points, args.ba_poses, fix)
+            avg_ms = launch["ms"] / max(launch["launches"], 1)
+            roof = dict(bound="mfma", achieved=flops / (launch["ms"] * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+            roof["frac"] = roof["achieved"] / roof["peak"]
+            roof.update(kernel="k_ba_lm", avg_launch_ms=avg_ms, launches=launch["launches"],
+                        windows_per_launch=launch["windows"] / max(launch["launches"], 1),
+                        algorithmic_per_launch=flops / max(launch["launches"], 1),
+                        trials_per_solve=trials / max(solves, 1))
+            tr = pmc_traffic("k_ba_lm")
+            # HBM-side bytes per launch from the rocprofv3 PMC passes of this workload; the hand-offs are 8-byte accesses, a
+            # width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported uncorrected
+            roof["traffic"], roof["traffic_source"] = (tr[0], tr[1]) if tr else (None, None)
+            per_kernel["k_ba_lm"] = launch["ms"] / max(args.steps * args.streams, 1)
+        else:
+            roof = None
+        # ---- per-kernel durations of the other kernels: HIP events on the ctx stream of one shard (mvo_profile_*)
         s0.ctx.profile_enable(True)
         s0.ctx.profile_reset()
         nprof = min(20, max(args.steps, 5))
-        trials0 = 0
-        for _ in range(nprof):
-            s0.run(1)
-            trials0 += s0.last_stats["trials"]
+        s0.run(nprof)
         prof = s0.ctx.profile_get()
         s0.ctx.profile_enable(False)
-        work, _ = algorithmic_work(args, s0)
-        per_frame = {k: v[1] / nprof for k, v in prof.items()}                     # ms per frame per kernel
-        dom = max(per_frame, key=per_frame.get)
-        launches, total_ms = prof[dom]
-        avg_ms = total_ms / launches
-        kind, amount = work.get(dom, ("hbm", 0.0))
-        if dom == "k_ba_lm":
-            amount *= trials0 / nprof
-        if kind == "hbm":
-            roof = dict(bound="hbm", achieved=amount / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
-        elif kind == "valu":
-            roof = dict(bound="valu", achieved=amount / (avg_ms * 1e-3) / 1e12, peak=VALU_PEAK_TOPS, unit="Tlane-op/s")
-        else:
-            roof = dict(bound="mfma", achieved=amount / (avg_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM-side bytes per launch from rocprofv3 PMC passes of THIS workload (profiles/r01_pmc_*.csv: separate
-        # --pmc FETCH_SIZE / WRITE_SIZE runs); the BA kernel's traffic is 8-byte write-through partial exchange,
-        # a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported uncorrected.
-        default_workload = (args.width, args.height, args.max_kp, args.ba_poses, args.ba_points, args.ba) == \
-            (640, 480, 2000, 5, 2000, "full")
-        pmc_kb = {"k_ba_lm": 28419.6 + 55262.5, "k_fast_nms": 2 * 1526.0 + 818.7, "k_blur": 2 * 2217.1 + 1012.1,
-                  "k_knn2_partial": 2 * 295.4 + 1016.5}
-        roof["traffic"] = pmc_kb[dom] * 1024 if (default_workload and dom in pmc_kb) else None
-        roof["traffic_source"] = "profiles/r01_pmc_fetch_write_size_per_kernel.csv" if roof["traffic"] else None
-        roof["kernel"] = dom
-        roof["avg_launch_ms"] = avg_ms
-        roof["algorithmic_per_launch"] = amount
+        work = algorithmic_work(args)
+        kern = {}
+        for k, (n_, ms) in prof.items():
+            if k == "k_ba_lm":
+                continue
+            per_kernel[k] = ms / nprof
+            kind, amount = work.get(k, ("hbm", 0.0))
+            avg = ms / max(n_, 1)
+            kern[k] = dict(avg_launch_us=round(avg * 1e3, 2), launches_per_frame=round(n_ / nprof, 2),
+                           frac=round((amount / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if kind == "hbm" else
+                                      (amount / (avg * 1e-3) / 1e12 / VALU_PEAK_TOPS), 5), bound=kind)
+        if roof is None and per_kernel:
+            dom = max(per_kernel, key=per_kernel.get)
+            roof = dict(kernel=dom, **kern.get(dom, {}))
 
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, shards[0])
+        # ---- secondary numbers: one sequence alone (extraction of frame i+1 overlapped with the BA of frame i), and the
+        # round-1 style "resident window" rate (kernel-side upper bound: nothing is marshalled or uploaded per frame)
+        secondary = {}
+        if not args.no_secondary and args.ba_mode == "rebuild":
+            frames0 = (s0.host_frames, s0.dev_frames)
+            one = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", True, frames=frames0, pool=s0.pool)
+            one.run(max(5, args.warmup))
+            nsingle = max(30, args.steps)
+            dt = timed_run([one], nsingle, env.sync)
+            secondary["single_sequence_fps"] = nsingle / dt
+            secondary["single_sequence_note"] = "1 shard, extraction+matching of frame i+1 overlapped with the BA of frame i (2 ctx)"
+            one_serial = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", False, frames=frames0, pool=s0.pool)
+            one_serial.run(max(5, args.warmup))
+            dt = timed_run([one_serial], nsingle, env.sync)
+            secondary["single_sequence_serial_fps"] = nsingle / dt
+            one.close()
+            one_serial.close()
+            res = [env.make_shard(s.id, args, "resident", False, frames=(s.host_frames, s.dev_frames), pool=s.pool[:1])
+                   for s in shards[:12]]
+            run_steps(res, max(5, args.warmup))
+            nres = max(20, args.steps // 2)
+            dt = timed_run(res, nres, env.sync)
+            secondary["resident_window_fps"] = len(res) * nres / dt
+            secondary["resident_window_note"] = ("round-1 mode, %d shards, serial frame loop: ONE pre-uploaded window re-solved "
+                                                 "per frame (no marshalling / upload)" % len(res))
+            for r_ in res:
+                r_.close()
 
+        cpu = None if args.no_cpu_baseline else cpu_baseline(args, shards[0])
         cpu_mt = None
         if not args.no_cpu_baseline and args.cpu_threads > 1:
             cpu_mt = cpu_baseline_threads(args, shards[0], args.cpu_threads)
+        st = st_after[0]
         result = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (extract/match) + f64 (BA)", "data": "synthetic",
             "config": {"workload": "S%d: %dx%d BGR frames resident in HBM, <=%d kp (ORB 8000 -> grid), 2-NN Hamming + "
-                                   "Lowe 0.8 + de-dup vs previous frame, BA%d %s (%d poses / %d landmarks / %d edges, "
-                                   "50 LM iterations)" % (args.width, args.width, args.height, args.max_kp + 1,
-                                                          args.ba_poses, args.ba, args.ba_poses, args.ba_points,
-                                                          len(s0.pb["edge_pose"])),
+                                   "Lowe 0.8 + de-dup vs previous frame, BA%d %s with the BA window rebuilt per frame "
+                                   "(%d distinct windows per shard rotated; marshalled from Frame/MapPoint objects like "
+                                   "vo.cpp:408-449, flattened, uploaded, solved, written back: %d poses / %d landmarks / "
+                                   "~%d edges, 50 LM iterations)"
+                                   % (args.width, args.width, args.height, args.max_kp + 1, args.ba_poses, args.ba,
+                                      len(s0.pool), args.ba_poses, args.ba_points, int(E_avg))
+                       if args.ba_mode == "rebuild" else "S%d extract+match, BA mode %s" % (args.width, args.ba_mode),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
-                       "frame_loop": "python threads" if args.python_loop else "native (host/driver/frame_loop.cpp)",
-                       "keypoints": s0.n_kp, "matches": s0.n_match,
-                       "ba_trials_per_solve": trials0 / nprof,
+                       "frame_loop": "native (host/driver/frame_loop.cpp)" + (", extraction of frame i+1 overlapped with BA of frame i" if pipeline else ""),
+                       "keypoints": st.n_kp, "matches": st.n_match,
+                       "ba_trials_per_solve": trials / max(solves, 1),
                        "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers) every "
                                          "frame; keyframe row (findEssentialMat filter on 1000 matches + triangulation + "
                                          "culling -> %d points) every %d frames"
-                                         % (len(s0.track["pts3d"]), s0.n_inliers, s0.n_tri, args.keyframe_every))
+                                         % (len(s0.track["pts3d"]), st.n_inliers, st.n_tri, args.keyframe_every))
                        if args.track else "off"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "cpu_baseline_all_threads": cpu_mt,
-            "kernel_ms_per_frame": {k: round(v, 5) for k, v in sorted(per_frame.items(), key=lambda kv: -kv[1])},
+            "secondary": secondary,
+            "kernels": kern,
+            "kernel_ms_per_frame": {k: round(v, 5) for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1])},
         }
         print(json.dumps(result))
     for s in shards:
-        s.ctx.ba_release(s.ba)
-        s.ctx.close()
+        s.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -447,8 +498,7 @@ def cpu_baseline(args, shard):
     one thread (the reference is single-threaded), on a bounded sample of the same workload."""
     O = graft.load_oracle()
     p = O.default_params(max_keypoints=args.max_kp)
-    pb = shard.pb
-    kw = shard.ba_kw
+    kw = dict(fix_points=args.ba == "pose_only")
     prev = None
     n = 0
     t0 = time.perf_counter()
@@ -460,12 +510,15 @@ def cpu_baseline(args, shard):
         if prev is not None:
             O.match_features(prev, d, 2, 2.0, 0.8)
         prev = d
-        O.bundle_adjustment(*shard.ba_args, **kw)
+        if args.ba_mode != "none":
+            pb = shard.pool[n % len(shard.pool)]
+            O.bundle_adjustment(pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"],
+                                pb["cx"], pb["cy"], **kw)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same S%d + BA%d workload, oracle -O3 x86-64-v3, 1 thread, %.1f s on a %d-core host"
-                      % (n, args.width, args.ba_poses, dt, os.cpu_count() or 0)}
+            "sample": "%d frames of the same S%d + BA%d workload (windows rotated), oracle -O3 x86-64-v3, 1 thread, %.1f s on a "
+                      "%d-core host" % (n, args.width, args.ba_poses, dt, os.cpu_count() or 0)}
 
 
 def cpu_baseline_threads(args, shard, nthreads):
@@ -473,6 +526,7 @@ def cpu_baseline_threads(args, shard, nthreads):
     (the GPU side also fills the chip with independent sequences); ctypes releases the GIL inside the oracle."""
     O = graft.load_oracle()
     p = O.default_params(max_keypoints=args.max_kp)
+    kw = dict(fix_points=args.ba == "pose_only")
     per_thread = max(4, min(16, args.cpu_frames // 8))
     done = []
 
@@ -485,7 +539,9 @@ def cpu_baseline_threads(args, shard, nthreads):
             if prev is not None:
                 O.match_features(prev, d, 2, 2.0, 0.8)
             prev = d
-            O.bundle_adjustment(*shard.ba_args, **shard.ba_kw)
+            pb = shard.pool[(n + tid) % len(shard.pool)]
+            O.bundle_adjustment(pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"],
+                                pb["cx"], pb["cy"], **kw)
         done.append(per_thread)
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]

@@ -430,6 +430,9 @@ class Context:
                     dlt=int(info[2]), lm_iters=int(info[3]), lm_evals=int(info[4]), n_hyp=int(info[5]))
 
     # ---- measurement / debug
+    def last_error(self):
+        return (self.lib.mvo_last_error(self.h) or b"").decode() if self.h else ""
+
     def synchronize(self):
         self._chk(self.lib.mvo_synchronize(self.h))
 

@@ -13,7 +13,9 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -117,6 +119,9 @@ struct BaService {
     std::deque<BaJob*> q;
     std::thread th;
     bool started = false;
+    // who submitted recently (workspace -> time of its last job): with several clients active a launch waits a moment for
+    // a full batch, a lone client is never held back
+    std::map<const BaWorkspace*, std::chrono::steady_clock::time_point> seen;
     // statistics (mvo_ba_launch_stats)
     long long launches = 0, windows = 0;
     double ms = 0;
@@ -137,12 +142,21 @@ void BaService::run() {
     (void)ba_kernel_set_lds_limit();
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
+    // (Queuing a second launch behind the running one was tried: it splits batches and lowered the frame rate.)
     for (;;) {
         BaJob* jobs[BA_MAX_BATCH];
         int nj = 0;
         {
             std::unique_lock<std::mutex> lk(m);
             cv_work.wait(lk, [&] { return !q.empty(); });
+            {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
+                const auto now = std::chrono::steady_clock::now();
+                for (auto it = seen.begin(); it != seen.end();)
+                    it = (now - it->second > std::chrono::milliseconds(10)) ? seen.erase(it) : std::next(it);
+                const size_t want = std::min<size_t>(BA_MAX_BATCH, seen.size());
+                if (q.size() < want)
+                    cv_work.wait_for(lk, std::chrono::microseconds(250), [&] { return q.size() >= want; });
+            }
             // one workgroup per CU (the LDS slice is > 80 KB): a launch may not hold more workgroups than the device has
             // CUs, or its hand-offs would wait for workgroups that cannot become resident
             int sum_wgs = 0;
@@ -207,7 +221,11 @@ BaService& service_for(int device) {
 void service_submit(BaService& s, BaJob* jobs, int n) {
     {
         std::lock_guard<std::mutex> lk(s.m);
-        for (int i = 0; i < n; ++i) s.q.push_back(&jobs[i]);
+        const auto now = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; ++i) {
+            s.q.push_back(&jobs[i]);
+            s.seen[jobs[i].ws] = now;
+        }
     }
     s.cv_work.notify_one();
 }

@@ -19,7 +19,14 @@ using std::vector;
 
 // One process-wide mvo_ctx per host thread: plays the role of the function-local statics (cv::ORB objects,
 // matchers, latched parameters) the reference keeps inside feature_match.cpp / vo.cpp.
+// A driver that manages its own contexts (one per sequence, or two per sequence when it overlaps extraction with
+// bundle adjustment) binds the one the adapters of the calling thread shall use; nullptr = the thread's default.
+inline mvo_ctx*& hot_path_ctx_binding() {
+    static thread_local mvo_ctx* bound = nullptr;
+    return bound;
+}
 inline mvo_ctx* hot_path_ctx() {
+    if (hot_path_ctx_binding()) return hot_path_ctx_binding();
     struct Holder {
         mvo_ctx* c = nullptr;
         Holder() {

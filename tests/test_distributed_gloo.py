@@ -34,6 +34,40 @@ WORKER = textwrap.dedent("""
     assert t == float(world)
     dist.barrier()
     dist.destroy_process_group()
+
+    # ---- the whole control flow of bench.run_benchmark (warm-up, barriers, timed region, MAX over ranks, the one
+    # collective with REAL per-frame rows) with stand-in shards: what a rank does at N > 1, executed, not just its helpers
+    import time, types
+    class StubCtx:
+        def ba_launch_stats(self, reset=False): return dict(launches=1, windows=1, ms=1.0)
+        def synchronize(self): pass
+    class StubShard:
+        def __init__(self, sid):
+            self.id, self.traj, self.ctx, self.frame = sid, [], StubCtx(), 0
+        def state(self):
+            return types.SimpleNamespace(ba_trials=10 * self.frame, ba_solves=self.frame, ba_edges=100 * self.frame, frame_no=self.frame)
+        def run(self, n):
+            for _ in range(n):
+                self.traj.append(np.full(12, 1000.0 * self.id + self.frame))
+                self.frame += 1
+            time.sleep(0.01 * (1 + rank))             # the slower rank defines the clock
+    class StubEnv:
+        device = "cpu"
+        def init_process_group(self, d): d.init_process_group("gloo")
+        def sync(self): pass
+        def make_shard(self, sid, args, ba_mode, pipeline, **kw): return StubShard(sid)
+    args = bench.parse(["--gpus", str(world), "--steps", "4", "--warmup", "2", "--streams", "3"])
+    R = bench.run_benchmark(args, StubEnv())
+    assert R["world"] == world and R["traj_all"].shape == (world, 3, 4, 12)
+    for r in range(world):
+        for s_ in range(3):
+            sid = r * 3 + s_
+            assert np.array_equal(R["traj_all"][r, s_, :, 0], 1000.0 * sid + np.arange(2, 6)), R["traj_all"][r, s_, :, 0]
+    assert R["elapsed"] >= 0.01 * world                                    # MAX over ranks
+    assert abs(R["value"] - world * 3 * 4 / R["elapsed"]) < 1e-9           # whole-job aggregate
+    import torch.distributed as dist2
+    dist2.barrier()
+    dist2.destroy_process_group()
     print("rank", rank, "ok")
 """) % ROOT
 
