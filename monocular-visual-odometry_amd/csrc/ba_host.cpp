@@ -269,10 +269,12 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     const int E = (int)act.size();
     const int n = 6 * nfree;
     const int NT = (n + 1 + 15) / 16, npair = NT * (NT + 1) / 2;
-    const int nlow = n * (n + 1) / 2 + n, npk = std::max(16, (nlow + 15) & ~15);
     const int ldu = 16 * NT, nhp = BA_HP * nfree + 1;
+    // packed entries of the reduced system; the exchange rows also hold the pose-block partials that ride along
+    const int nlow = n * (n + 1) / 2 + n, npk = std::max(16, (nlow + nhp + 15) & ~15);
     const bool do_schur = !p->fix_points && n > 0;
-    const int nsplit = do_schur ? std::max(1, BA_WAVES / npair) : 1;
+    int nsplit = do_schur ? std::max(1, BA_WAVES / npair) : 1;
+    if (const char* env = std::getenv("MVO_BA_NSPLIT")) nsplit = std::max(1, std::min(nsplit, std::atoi(env)));
     P.F = F;
     P.L = L;
     P.E = E;
@@ -313,7 +315,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
             maxEg = std::max(maxEg, wg_edge[g + 1] - wg_edge[g]);
             maxLg = std::max(maxLg, wg_pt[g + 1] - wg_pt[g]);
         }
-        P.lds = ba_lds_bytes(n, nlow, nhp, G, npair, nsplit, ldu, nfree, maxEg, maxLg, p->fix_points);
+        P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, nsplit, ldu, nfree, maxEg, maxLg, p->fix_points);
         if (P.lds <= BA_LDS_BUDGET && maxEg < 32000 && maxLg < 32000) break;
         if (G >= BA_MAX_WGS)
             return mvo_set_err(ctx, MVO_ERR_CAPACITY, "BA window too large for the LDS-resident solver", hipSuccess);

@@ -492,7 +492,8 @@ __device__ __forceinline__ void packed_ij(int idx, int n, int& i, int& j) {
 struct WgLds {
     double* SL;     // reduced system / transposed L
     double* colbuf; // 2 x 64 column broadcast + 64 scratch
-    double* Rl;     // nlow (+16) packed entries of the summed Schur system
+    double* Rl;     // nlow + nhp (+16) packed entries of the summed Schur system (+ pose blocks)
+    double* hpl;    // nhp own pose-block partials waiting for the next Schur exchange
     double* M;      // maxEg x 14
     double* uv;     // maxEg x 2
     double* pts;    // maxLg x 3
@@ -522,8 +523,8 @@ __device__ __forceinline__ double edge_error(const BaDev& B, const WgLds& W, int
     Xc[0] = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0];
     Xc[1] = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1];
     Xc[2] = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
-    const double e0 = W.uv[2 * el] - (Xc[0] / Xc[2] * B.f + B.cx);
-    const double e1 = W.uv[2 * el + 1] - (Xc[1] / Xc[2] * B.f + B.cy);
+    const double e0 = W.uv[el] - (Xc[0] / Xc[2] * B.f + B.cx);
+    const double e1 = W.uv[B.maxEg + el] - (Xc[1] / Xc[2] * B.f + B.cy);
     ew[0] = B.lc00 * e0 + B.lc01 * e1;
     ew[1] = B.lc11 * e1;
     return ew[0] * ew[0] + ew[1] * ew[1];
@@ -540,50 +541,79 @@ __device__ double robust_chi2_local(const BaDev& B, const WgLds& W, int Eg, cons
     return block_sum(s, scratch);
 }
 
-// U buffer addressing: column `col` (= 3 landmark + k), row `row`; with a 32- or 64-row pitch the two columns an MFMA
-// half-wave pair reads would hit the same banks -> odd columns are stored with their 16-row halves swapped
+// U buffer addressing: column `col` (= 3 landmark + k), row `row`.  The column pitch `ldu` is ODD (rows + 1): the
+// per-landmark phases run one lane per column (all lanes touch the same row of different columns); with an even pitch of
+// 32 doubles every such access would land on one LDS bank.
 __device__ __forceinline__ int u_index(int col, int row, int ldu) {
-    const int swz = (ldu & 31) == 0 ? ((col & 1) << 4) : 0;
-    return col * ldu + (row ^ swz);
+    return col * ldu + row;
 }
 
 // One chain of the partial Schur system: tile pair (ti, tj), MFMA steps [m0, m1) over the columns of U, four columns
 // per instruction: acc[i][j] = fma chain over the columns of U[col][16 ti + i] * U[col][16 tj + j].  The columns
-// behind the last landmark (up to the next multiple of four) are zero.  Four steps of operand loads are in flight.
-__device__ __forceinline__ v4d schur_chain(const double* U, int ldu, int ti, int tj, int m0, int m1, int lane) {
+// behind the last landmark (up to the next multiple of four) are zero.
+// The wave issues in order and stalls at every dependent MFMA, so everything else of a group of four steps -- the eight
+// operand loads of the NEXT group -- is placed right behind the first MFMA, where it is issued while the matrix core
+// works; two register sets alternate (no copies) and the column pitch is a compile-time constant (immediate offsets).
+template <int LDU>
+__device__ __forceinline__ v4d schur_chain_t(const double* U, int ti, int tj, int m0, int m1, int lane) {
     v4d acc = {0, 0, 0, 0};
     const int k = lane >> 4, i = lane & 15;
-    const int swz = (ldu & 31) == 0 ? ((k & 1) << 4) : 0;  // (column parity = k parity: 4 m is even)
-    const double* pa = U + (size_t)(4 * m0 + k) * ldu + ((16 * ti + i) ^ swz);
-    const double* pb = U + (size_t)(4 * m0 + k) * ldu + ((16 * tj + i) ^ swz);
-    const int st = 4 * ldu;
+    constexpr int st = 4 * LDU;
+    const double* pa = U + (size_t)(4 * m0 + k) * LDU + (16 * ti + i);
+    const double* pb = U + (size_t)(4 * m0 + k) * LDU + (16 * tj + i);
     int m = m0;
+#define BA_LOAD4(A, Bv) \
+    A##0 = pa[0], Bv##0 = pb[0], A##1 = pa[st], Bv##1 = pb[st], A##2 = pa[2 * st], Bv##2 = pb[2 * st], A##3 = pa[3 * st], Bv##3 = pb[3 * st]; \
+    pa += 4 * st;                                                                                                                           \
+    pb += 4 * st
+#define BA_MFMA4_LOADNEXT(A, Bv, C, D, more)                                     \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A##0, Bv##0, acc, 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    if (more) { BA_LOAD4(C, D); }                                                \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A##1, Bv##1, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A##2, Bv##2, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A##3, Bv##3, acc, 0, 0, 0)
     if (m + 4 <= m1) {
-        double a0 = pa[0], b0 = pb[0], a1 = pa[st], b1 = pb[st], a2 = pa[2 * st], b2 = pb[2 * st], a3 = pa[3 * st], b3 = pb[3 * st];
-        pa += 4 * st;
-        pb += 4 * st;
+        double a0, a1, a2, a3, b0, b1, b2, b3, c0 = 0, c1 = 0, c2 = 0, c3 = 0, d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+        BA_LOAD4(a, b);
         m += 4;
-        for (; m + 4 <= m1; m += 4) {  // the next four operand pairs are in flight while the matrix core works
-            const double c0 = pa[0], d0 = pb[0], c1 = pa[st], d1 = pb[st], c2 = pa[2 * st], d2 = pb[2 * st], c3 = pa[3 * st], d3 = pb[3 * st];
-            __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            a0 = c0, b0 = d0, a1 = c1, b1 = d1, a2 = c2, b2 = d2, a3 = c3, b3 = d3;
-            pa += 4 * st;
-            pb += 4 * st;
+        for (;;) {
+            const bool more1 = m + 4 <= m1;
+            BA_MFMA4_LOADNEXT(a, b, c, d, more1);
+            if (!more1) break;
+            m += 4;
+            const bool more2 = m + 4 <= m1;
+            BA_MFMA4_LOADNEXT(c, d, a, b, more2);
+            if (!more2) break;
+            m += 4;
         }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
     }
+#undef BA_LOAD4
+#undef BA_MFMA4_LOADNEXT
     for (; m < m1; ++m) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
-        pa += st;
-        pb += st;
+        pa += LDU;
+        pb += LDU;
+    }
+    return acc;
+}
+__device__ __forceinline__ v4d schur_chain(const double* U, int ldu, int ti, int tj, int m0, int m1, int lane) {
+    switch (ldu) {
+        case 17: return schur_chain_t<17>(U, ti, tj, m0, m1, lane);
+        case 33: return schur_chain_t<33>(U, ti, tj, m0, m1, lane);
+        case 49: return schur_chain_t<49>(U, ti, tj, m0, m1, lane);
+        case 65: return schur_chain_t<65>(U, ti, tj, m0, m1, lane);
+        default: break;
+    }
+    v4d acc = {0, 0, 0, 0};  // larger windows (> 10 free poses): plain loop
+    const int k = lane >> 4, i = lane & 15;
+    const double* pa = U + (size_t)(4 * m0 + k) * ldu + (16 * ti + i);
+    const double* pb = U + (size_t)(4 * m0 + k) * ldu + (16 * tj + i);
+    for (int m = m0; m < m1; ++m) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
+        pa += 4 * ldu;
+        pb += 4 * ldu;
     }
     return acc;
 }
@@ -610,19 +640,24 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     const BaDev& B = sB;
     if (g >= B.G) return;
     double* dyn = ba_dyn_lds;
-    __shared__ double sP[BA_MAX_POSES * 8], sPbak[BA_MAX_POSES * 8];  // q[4] t[3] pad
-    __shared__ double sR[BA_MAX_POSES * 9], sT[BA_MAX_POSES * 3];
-    __shared__ double sHpp[BA_MAX_POSES * 36], sBp[BA_MAX_POSES * 6], sDx[BA_MAX_POSES * 6];
     __shared__ double sScr[BA_WAVES];
-    __shared__ double sSol[6 * BA_MAX_POSES];
-    __shared__ double sX[BA_MAX_WGS * 2];
+    // per-pose state and the per-workgroup exchange values live at the front of the dynamic segment (sized by F and G)
+    double* const sP = dyn;                       // q[4] t[3] pad
+    double* const sPbak = sP + 8 * B.F;
+    double* const sR = sPbak + 8 * B.F;
+    double* const sT = sR + 9 * B.F;
+    double* const sHpp = sT + 3 * B.F;
+    double* const sBp = sHpp + 36 * B.F;
+    double* const sDx = sBp + 6 * B.F;
+    double* const sSol = sDx + 6 * B.F;           // 6 F (+ rhs slot)
+    double* const sX = dyn + ba_pose_doubles(B.F);  // 2 G
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ int sFlag[4];
     __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
     if (threadIdx.x == 0) sFlag[2] = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = B.n, G = B.G, nfree = B.nfree, ldu = B.ldu, nlow = B.nlow, npk = B.npk;
+    const int n = B.n, G = B.G, nfree = B.nfree, urows = B.ldu, ldu = B.ldu + 1, nlow = B.nlow, npk = B.npk;
     const int pt_lo = B.wg_pt_start[g], Lg = B.wg_pt_start[g + 1] - pt_lo;
     const int e_lo = B.wg_edge_start[g], Eg = B.wg_edge_start[g + 1] - e_lo;
     const unsigned tag0 = batch.tag_base[win];
@@ -632,13 +667,15 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     WgLds W;
     double* stage;
     {
-        double* d = dyn;
+        double* d = dyn + ba_pose_doubles(B.F) + 2 * (size_t)G + 8;
         W.SL = d;
-        d += ba_solver_doubles(n, nlow, G, B.npair, B.nsplit) - 3 * 64;
+        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.nsplit) - 3 * 64;
         W.colbuf = d;
         d += 3 * 64;
         W.Rl = d;
-        d += nlow + 16;
+        d += nlow + B.nhp + 16;
+        W.hpl = d;
+        d += B.nhp + 1;
         W.M = d;
         d += (size_t)B.maxEg * BA_MSTRIDE;
         W.uv = d;
@@ -650,15 +687,15 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         const size_t st = (size_t)B.nhp * (size_t)min(G, max(1, 4096 / B.nhp));
         const size_t full = B.fix_points ? 0 : 1;
         W.X = d;
-        d += full * B.maxEg * 6;
+        d += full * B.maxEg * BA_XS;
         W.bak = d;
         d += full * B.maxLg * 3;
         W.Hll = d;
-        d += full * B.maxLg * 6;
+        d += full * B.maxLg * BA_XS;
         W.bl = d;
         d += full * B.maxLg * 3;
         W.Cc = d;
-        d += full * B.maxLg * 6;
+        d += full * B.maxLg * BA_XS;
         W.cl = d;
         d += full * B.maxLg * 3;
         W.rr = d;
@@ -686,8 +723,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         W.ept[el] = (short)(B.e_point[e_lo + el] - pt_lo);
         W.dup[el] = B.dup_next[e_lo + el];
         W.ptl[el] = (short)(B.pt_edge_list[e_lo + el] - e_lo);
-        W.uv[2 * el] = B.e_uv[2 * (size_t)(e_lo + el)];
-        W.uv[2 * el + 1] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
+        W.uv[el] = B.e_uv[2 * (size_t)(e_lo + el)];  // (u and v in separate arrays)
+        W.uv[B.maxEg + el] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
     }
     for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = B.pts_in[3 * (size_t)pt_lo + i];
     for (int i = tid; i <= Lg; i += BA_THREADS) W.pts0[i] = (short)(B.pt_edge_start[pt_lo + i] - e_lo);
@@ -783,7 +820,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             if (!B.fix_points) {
                 const double* R = sR + 9 * p;
                 const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};
-                double* Xr = W.X + 6 * el;
+                double* Xr = W.X + BA_XS * el;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);
@@ -797,7 +834,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         PH_END(0);
         // ================= pose blocks: partial [H_pp | -b_p] = M^T M over the own edges of every free pose: wave w
         // runs the chains of the poses w, w + 8, ...: one MFMA per 4 rows (2 edges), rows in storage order
-        ++tagH;
+        // From the second iteration on the pose-block partials ride along with the first Schur exchange of the iteration
+        // (one all-to-all less per iteration); iteration 0 needs them earlier (lambda_0 = tau max |diag H|) and pose-only
+        // windows have no Schur exchange: those use the exchange of their own below.
+        const bool hp_deferred = do_schur && G > 1 && it > 0;
+        if (!hp_deferred) ++tagH;
         {
             const int col = lane & 15;
             for (int p = wave; p < B.F; p += BA_WAVES) {
@@ -807,30 +848,32 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 if (batch.use_mfma) {
                     const int rows = 2 * (e - s), nfull = rows / 4;
                     const bool cv = col < 7;
-                    const double* pm = W.M + 7 * (2 * s + (lane >> 4)) + (cv ? col : 0);  // row 2 s + 4 st + k, stride 7
+                    // row 2 s + 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
+                    const double* pm = W.M + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? col : 0);
                     v4d acc = {0, 0, 0, 0};
                     int st = 0;
                     for (; st + 4 <= nfull; st += 4) {
-                        const double v0 = pm[0], v1 = pm[28], v2 = pm[56], v3 = pm[84];
+                        const double v0 = pm[0], v1 = pm[2 * BA_MSTRIDE], v2 = pm[4 * BA_MSTRIDE], v3 = pm[6 * BA_MSTRIDE];
                         const double w0 = cv ? v0 : 0.0, w1 = cv ? v1 : 0.0, w2 = cv ? v2 : 0.0, w3 = cv ? v3 : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, w2, acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
-                        pm += 112;
+                        pm += 8 * BA_MSTRIDE;
                     }
                     for (; 4 * st < rows; ++st) {  // remaining steps, the last one possibly with fewer than 4 rows
                         const bool ok = cv && 4 * st + (lane >> 4) < rows;
                         const double v = ok ? pm[0] : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
-                        pm += 28;
+                        pm += 2 * BA_MSTRIDE;
                     }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int rg = (lane >> 4) + 4 * j;  // acc[j] = entry (rg, col)
                         if (rg < 7 && col <= rg) {
                             const int pk = rg * (rg + 1) / 2 + col;
-                            if (G > 1) gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
+                            if (hp_deferred) W.hpl[BA_HP * sl + pk] = acc[j];
+                            else if (G > 1) gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
                             else stage[BA_HP * sl + pk] = acc[j];
                         }
                     }
@@ -839,8 +882,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     while ((i + 1) * (i + 2) / 2 <= lane) ++i;
                     const int j = lane - i * (i + 1) / 2;
                     double acc = 0;
-                    for (int r = 2 * s; r < 2 * e; ++r) acc = __builtin_fma(W.M[7 * r + i], W.M[7 * r + j], acc);
-                    if (G > 1) gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + lane), tag0 + tagH, acc, same_l2);
+                    for (int r = 2 * s; r < 2 * e; ++r)
+                        acc = __builtin_fma(W.M[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + i], W.M[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + j], acc);
+                    if (hp_deferred) W.hpl[BA_HP * sl + lane] = acc;
+                    else if (G > 1) gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + lane), tag0 + tagH, acc, same_l2);
                     else stage[BA_HP * sl + lane] = acc;
                 }
             }
@@ -853,7 +898,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
                 for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
                     const int el = W.ptl[k];
-                    const double* X = W.X + 6 * el;
+                    const double* X = W.X + BA_XS * el;
                     const double e0 = W.M[BA_MSTRIDE * el + 6], e1 = W.M[BA_MSTRIDE * el + 13];
                     h[0] += X[0] * X[0] + X[3] * X[3];
                     h[1] += X[0] * X[1] + X[3] * X[4];
@@ -866,7 +911,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     b[2] -= X[2] * e0 + X[5] * e1;
                 }
 #pragma unroll
-                for (int i = 0; i < 6; ++i) W.Hll[6 * l + i] = h[i];
+                for (int i = 0; i < 6; ++i) W.Hll[BA_XS * l + i] = h[i];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) W.bl[3 * l + i] = b[i];
                 maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
@@ -874,7 +919,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         }
         // ---- exchange: pose-block partials + the landmark max diagonal, summed in workgroup order; the partials are
         // staged `hrows` workgroups at a time (the staging area is bounded for windows with many workgroups)
-        {
+        if (hp_deferred) {
+            __syncthreads();  // (hpl complete)
+        } else {
             const double m = block_max(maxdiag, sScr);  // (two barriers: the chains' stage[] stores are visible below)
             const int nhp = B.nhp, hrows = min(G, max(1, 4096 / nhp));
             double hsum = 0, mm = 0;
@@ -920,19 +967,20 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
 
         double rho = 0;
         int qmax = 0;
+        bool hp_pending = hp_deferred;
         do {
             STAMP(0);
             // ============= T1: (H_ll + lambda I)^-1 = C C^T, C^T b_l; U_l = [W_l C_l ; (C_l^T b_l)^T ; 0]
             if (!B.fix_points) {
                 for (int l = tid; l < Lg; l += BA_THREADS) {
-                    const double* h = W.Hll + 6 * l;
+                    const double* h = W.Hll + BA_XS * l;
                     const double D[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
                     double Di[9];
                     inv3(D, Di);
                     const double c00 = sqrt(Di[0]), c10 = Di[3] / c00, c20 = Di[6] / c00;
                     const double c11 = sqrt(Di[4] - c10 * c10), c21 = (Di[7] - c20 * c10) / c11;
                     const double c22 = sqrt(Di[8] - c20 * c20 - c21 * c21);
-                    double* cc = W.Cc + 6 * l;
+                    double* cc = W.Cc + BA_XS * l;
                     cc[0] = c00;
                     cc[1] = c10;
                     cc[2] = c11;
@@ -948,7 +996,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                         W.U[u_index(3 * l, n, ldu)] = c0;
                         W.U[u_index(3 * l + 1, n, ldu)] = c1;
                         W.U[u_index(3 * l + 2, n, ldu)] = c2;
-                        for (int row = n + 1; row < ldu; ++row)
+                        for (int row = n + 1; row < urows; ++row)
                             for (int k = 0; k < 3; ++k) W.U[u_index(3 * l + k, row, ldu)] = 0.0;
                     }
                 }
@@ -957,19 +1005,55 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     for (int q = ncol * ldu + tid; q < 4 * msteps * ldu; q += BA_THREADS) W.U[q] = 0.0;  // pad columns
                 __syncthreads();
                 STAMP(2);
-                if (do_schur) {
-                    // U rows of the pose blocks: one item per (landmark, pose slot, k): Y_k = (X~ C)[., k] of every edge of the
-                    // pair (normally one), u = A~^T Y_k (six values, contiguous in column 3 l + k)
+                if (do_schur && !B.has_dups) {
+                    // U rows of the pose blocks, the normal case (no two observations of one landmark from one pose): one
+                    // thread per edge computes Y = X~ C (2 x 3) and the block A~^T Y (6 x 3) of its (landmark, pose slot);
+                    // the pairs without an observation are cleared by a second sweep
+                    for (int el = tid; el < Eg; el += BA_THREADS) {
+                        const int sl = sSlot[W.epose[el]];
+                        if (sl < 0) continue;
+                        const int l = W.ept[el];
+                        const double* cc = W.Cc + BA_XS * l;
+                        const double* X = W.X + BA_XS * el;
+                        const double* A = W.M + BA_MSTRIDE * el;
+                        const double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4], c5 = cc[5];
+                        const double x0 = X[0], x1 = X[1], x2 = X[2], x3 = X[3], x4 = X[4], x5 = X[5];
+                        const double Y[6] = {x0 * c0 + x1 * c1 + x2 * c3, x1 * c2 + x2 * c4, x2 * c5,
+                                             x3 * c0 + x4 * c1 + x5 * c3, x4 * c2 + x5 * c4, x5 * c5};
+                        double a0[6], a1[6];
+#pragma unroll
+                        for (int c = 0; c < 6; ++c) {
+                            a0[c] = A[c];
+                            a1[c] = A[7 + c];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c)
+                                W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = 0.0 + (a0[c] * Y[k] + a1[c] * Y[3 + k]);
+                    }
+                    for (int q = tid; q < Lg * nfree; q += BA_THREADS) {
+                        if (W.eof[q] >= 0) continue;
+                        const int l = q / nfree, sl = q - l * nfree;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = 0.0;
+                    }
+                    __syncthreads();
+                } else if (do_schur) {
+                    // windows with duplicate observations: one item per (landmark, pose slot, k) walks the chain of edges of
+                    // the pair: Y_k = (X~ C)[., k] of every edge, u = sum A~^T Y_k (six values of column 3 l + k)
                     const int n3 = 3 * nfree;
                     for (int q = tid; q < Lg * n3; q += BA_THREADS) {
                         const int l = q / n3, rem = q - l * n3, sl = rem / 3, k = rem - 3 * sl;
-                        const double* cc = W.Cc + 6 * l;
+                        const double* cc = W.Cc + BA_XS * l;
                         // column k of the lower-triangular C: C[c][k] for c = k .. 2
                         const double ck0 = k == 0 ? cc[0] : 0.0, ck1 = k == 0 ? cc[1] : (k == 1 ? cc[2] : 0.0),
                                      ck2 = k == 0 ? cc[3] : (k == 1 ? cc[4] : cc[5]);
                         double acc[6] = {0, 0, 0, 0, 0, 0};
                         for (int el = W.eof[l * nfree + sl]; el >= 0; el = W.dup[el]) {
-                            const double* X = W.X + 6 * el;
+                            const double* X = W.X + BA_XS * el;
                             const double* A = W.M + BA_MSTRIDE * el;
                             double y0, y1;
                             if (k == 0) {
@@ -1059,7 +1143,10 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     STAMP(6);
                     // stage 1: this workgroup reduces its SLICE of the packed entries over all G partials, in workgroup
                     // order, and republishes the slice
-                    const int sl0 = g * slice, sln = max(0, min(slice, nlow - sl0));
+                    const int nhpx = hp_pending ? B.nhp - 1 : 0, nlowx = nlow + nhpx;
+                    const int slicex = hp_pending ? (nlowx + G - 1) / G : slice;
+                    for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(B.xP + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], same_l2);
+                    const int sl0 = g * slicex, sln = max(0, min(slicex, nlowx - sl0));
                     if (sln > 0) {
                         // item q = (w, el): partial of workgroup w, entry sl0 + el
                         if (!gather_tagged(B.xP + 2 * (size_t)sl0, sln * G, sln, npk, tag0 + tagA, W.SL, PROF ? &ph[PROF ? 12 : 0] : nullptr)) sFlag[2] = 1;
@@ -1075,8 +1162,25 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     }
                     STAMP(9);
                     // stage 2: everybody reads the summed entries
-                    if (!gather_tagged(B.xR, nlow, nlow, 0, tag0 + tagA, W.Rl, PROF ? &ph[PROF ? 13 : 0] : nullptr)) sFlag[2] = 1;
+                    if (!gather_tagged(B.xR, nlowx, nlowx, 0, tag0 + tagA, W.Rl, PROF ? &ph[PROF ? 13 : 0] : nullptr)) sFlag[2] = 1;
                     STAMP(10);
+                    if (hp_pending) {  // the summed pose blocks of this iteration: [H_pp | -b_p] of every free pose
+                        __syncthreads();
+                        if (tid < BA_HP * nfree) {
+                            const double hsum = W.Rl[nlow + tid];
+                            const int sl = tid / BA_HP, pk = tid - BA_HP * sl, p = sSlotPose[sl];
+                            int i = 0;
+                            while ((i + 1) * (i + 2) / 2 <= pk) ++i;
+                            const int j = pk - i * (i + 1) / 2;
+                            if (i < 6) {
+                                sHpp[36 * p + 6 * i + j] = hsum;
+                                sHpp[36 * p + 6 * j + i] = hsum;
+                            } else if (j < 6) {
+                                sBp[6 * p + j] = -hsum;
+                            }
+                        }
+                        hp_pending = false;
+                    }
                 }
                 __syncthreads();
                 if (sFlag[2]) error = 1;
@@ -1171,13 +1275,12 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 for (int q = tid; q < 3 * Lg; q += BA_THREADS) {
                     double r = W.cl[q];
                     if (do_schur) {
-                        const int swz = (ldu & 31) == 0 ? ((q & 1) << 4) : 0;
                         const double* up = W.U + (size_t)q * ldu;
                         for (int row = 0; row < n; row += 6) {  // (n = 6 x free poses)
                             double u6[6], x6[6];
 #pragma unroll
                             for (int c = 0; c < 6; ++c) {
-                                u6[c] = up[(row + c) ^ swz];
+                                u6[c] = up[row + c];
                                 x6[c] = sSol[row + c];
                             }
 #pragma unroll
@@ -1191,7 +1294,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 STAMP(15);
                 for (int l = tid; l < Lg; l += BA_THREADS) {
                     const double* r = W.rr + 3 * l;
-                    const double* cc = W.Cc + 6 * l;
+                    const double* cc = W.Cc + BA_XS * l;
                     double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
                     if (!ok2) d[0] = d[1] = d[2] = 0;
 #pragma unroll

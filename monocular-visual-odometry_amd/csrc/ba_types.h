@@ -21,8 +21,10 @@ typedef unsigned long long ba_u64;
 #define BA_THREADS 512
 #define BA_WAVES 8
 #define BA_MAX_POSES 20
-#define BA_MSTRIDE 14               // doubles per edge in M: two rows [A~ (6) | e~]
-#define BA_LDS_BUDGET (142 * 1024)  // dynamic part; the static part (~17.5 KB) comes on top (160 KB per CU)
+#define BA_MSTRIDE 15               // doubles per edge in M: two rows [A~ (6) | e~] at +0 and +7, one pad (odd pitch)
+#define BA_XS 7                     // doubles per edge in X~ (6 used) and per landmark in H_ll / C (6 used): odd pitches,
+//                                  so that one-lane-per-edge / per-landmark accesses spread over the LDS banks
+#define BA_LDS_BUDGET (157 * 1024)  // dynamic part; the static part (descriptor, flags: < 1.5 KB) comes on top (160 KB per CU)
 #define BA_MAX_WGS 256
 #define BA_MAX_BATCH 8              // windows per launch (8 x 32 workgroups = one workgroup per CU)
 #define BA_NPHASE 16
@@ -104,17 +106,20 @@ __host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int 
     if (sl > a) a = sl;
     return a + 3 * 64;  // + two column-broadcast buffers + scratch
 }
-__host__ __device__ inline size_t ba_lds_bytes(int n, int nlow, int nhp, int G, int npair, int nsplit, int ldu, int nfree,
+// per-pose state: q t (8) + backup (8), R (9), t (3), H_pp (36), b_p (6), dx (6), solution (6)
+__host__ __device__ inline size_t ba_pose_doubles(int F) { return (size_t)(F > 0 ? F : 1) * 82; }
+__host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int nsplit, int ldu, int nfree,
                                                int maxEg, int maxLg, int fix_points) {
-    size_t d = ba_solver_doubles(n, nlow, G, npair, nsplit) + (size_t)nlow + 16 + (size_t)maxEg * (BA_MSTRIDE + 2) +
-               (size_t)maxLg * 3;
+    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, nsplit) + (size_t)nlow + 2 * (size_t)nhp + 17 +
+               (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
+    d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
     size_t hrows = 4096 / (size_t)(nhp > 0 ? nhp : 1);  // pose-block exchange staging: <= 4096 values at a time
     if (hrows < 1) hrows = 1;
     if (hrows > (size_t)G) hrows = (size_t)G;
     const size_t stage = (size_t)nhp * hrows;
     if (!fix_points) {
-        d += (size_t)maxEg * 6 + (size_t)maxLg * (3 + 6 + 3 + 6 + 3 + 3);
-        const size_t u = ((size_t)3 * maxLg + 3) * ldu;  // the pose-block staging lives inside the U buffer (rebuilt per trial)
+        d += (size_t)maxEg * BA_XS + (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3 + 3);
+        const size_t u = ((size_t)3 * maxLg + 3) * (ldu + 1);  // (odd column pitch)  // the pose-block staging lives inside the U buffer (rebuilt per trial)
         d += u > stage ? u : stage;
     } else {
         d += stage;
