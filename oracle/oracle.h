@@ -128,6 +128,11 @@ typedef struct {
 
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317). */
 int orc_bundle_adjustment(orc_ba_problem* prob, orc_ba_stats* stats);
+/* The same algorithm with the BLOCKED summation order the device declares (ba_blocked_oracle.cpp): G landmark ranges
+ * (wg_pt_start: G + 1 entries), nsplit column pieces per Schur chain.  trace (may be NULL): rows {lambda, chi2, rho,
+ * accepted} per LM trial.  Used to check the MI355X solve bit for bit. */
+int orc_bundle_adjustment_blocked(orc_ba_problem* prob, int G, const int32_t* wg_pt_start, int nsplit, orc_ba_stats* stats,
+                                  double* trace, int trace_cap, int* trace_n);
 /* One linearisation at the current state: dense H (n x n, n = 6*free poses + 3*free points),
  * b, robust chi2.  For known-answer tests of the Jacobians. */
 int orc_ba_linearize(const orc_ba_problem* prob, double* H, double* b, double* chi2, int ncap);

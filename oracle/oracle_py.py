@@ -228,6 +228,24 @@ def bundle_adjustment(poses, points, edge_pose, edge_point, edge_uv, focal, cx, 
     return keep["poses"].reshape(-1, 4, 4), keep["points"], stats
 
 
+def bundle_adjustment_blocked(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, plan, info=(1, 0, 0, 1),
+                              huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50):
+    """The same LM solve with the blocked summation order of `plan` = dict(wgs, nsplit, wg_pt_start) (what
+    mvo_debug_get_ba_plan reports).  Returns (poses, points, stats, trace [trials, 4] = lambda, chi2, rho, accepted)."""
+    pr, keep = _ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
+                           fix_points, pose_fixed, max_iterations)
+    st = BaStats()
+    wg = np.ascontiguousarray(plan["wg_pt_start"], np.int32)
+    trace = np.zeros((512, 4))
+    nt = C.c_int()
+    r = lib().orc_bundle_adjustment_blocked(C.byref(pr), int(plan["wgs"]), wg.ctypes.data_as(C.c_void_p), int(plan["nsplit"]),
+                                            C.byref(st), trace.ctypes.data_as(C.c_void_p), 512, C.byref(nt))
+    if r != 0:
+        raise RuntimeError("oracle BA (blocked order) failed: %d" % r)
+    stats = {k: getattr(st, k) for k, _ in BaStats._fields_}
+    return keep["poses"].reshape(-1, 4, 4), keep["points"], stats, trace[:min(nt.value, 512)].copy()
+
+
 def ba_linearize(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info=(1, 0, 0, 1),
                  huber_delta=1.0, fix_points=False, pose_fixed=None):
     pr, keep = _ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,

@@ -216,3 +216,75 @@ def test_config4_ba10_window(mvo, O, ctx):
     Po, Xo, sto = O.bundle_adjustment(*_args(pb), fix_points=False, pose_fixed=_fix(10, 2))
     assert _rel(P[:, :3, 3], Po[:, :3, 3]) < TOL and np.abs(P[:, :3, :3] - Po[:, :3, :3]).max() < TOL, (st, sto)
     assert ctx.debug_ba_phases()["wgs"] >= 64
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Bit-exact parity: the device declares the association of every sum of the solve; the oracle restates the
+# same LM algorithm with that blocked order (oracle/ba_blocked_oracle.cpp).  Then ALL 50 iterations must agree exactly:
+# every trial's damping, robust chi2, gain ratio and accept/reject decision, and the final poses and landmarks bit for bit.
+def _bitwise(mvo, O, ctx, pb, **kw):
+    ctx.ba_trace_enable(True)
+    try:
+        P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+        tr = ctx.ba_trace()
+        plan = ctx.ba_plan()
+    finally:
+        ctx.ba_trace_enable(False)
+    Po, Xo, sto, tro = O.bundle_adjustment_blocked(*_args(pb), plan=plan, **kw)
+    msg = "plan %s\ngpu %s\noracle %s" % ({k: (v if k != "wg_pt_start" else len(v)) for k, v in plan.items()}, st, sto)
+    n = min(len(tr), len(tro))
+    def bits(a):   # bit patterns, any NaN encoding counts as the same NaN (host and device quiet NaNs differ in sign)
+        a = np.ascontiguousarray(a[:n]).copy()
+        a[np.isnan(a)] = 1.2345678e304
+        return a.view(np.uint64)
+    bad = np.nonzero(((bits(tr) != bits(tro)) | (np.isnan(tr[:n]) != np.isnan(tro[:n]))).any(1))[0]
+    assert len(bad) == 0, msg + "\nfirst differing trial %d:\n gpu    %r\n oracle %r" % (bad[0], tr[bad[0]], tro[bad[0]])
+    assert st["trials"] == sto["trials"] and st["iterations"] == sto["iterations"] and st["terminated"] == sto["terminated"], msg
+    assert st["chi2_initial"] == sto["chi2_initial"] and st["chi2_final"] == sto["chi2_final"], msg
+    assert st["lambda_final"] == sto["lambda_final"], msg
+    assert np.array_equal(P, Po), msg + "\nmax pose difference %g" % np.abs(P - Po).max()
+    assert np.array_equal(X, Xo), msg + "\nmax landmark difference %g" % np.abs(X - Xo).max()
+    return st, plan
+
+
+def test_bitwise_the_benchmarked_window_all_50_iterations(mvo, O, ctx):
+    """The exact window bench.py solves (BA5: 5 poses / 2000 landmarks / ~9.4k edges, seed 7, NO fixed vertex, 50
+    iterations): north-star '1e-4 on poses and landmarks' is met with zero difference."""
+    st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
+    assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 32
+
+
+def test_bitwise_config4_ba10_window(mvo, O, ctx):
+    """BASELINE configs[3]: 10 keyframes / 4000 landmarks / ~36k edges (KITTI shape), no fixed vertex."""
+    pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)
+    st, plan = _bitwise(mvo, O, ctx, pb, fix_points=False)
+    assert st["iterations"] == 50 and plan["wgs"] >= 64
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("case", ["pose_only", "anchored", "fixed0_info", "tiny_one_range", "dups", "seven_poses"])
+def test_bitwise_variants(mvo, O, ctx, case, mfma):
+    mvo.debug_set("ba_mfma", mfma)
+    try:
+        if case == "pose_only":
+            _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
+        elif case == "anchored":
+            pb = mvo.synth.ba_problem(5, 2000, 7)
+            pb["poses0"][:2] = pb["poses_gt"][:2]
+            _bitwise(mvo, O, ctx, pb, fix_points=False, pose_fixed=_fix(5, 2))
+        elif case == "fixed0_info":
+            _bitwise(mvo, O, ctx, mvo.synth.ba_problem(4, 700, 21), fix_points=False, pose_fixed=_fix(4, 1),
+                     info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5)
+        elif case == "tiny_one_range":
+            st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(3, 40, 5), fix_points=False)
+            assert plan["wgs"] == 1
+        elif case == "dups":
+            pb = mvo.synth.ba_problem(3, 300, 6)
+            pb = dict(pb, edge_pose=np.concatenate([pb["edge_pose"], pb["edge_pose"][:90]]),
+                      edge_point=np.concatenate([pb["edge_point"], pb["edge_point"][:90]]),
+                      edge_uv=np.concatenate([pb["edge_uv"], pb["edge_uv"][:90] + 0.3]))
+            _bitwise(mvo, O, ctx, pb, fix_points=False, pose_fixed=_fix(3, 1))
+        else:
+            _bitwise(mvo, O, ctx, mvo.synth.ba_problem(7, 1500, 31), fix_points=False)
+    finally:
+        mvo.debug_set("ba_mfma", 1)
