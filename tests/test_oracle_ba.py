@@ -161,15 +161,6 @@ def test_ba5_free_points_converges(O, S):
     assert stf["chi2_final"] < 0.2 * stf["chi2_initial"]
 
 
-def _args(pb, poses=None):
-    return (pb["poses0"] if poses is None else poses, pb["points0"], pb["edge_pose"], pb["edge_point"],
-            pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
-
-
-def _rel(a, b):
-    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
-
-
 def _fix(F, k):
     f = np.zeros(F, np.uint8)
     f[:k] = 1
