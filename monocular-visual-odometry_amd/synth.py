@@ -266,3 +266,47 @@ def feature_sequence(n_frames=30, n_points=5000, seed=61, width=640, height=480,
                            desc=np.ascontiguousarray(np.concatenate([d, cd])[order]),
                            point_id=np.concatenate([vis, -np.ones(clutter, int)])[order]))
     return dict(K=K, cols=width, rows=height, frames=frames, points=pts)
+
+
+# ---------------------------------------------------------------- image-level 3-D sequence (headless run_vo)
+class Scene3D:
+    """A textured, gently undulating surface in front of a moving camera: real perspective images with parallax and their
+    ground-truth poses (T_w_c, camera -> world), for the end-to-end run of host/driver/run_vo.
+
+    Surface z = z0 + amp * sin(kx X + 0.7) * cos(ky Y) + tilt * X (metres, camera axes: X right, Y down, Z forward);
+    texture = world_texture() with one texel per pixel at depth z0.  Every pixel's ray is intersected with the surface by
+    fixed-point iteration (the surface is smooth and far: 8 rounds reach < 1e-6 m)."""
+
+    def __init__(self, width=640, height=480, K=FR1_K, seed=77, z0=2.0, amp=0.22, tilt=0.12, step=0.02, tex_size=2048):
+        self.w, self.h, self.K, self.seed = width, height, K, seed
+        self.z0, self.amp, self.tilt, self.step = z0, amp, tilt, step
+        self.tex = world_texture(seed, tex_size)
+        self.tex_size = tex_size
+        self.m = z0 / K["fx"]                     # metres per texel
+
+    def surface(self, X, Y):
+        return self.z0 + self.amp * np.sin(2.1 * X + 0.7) * np.cos(1.7 * Y) + self.tilt * X
+
+    def pose(self, i):
+        T = np.eye(4)
+        T[:3, :3] = _rot([0.1, 1.0, 0.05], np.deg2rad(0.12 * i)) @ _rot([0, 0, 1], np.deg2rad(0.1 * i))
+        T[:3, 3] = [self.step * i, 0.004 * np.sin(0.4 * i), 0.003 * i]
+        return T
+
+    def frame(self, i, noise=1.5):
+        from scipy import ndimage
+        K, T = self.K, self.pose(i)
+        ys, xs = np.mgrid[0:self.h, 0:self.w].astype(np.float64)
+        d = np.stack([(xs - K["cx"]) / K["fx"], (ys - K["cy"]) / K["fy"], np.ones_like(xs)], -1) @ T[:3, :3].T
+        C = T[:3, 3]
+        t = (self.z0 - C[2]) / d[..., 2]
+        for _ in range(8):
+            X, Y = C[0] + t * d[..., 0], C[1] + t * d[..., 1]
+            t = (self.surface(X, Y) - C[2]) / d[..., 2]
+        X, Y = C[0] + t * d[..., 0], C[1] + t * d[..., 1]
+        u, v = self.tex_size / 2 + X / self.m, self.tex_size / 2 + Y / self.m
+        img = ndimage.map_coordinates(self.tex, [v, u], order=1, mode="reflect")
+        rng = np.random.RandomState((self.seed * 7919 + i) % (2 ** 32))
+        img = img + rng.normal(0, noise, img.shape)
+        g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        return np.repeat(g[:, :, None], 3, axis=2)

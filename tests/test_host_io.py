@@ -77,3 +77,32 @@ def test_reference_config_parses_if_present(tmp_path):
     assert out["dataset_name"] == "matlab" and out["num_images"] == "150"
     assert [float(v) for v in out["K"].split()] == [615, 615, 320, 240]
     assert out["max_number_of_keypoints"] == "1500" and out["findEssentialMat_prob"] == "0.999"
+
+
+def test_image_reader_decodes_png_and_pnm_like_pil(tmp_path):
+    """basics::imread (host/include/my_slam/basics/image_io.h) = cv::imread stand-in of the headless run_vo: BGR, 8 bit,
+    3 channels, for gray / RGB / RGBA PNGs (all scanline filters occur in these images) and binary PGM / PPM."""
+    import subprocess
+    from PIL import Image
+    exe = os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "driver", "read_image")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    rng = np.random.RandomState(3)
+    yy, xx = np.mgrid[0:61, 0:83]
+    smooth = ((np.sin(xx / 7.0) + np.cos(yy / 5.0)) * 60 + 120).astype(np.uint8)
+    rgb = np.stack([smooth, np.roll(smooth, 5, 1), rng.randint(0, 256, smooth.shape).astype(np.uint8)], -1)
+    cases = {"gray.png": Image.fromarray(smooth), "rgb.png": Image.fromarray(rgb),
+             "rgba.png": Image.fromarray(np.dstack([rgb, np.full(smooth.shape, 200, np.uint8)]), "RGBA"),
+             "gray.pgm": Image.fromarray(smooth), "rgb.ppm": Image.fromarray(rgb)}
+    for name, im in cases.items():
+        path, out = tmp_path / name, tmp_path / (name + ".raw")
+        im.save(path)
+        r = subprocess.run([exe, str(path), str(out)], capture_output=True, text=True)
+        assert r.returncode == 0, (name, r.stderr)
+        raw = np.fromfile(out, np.uint8)
+        w, h = np.frombuffer(raw[:8].tobytes(), "<i4")
+        got = raw[8:].reshape(h, w, 3)
+        want = np.asarray(im.convert("RGB"))[:, :, ::-1]            # BGR like cv::imread
+        assert (w, h) == im.size and np.array_equal(got, want), name
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(b"not an image")
+    assert subprocess.run([exe, str(bad), str(tmp_path / "x.raw")]).returncode == 1      # empty Mat, like cv::imread
