@@ -47,6 +47,10 @@ typedef struct {
     int32_t max_keypoints;     /* max_number_of_keypoints */
     int32_t grid_size;         /* kpts_uniform_selection_grid_size */
     int32_t grid_max_per_cell; /* kpts_uniform_selection_max_pts_per_grid */
+    /* How cv::ORB resamples its pyramid -- a property of the OpenCV version, not of config.yaml: 1 = INTER_LINEAR_EXACT
+     * (OpenCV >= 3.4, what the reference's README asks for: bit-exact 8.8 fixed point), 0 = INTER_LINEAR (older
+     * OpenCV: 11-bit coefficients from float coordinates, truncating vertical pass). */
+    int32_t pyramid_interpolation;
 } mvo_orb_params;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -32,7 +32,7 @@ CANDIDATE_DTYPE = np.dtype([("x", "<i2"), ("y", "<i2"), ("level_score", "<i4"), 
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("fast_threshold", C.c_int32), ("max_keypoints", C.c_int32), ("grid_size", C.c_int32),
-                ("grid_max_per_cell", C.c_int32)]
+                ("grid_max_per_cell", C.c_int32), ("pyramid_interpolation", C.c_int32)]
 
 
 class BaProblem(C.Structure):
@@ -109,7 +109,8 @@ class Context:
         self.h = h
         self.device = int(device)
         self.params = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500,
-                           grid_size=16, grid_max_per_cell=8)  # config/config.yaml:65-69,94-95
+                           grid_size=16, grid_max_per_cell=8,  # config/config.yaml:65-69,94-95
+                           pyramid_interpolation=1)             # cv::ORB of OpenCV >= 3.4: INTER_LINEAR_EXACT
         if orb_params:
             self.orb_configure(**orb_params)
 

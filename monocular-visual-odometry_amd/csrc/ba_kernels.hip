@@ -593,8 +593,8 @@ __device__ __forceinline__ v4d schur_chain_t(const double* U, int ti, int tj, in
 #undef BA_MFMA4_LOADNEXT
     for (; m < m1; ++m) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
-        pa += LDU;
-        pb += LDU;
+        pa += st;
+        pb += st;
     }
     return acc;
 }

@@ -75,7 +75,7 @@ int mvo_create(mvo_ctx** out, int device) {
         return MVO_ERR_NO_DEVICE;
     }
     // config/config.yaml:65-69,94-95
-    ctx->orb = mvo_orb_params{8000, 1.2f, 4, 20, 1500, 16, 8};
+    ctx->orb = mvo_orb_params{8000, 1.2f, 4, 20, 1500, 16, 8, 1};  // config.yaml:65-69,94-95; pyramid: INTER_LINEAR_EXACT
     ctx->orb_configured = true;
     *out = ctx;
     return MVO_OK;

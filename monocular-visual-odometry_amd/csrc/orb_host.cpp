@@ -35,8 +35,31 @@ void feature_quota(const mvo_orb_params& p, std::vector<int>& q) {
     q[p.nlevels - 1] = std::max(p.nfeatures - sum, 0);
 }
 
-// cv::resize(INTER_LINEAR, 8-bit): source offset + two 11-bit coefficients per destination sample
-void fill_resize_tab(ResizeEntry* tab, int ssize, int dsize) {
+// cv::resize as cv::ORB calls it, 8-bit: source offset + two coefficients per destination sample.
+// exact (cv::INTER_LINEAR_EXACT, OpenCV >= 3.4): coordinate in double, 8-bit coefficients summing to 256;
+// otherwise (cv::INTER_LINEAR): coordinate in float, 11-bit coefficients.
+void fill_resize_tab(ResizeEntry* tab, int ssize, int dsize, bool exact) {
+    if (exact) {
+        const double scale = (double)ssize / (double)dsize;
+        for (int d = 0; d < dsize; ++d) {
+            double f = scale * ((double)d + 0.5) - 0.5;
+            int s = (int)std::floor(f);
+            f -= s;
+            if (s < 0) {
+                f = 0;
+                s = 0;
+            }
+            if (s >= ssize - 1) {
+                f = 0;
+                s = ssize - 1;
+            }
+            const int c1 = cv_round(f * 256.0);
+            tab[d].ofs = s;
+            tab[d].c0 = (int16_t)(256 - c1);
+            tab[d].c1 = (int16_t)c1;
+        }
+        return;
+    }
     const double scale = 1. / ((double)dsize / ssize);
     for (int d = 0; d < dsize; ++d) {
         float f = (float)((d + 0.5) * scale - 0.5);
@@ -145,8 +168,8 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     MVO_HIP(hipMalloc((void**)&ctx->d_cell_off, (size_t)cells * 4 + 64));
     std::vector<ResizeEntry> tabs(tab);
     for (int l = 1; l < p.nlevels; ++l) {
-        fill_resize_tab(&tabs[P.lv[l].tab_off], P.lv[l - 1].w, P.lv[l].w);
-        fill_resize_tab(&tabs[P.lv[l].tab_off + P.lv[l].w], P.lv[l - 1].h, P.lv[l].h);
+        fill_resize_tab(&tabs[P.lv[l].tab_off], P.lv[l - 1].w, P.lv[l].w, ctx->orb.pyramid_interpolation != 0);
+        fill_resize_tab(&tabs[P.lv[l].tab_off + P.lv[l].w], P.lv[l - 1].h, P.lv[l].h, ctx->orb.pyramid_interpolation != 0);
     }
     MVO_HIP(hipMemcpy(ctx->d_tabs, tabs.data(), tab * sizeof(ResizeEntry), hipMemcpyHostToDevice));
     if (!ctx->d_hdr) {

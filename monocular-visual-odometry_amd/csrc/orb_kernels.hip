@@ -60,9 +60,10 @@ __global__ __launch_bounds__(256) void k_gray_border(const uint8_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ resize
-// cv::resize(INTER_LINEAR) 8-bit fixed point; coefficient tables are built on the host once per geometry.
+// cv::resize 8-bit fixed point; coefficient tables are built on the host once per geometry.  exact: INTER_LINEAR_EXACT
+// (8-bit coefficients, one rounding), else INTER_LINEAR (11-bit coefficients, OpenCV's truncating vertical pass).
 __global__ __launch_bounds__(256) void k_resize_border(uint8_t* __restrict__ raw, LevelInfo S, LevelInfo D,
-                                                       const ResizeEntry* __restrict__ tabs) {
+                                                       const ResizeEntry* __restrict__ tabs, int exact) {
     const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
     const int by = blockIdx.y * 4 + threadIdx.y;
     if (x4 >= D.stride || by >= D.h + 2 * MVO_BORDER) return;
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(256) void k_resize_border(uint8_t* __restrict__ raw
             int sx1 = min(tx.ofs + 1, S.w - 1);
             int h0 = r0[tx.ofs] * tx.c0 + r0[sx1] * tx.c1;
             int h1 = r1[tx.ofs] * tx.c0 + r1[sx1] * tx.c1;
-            g = (uint32_t)((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+            g = exact ? (uint32_t)((ty.c0 * h0 + ty.c1 * h1 + 32768) >> 16) & 0xff
+                      : (uint32_t)((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
         }
         out |= g << (8 * k);
     }
@@ -519,7 +521,7 @@ int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int chann
         const LevelInfo& D = P.lv[l];
         dim3 blk(64, 4), grd((D.stride / 4 + 63) / 64, (D.h + 2 * MVO_BORDER + 3) / 4);
         ProfScope ps(ctx, "k_resize_border");
-        hipLaunchKernelGGL(k_resize_border, grd, blk, 0, ctx->stream, ctx->d_raw, P.lv[l - 1], D, ctx->d_tabs);
+        hipLaunchKernelGGL(k_resize_border, grd, blk, 0, ctx->stream, ctx->d_raw, P.lv[l - 1], D, ctx->d_tabs, ctx->orb.pyramid_interpolation != 0 ? 1 : 0);
     }
     MVO_HIP(hipGetLastError());
     return MVO_OK;

@@ -26,6 +26,8 @@ inline void latch_orb_params() {
     p.max_keypoints = basics::Config::get<int>("max_number_of_keypoints");
     p.grid_size = basics::Config::get<int>("kpts_uniform_selection_grid_size");
     p.grid_max_per_cell = basics::Config::get<int>("kpts_uniform_selection_max_pts_per_grid");
+    // not a config.yaml key: which cv::resize flavour cv::ORB uses depends on the OpenCV version (>= 3.4: EXACT)
+    p.pyramid_interpolation = basics::Config::has("orb_pyramid_interpolation") ? basics::Config::get<int>("orb_pyramid_interpolation") : 1;
     mvo_check(mvo_orb_configure(hot_path_ctx(), &p), "mvo_orb_configure");
     done = true;
 }

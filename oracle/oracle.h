@@ -40,6 +40,7 @@ typedef struct {
     int32_t max_keypoints;     /* max_number_of_keypoints (1500) */
     int32_t grid_size;         /* kpts_uniform_selection_grid_size (16) */
     int32_t grid_max_per_cell; /* kpts_uniform_selection_max_pts_per_grid (8) */
+    int32_t pyramid_interpolation; /* 1 = cv::INTER_LINEAR_EXACT (cv::ORB of OpenCV >= 3.4), 0 = cv::INTER_LINEAR */
 } orc_orb_params;
 
 /* One FAST+NMS survivor inside the 31-px border of a pyramid level, in canonical order

@@ -25,7 +25,7 @@ def build(force=False):
 class OrbParams(C.Structure):
     _fields_ = [("nfeatures", C.c_int32), ("scale_factor", C.c_float), ("nlevels", C.c_int32),
                 ("fast_threshold", C.c_int32), ("max_keypoints", C.c_int32), ("grid_size", C.c_int32),
-                ("grid_max_per_cell", C.c_int32)]
+                ("grid_max_per_cell", C.c_int32), ("pyramid_interpolation", C.c_int32)]
 
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
@@ -62,7 +62,7 @@ def lib():
 def default_params(**kw):
     """config/config.yaml:65-69, 94-95 defaults."""
     p = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500,
-             grid_size=16, grid_max_per_cell=8)
+             grid_size=16, grid_max_per_cell=8, pyramid_interpolation=1)
     p.update(kw)
     return OrbParams(**p)
 

@@ -90,11 +90,41 @@ void toGray(const uint8_t* img, int w, int h, int stride, int ch, Level& L) {
     L.fillBorder();
 }
 
-// cv::resize(INTER_LINEAR) for 8-bit: 11-bit coefficients, >>4 / >>16 / +2 >>2 vertical pass.
+// cv::ORB builds its pyramid with cv::resize.  Two arithmetic flavours exist upstream:
+//   INTER_LINEAR (OpenCV < 3.4; modules/imgproc/src/resize.cpp, HResizeLinear / VResizeLinear for uchar): source coordinate in
+//     FLOAT, 11-bit coefficients cvRound(f * 2048), vertical pass ((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+//   INTER_LINEAR_EXACT (OpenCV >= 3.4, what cv::ORB uses there; resize.cpp bit-exact path on ufixedpoint16): source coordinate
+//     in DOUBLE (softdouble), 8-bit coefficients cvRound(f * 256) with the pair summing to 256, horizontal pass exact in 8.8,
+//     vertical pass rounded once: (b0 * h0 + b1 * h1 + 2^15) >> 16.
+// The reference's README requires OpenCV >= 3.4.5 / 4.0, so EXACT is the canonical flavour (orc_orb_params default 1).
 struct ResizeTab {
     std::vector<int> ofs;     // source index
     std::vector<short> coef;  // 2 per destination sample
 };
+ResizeTab makeTabExact(int ssize, int dsize) {
+    ResizeTab t;
+    t.ofs.resize(dsize);
+    t.coef.resize(2 * dsize);
+    const double scale = (double)ssize / (double)dsize;
+    for (int d = 0; d < dsize; ++d) {
+        double f = scale * ((double)d + 0.5) - 0.5;
+        int s = (int)std::floor(f);
+        f -= s;
+        if (s < 0) {
+            f = 0;
+            s = 0;
+        }
+        if (s >= ssize - 1) {
+            f = 0;
+            s = ssize - 1;
+        }
+        const int c1 = cvRound(f * 256.0);
+        t.ofs[d] = s;
+        t.coef[2 * d] = (short)(256 - c1);
+        t.coef[2 * d + 1] = (short)c1;
+    }
+    return t;
+}
 ResizeTab makeTab(int ssize, int dsize) {
     ResizeTab t;
     t.ofs.resize(dsize);
@@ -119,8 +149,8 @@ ResizeTab makeTab(int ssize, int dsize) {
     }
     return t;
 }
-void resizeLinear(const Level& S, Level& D) {
-    ResizeTab tx = makeTab(S.w, D.w), ty = makeTab(S.h, D.h);
+void resizeLinear(const Level& S, Level& D, bool exact) {
+    ResizeTab tx = exact ? makeTabExact(S.w, D.w) : makeTab(S.w, D.w), ty = exact ? makeTabExact(S.h, D.h) : makeTab(S.h, D.h);
     for (int dy = 0; dy < D.h; ++dy) {
         int sy0 = ty.ofs[dy], sy1 = std::min(sy0 + 1, S.h - 1);
         int b0 = ty.coef[2 * dy], b1 = ty.coef[2 * dy + 1];
@@ -132,7 +162,8 @@ void resizeLinear(const Level& S, Level& D) {
             int a0 = tx.coef[2 * dx], a1 = tx.coef[2 * dx + 1];
             int h0 = r0[sx0] * a0 + r0[sx1] * a1;
             int h1 = r1[sx0] * a0 + r1[sx1] * a1;
-            d[dx] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+            d[dx] = exact ? (uint8_t)((b0 * h0 + b1 * h1 + 32768) >> 16)
+                          : (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
         }
     }
 }
@@ -147,14 +178,43 @@ void buildPyramid(const uint8_t* img, int w, int h, int stride, int ch, const or
         levelSize(w, h, p, l, lw, lh, sc);
         pyr[l].alloc(lw, lh);
         pyr[l].scale = sc;
-        resizeLinear(pyr[l - 1], pyr[l]);  // each level from the PREVIOUS level
+        resizeLinear(pyr[l - 1], pyr[l], p.pyramid_interpolation != 0);  // each level from the PREVIOUS level
         pyr[l].fillBorder();
     }
 }
 
 // cv::GaussianBlur(7x7, sigma 2) canonical fixed point: 8-bit kernel (sum 256, error diffused from
 // the tails to the centre), horizontal pass kept in 8.8, vertical pass rounded (+2^15) >> 16.
-const int kGauss7[7] = {18, 34, 48, 56, 48, 34, 18};
+// The kernel is DERIVED the way OpenCV's bit-exact path does (getGaussianKernelBitExact + fixed-point conversion with
+// error diffusion, modules/imgproc/src/smooth.dispatch.cpp): k_i = exp(-i^2 / (2 sigma^2)) normalised to 1, then from the
+// outermost tap inwards v_i = cvRound(k_i * 256 + err), err = (k_i * 256 + err) - v_i, and the centre takes what is left
+// of 256.  For ksize 7, sigma 2 this gives {18, 34, 48, 56, 48, 34, 18} (tests/test_oracle_orb.py checks it).
+void gaussKernelFixed(int ksize, double sigma, int bits, int* out) {
+    std::vector<double> k(ksize);
+    double sum = 0;
+    for (int i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        k[i] = std::exp(-0.5 / (sigma * sigma) * x * x);
+        sum += k[i];
+    }
+    const double mul = (double)(1 << bits);
+    double err = 0;
+    int acc = 0;
+    for (int i = 0; i < ksize / 2; ++i) {
+        const double adj = k[i] / sum * mul + err;
+        const int v = cvRound(adj);
+        err = adj - v;
+        out[i] = out[ksize - 1 - i] = v;
+        acc += 2 * v;
+    }
+    out[ksize / 2] = (1 << bits) - acc;
+}
+struct Gauss7 {
+    int k[7];
+    Gauss7() { gaussKernelFixed(7, 2.0, 8, k); }
+};
+const Gauss7 kGaussDerived;
+const int* const kGauss7 = kGaussDerived.k;
 void blurLevel(const Level& S, Level& D) {
     D = S;  // frame stays unblurred
     std::vector<int> hbuf((size_t)(S.h + 6) * S.w);

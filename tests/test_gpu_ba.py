@@ -262,7 +262,8 @@ def test_bitwise_config4_ba10_window(mvo, O, ctx):
 
 
 @pytest.mark.parametrize("mfma", [1, 0])
-@pytest.mark.parametrize("case", ["pose_only", "anchored", "fixed0_info", "tiny_one_range", "dups", "seven_poses"])
+@pytest.mark.parametrize("case", ["pose_only", "anchored", "fixed0_info", "tiny_one_range", "ragged_chain_tails",
+                                  "dups", "seven_poses"])
 def test_bitwise_variants(mvo, O, ctx, case, mfma):
     mvo.debug_set("ba_mfma", mfma)
     try:
@@ -278,6 +279,14 @@ def test_bitwise_variants(mvo, O, ctx, case, mfma):
         elif case == "tiny_one_range":
             st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(3, 40, 5), fix_points=False)
             assert plan["wgs"] == 1
+        elif case == "ragged_chain_tails":
+            # every remainder of the chain length modulo the unrolled group of four steps, with one and with several
+            # column pieces; the first window is the committed golden one (tests/golden/ba_3x40.npz)
+            _bitwise(mvo, O, ctx, mvo.synth.ba_problem(3, 40, 77), fix_points=False, max_iterations=3)
+            for L in (37, 41, 42, 43, 150):
+                _bitwise(mvo, O, ctx, mvo.synth.ba_problem(3, L, 100 + L), fix_points=False, max_iterations=12)
+                _bitwise(mvo, O, ctx, mvo.synth.ba_problem(3, L, 200 + L), fix_points=False, max_iterations=12,
+                         pose_fixed=_fix(3, 1))
         elif case == "dups":
             pb = mvo.synth.ba_problem(3, 300, 6)
             pb = dict(pb, edge_pose=np.concatenate([pb["edge_pose"], pb["edge_pose"][:90]]),

@@ -10,7 +10,8 @@ SIZES = [(160, 120, 3), (320, 240, 3), (333, 251, 1), (640, 480, 3)]
 
 
 DEFAULTS = dict(nfeatures=8000, scale_factor=1.2, nlevels=4, fast_threshold=20, max_keypoints=1500, grid_size=16,
-                grid_max_per_cell=8)   # config/config.yaml:65-69,94-95
+                grid_max_per_cell=8,   # config/config.yaml:65-69,94-95
+                pyramid_interpolation=1)   # cv::ORB of OpenCV >= 3.4 (INTER_LINEAR_EXACT)
 
 
 def _cfg(mvo, O, ctx, **kw):
@@ -45,6 +46,24 @@ def test_pyramid_blur_candidates_bit_exact(mvo, O, ctx, w, h, ch):
             assert len(bad) == 0, "level %d blurred=%d: %d px differ, first %s (gpu %d oracle %d)" % (
                 l, blurred, len(bad), bad[0], g[tuple(bad[0])], o[tuple(bad[0])])
     _cand_cmp(mvo, ctx.debug_candidates(), O.candidates(img, p))
+
+
+def test_legacy_inter_linear_pyramid_bit_exact(mvo, O, ctx):
+    """pyramid_interpolation = 0: cv::INTER_LINEAR as cv::ORB of OpenCV < 3.4 resampled (11-bit coefficients, truncating
+    vertical pass) -- the other flavour of the oracle; every level, the candidates and the descriptors follow."""
+    p = _cfg(mvo, O, ctx, max_keypoints=2000, pyramid_interpolation=0)
+    img = mvo.synth.small_test_image(99, 320, 240)
+    k = ctx.calc_keypoints(img, cap=4096)
+    for l in range(1, p.nlevels):
+        assert np.array_equal(ctx.debug_level(l, False), O.pyramid_level(img, p, l, False)), l
+    pe = O.default_params(max_keypoints=2000)
+    assert (O.pyramid_level(img, p, 1) != O.pyramid_level(img, pe, 1)).any()      # really the other arithmetic
+    _cand_cmp(mvo, ctx.debug_candidates(), O.candidates(img, p))
+    ko = O.calc_keypoints(img, p)
+    assert_struct_equal(k, ko.astype(k.dtype), "calcKeyPoints (INTER_LINEAR pyramid)")
+    k2, d = ctx.calc_descriptors(img, k, reuse_pyramid=True)
+    ko2, do = O.calc_descriptors(img, ko, p)
+    assert np.array_equal(d, do)
 
 
 @pytest.mark.parametrize("w,h,ch", SIZES)

@@ -240,3 +240,56 @@ def test_brief_rotation_consistency(O):
         descs.append(d[0])
     for q in range(1, 4):
         assert np.array_equal(descs[0], descs[q]), q
+
+
+def test_blur_kernel_is_the_error_diffused_fixed_point_gaussian(O):
+    """The 7-tap sigma-2 kernel is DERIVED like OpenCV's bit-exact GaussianBlur does (normalised Gaussian -> 8.8 fixed point
+    with error diffusion from the tails, the centre takes the remainder): {18, 34, 48, 56, 48, 34, 18}; read back here as the
+    impulse response of the blur (horizontal x vertical = outer product, (+2^15) >> 16)."""
+    k = np.exp(-0.5 / 4.0 * (np.arange(7) - 3.0) ** 2)
+    k = k / k.sum() * 256
+    err, half = 0.0, []
+    for i in range(3):
+        adj = k[i] + err
+        v = int(np.rint(adj))
+        err = adj - v
+        half.append(v)
+    kern = np.array(half + [256 - 2 * sum(half)] + half[::-1])
+    assert kern.tolist() == [18, 34, 48, 56, 48, 34, 18]
+    imp = np.zeros((41, 41), np.uint8)
+    imp[20, 20] = 255
+    bl = O.pyramid_level(imp, P(O, nlevels=1), 0, blurred=True)[32:-32, 32:-32].astype(int)
+    want = (255 * np.outer(kern, kern) + 32768) >> 16
+    assert np.array_equal(bl[17:24, 17:24], want)
+
+
+def test_pyramid_interpolation_flavours(O):
+    """cv::ORB resamples its pyramid with INTER_LINEAR_EXACT from OpenCV 3.4 on (canonical here, the reference needs
+    >= 3.4.5) and with INTER_LINEAR before.  Both are restated; they differ by at most one grey level, agree on constants and
+    on exact 2:1 decimation grids, and EXACT equals its defining formula."""
+    rng = np.random.RandomState(4)
+    img = rng.randint(0, 256, (97, 131)).astype(np.uint8)
+    pe, pl = P(O, nlevels=2), P(O, nlevels=2, pyramid_interpolation=0)
+    le = O.pyramid_level(img, pe, 1)[32:-32, 32:-32].astype(int)
+    ll = O.pyramid_level(img, pl, 1)[32:-32, 32:-32].astype(int)
+    assert le.shape == ll.shape and np.abs(le - ll).max() <= 1 and (le != ll).any()
+    # the defining formula of the exact flavour: coordinates in double, 8-bit coefficients, one rounding
+    h, w = img.shape
+    dh, dw = le.shape
+    def tab(s, d):
+        f = (s / d) * (np.arange(d) + 0.5) - 0.5
+        o = np.floor(f).astype(int)
+        f = f - o
+        f[o < 0], o[o < 0] = 0, 0
+        f[o >= s - 1], o[o >= s - 1] = 0, s - 1
+        c1 = np.rint(f * 256).astype(int)
+        return o, 256 - c1, c1
+    ox, ax0, ax1 = tab(w, dw)
+    oy, ay0, ay1 = tab(h, dh)
+    I = img.astype(int)
+    x1, y1 = np.minimum(ox + 1, w - 1), np.minimum(oy + 1, h - 1)
+    hr = I[:, ox] * ax0 + I[:, x1] * ax1
+    want = (hr[oy] * ay0[:, None] + hr[y1] * ay1[:, None] + 32768) >> 16
+    assert np.array_equal(le, want)
+    for p in (pe, pl):
+        assert (O.pyramid_level(np.full((60, 80), 91, np.uint8), p, 1) == 91).all()
