@@ -95,6 +95,13 @@ typedef struct {
     float distance;
 } orc_dmatch; /* cv::DMatch */
 
+/* FLANN LSH(tables, key_size, multi_probe_level) 2-NN with seeded key bits, and matchFeatures' selection rules applied
+ * to a given 2-NN table: used to quantify approximate-vs-exact matching (match_oracle.cpp). */
+int orc_match_knn2_lsh(const uint8_t* q, int nq, const uint8_t* t, int nt, int tables, int key_size, int probe_level,
+                       uint32_t seed, int32_t* idx, int32_t* dist);
+int orc_match_features_from_knn(const int32_t* idx, const int32_t* dist, int n1, int method, double xiang_gao_ratio,
+                                double lowe_ratio, orc_dmatch* out, int cap);
+
 /* geometry::matchFeatures (feature_match.cpp:126-239). method 1 uses the exact 1-NN in place of
  * FLANN-LSH (documented deviation). ratios are passed as the reference latches
  * them (get<int> -> 0.8 becomes 1; pass 0.8 for the intended behaviour). Returns match count. */

@@ -168,6 +168,30 @@ def match_radius_l1(q, qxy, t, txy, max_px):
     return idx, s
 
 
+def match_knn2_lsh(q, t, tables=5, key_size=10, probe_level=2, seed=1):
+    """2-NN through a restated FLANN LSH index (the reference's LshIndexParams(5, 10, 2)); -1 = no candidate."""
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.zeros((len(q), 2), np.int32)
+    dist = np.zeros((len(q), 2), np.int32)
+    n = lib().orc_match_knn2_lsh(q.ctypes.data_as(C.c_void_p), len(q), t.ctypes.data_as(C.c_void_p), len(t), tables,
+                                 key_size, probe_level, C.c_uint32(seed), idx.ctypes.data_as(C.c_void_p),
+                                 dist.ctypes.data_as(C.c_void_p))
+    assert n >= 0, n
+    return idx, dist
+
+
+def match_features_from_knn(idx, dist, method=1, xiang_gao_ratio=2.0, lowe_ratio=1.0):
+    idx = np.ascontiguousarray(idx, np.int32)
+    dist = np.ascontiguousarray(dist, np.int32)
+    out = np.zeros(max(len(idx), 1), DMATCH_DTYPE)
+    n = lib().orc_match_features_from_knn(idx.ctypes.data_as(C.c_void_p), dist.ctypes.data_as(C.c_void_p), len(idx),
+                                          method, C.c_double(xiang_gao_ratio), C.c_double(lowe_ratio),
+                                          out.ctypes.data_as(C.c_void_p), len(out))
+    assert n >= 0, n
+    return out[:n].copy()
+
+
 def match_features(d1, d2, method=1, xiang_gao_ratio=2.0, lowe_ratio=1.0, xy1=None, xy2=None, max_px=0.0):
     d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
     d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
