@@ -278,18 +278,11 @@ def algorithmic_work(args):
         lv.append((int(np.rint(w / s)), int(np.rint(h / s))))
     P = sum(a * b for a, b in lv)
     return {
-        "k_gray_border": ("hbm", w * h * 3 + w * h),
-        "k_resize_border": ("hbm", 2 * (P - w * h) / 3.0),            # per launch (3 launches / frame)
-        "k_pyramid": ("hbm", w * h * 3 + P),
-        "k_fast_nms": ("hbm", P),
-        "k_scan_cells": ("hbm", 8 * 12400),
-        "k_emit_cells": ("hbm", 12 * 12400 + 16 * 8000),
+        "k_pyramid": ("hbm", w * h * 3 + P),                           # BGR in, every level out (frames excluded)
+        "k_fast_nms": ("hbm", P + 8 * 12400 + 16 * 8000),              # levels in, cell masks + candidate list out
         "k_harris_angle": ("hbm", (81 + 749) * 8000),
-        "k_blur": ("hbm", 2 * P),
-        "k_brief": ("hbm", (961 + 32 + 16) * K),
-        "k_knn2_partial": ("valu", 16.0 * K * K),
+        "k_brief": ("hbm", (45 * 56 + 32 + 16) * K),                   # raw window in, descriptor out
         "k_knn2": ("valu", 16.0 * K * K),
-        "k_knn2_merge": ("hbm", 32 * 16.0 * K),
     }
 
 

@@ -5,10 +5,11 @@
 //   k_radius_l1 geometry::matchByRadiusAndBruteForce (feature_match.cpp:86-124).
 // Work decomposition (wave64): one LANE per query, the query's 256 bits live in 4 x u64 VGPRs; the train
 // descriptor of the current step is wave-uniform, so it is fetched with scalar loads (s_load_dwordx8) and
-// broadcast for free; distance = 8 x (v_xor + v_bcnt_u32).  k_knn2_partial: one wave per (64 queries, train slice)
-// pair, 32 slices -> 1024 single-wave workgroups for 2000 x 2000, each scanning its slice in index order;
-// k_knn2_merge folds the 32 partial (best, second) pairs of a query in slice order with strict '<', which
-// reproduces cv::batchDistance's tie rule exactly (equal distances keep the lower train index).  k_radius_l1
+// broadcast for free; distance = 8 x (v_xor + v_bcnt_u32).  k_knn2: one wave per (64 queries, train slice) pair,
+// 32 slices -> 1024 single-wave workgroups for 2000 x 2000, each scanning its slice in index order; the last wave to
+// arrive for a query group folds the 32 partial (best, second) pairs, keeping the lexicographically smallest
+// (distance, index) pairs, which reproduces cv::batchDistance's tie rule exactly (equal distances keep the lower
+// train index).  k_radius_l1
 // keeps the single-kernel form (16 waves x 64 queries, LDS merge).  Everything is integer: results are bit-exact.
 // The whole working set (<= 2 x 128 KB) is L2-resident: the bound is VALU integer throughput, not HBM.
 #include "mvo_internal.h"
@@ -34,14 +35,22 @@ __device__ __forceinline__ void top2_insert(Top2& t, int d, int j) {
     t.i1 = ni1;
 }
 
-// Stage 1: grid = (query groups of 64) x MK_SLICES train slices, ONE wave per workgroup -> 1024 waves for a
-// 2000 x 2000 call (every SIMD of the chip gets one).  The wave first parks its slice in registers -- lane j holds
-// train descriptor j of the current 64-train chunk (one coalesced 2 KB read) -- and then broadcasts descriptor j
-// to all lanes with v_readlane: no memory access and no LDS in the pair loop.
+// grid = (query groups of 64) x MK_SLICES train slices, ONE wave per workgroup -> 1024 waves for a 2000 x 2000 call
+// (every SIMD of the chip gets one).  The wave first parks its slice in registers -- lane j holds train descriptor j of
+// the current 64-train chunk (one coalesced 2 KB read) -- and then broadcasts descriptor j to all lanes with
+// v_readlane: no memory access and no LDS in the pair loop.  The partial (best, second) pairs go out write-through at
+// agent scope; the wave that arrives LAST for its query group (arrival counter per group) folds the 32 partials of its
+// 64 queries and delivers the result: no merge launch.  The fold keeps the two lexicographically smallest
+// (distance, train index) pairs, which is exactly the strict-'<' in-order scan (indices are unique), so the order in
+// which the slices finished does not matter.
 #define MK_SLICES 32
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
-__global__ __launch_bounds__(64) void k_knn2_partial(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t,
-                                                     int nt, int4* __restrict__ part) {
+__device__ __forceinline__ bool pair_less(int d, int i, int e, int j) {  // (d,i) < (e,j); index -1 = empty = +inf
+    return j < 0 ? i >= 0 : (i >= 0 && (d < e || (d == e && i < j)));
+}
+__global__ __launch_bounds__(64) void k_knn2(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
+                                             u64* __restrict__ part, int32_t* __restrict__ arrive,
+                                             int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
     const int lane = threadIdx.x;
     const int qi = blockIdx.x * 64 + lane;
     const int qc = min(qi, nq - 1);
@@ -60,27 +69,26 @@ __global__ __launch_bounds__(64) void k_knn2_partial(const uint4* __restrict__ q
             top2_insert(b, d, c0 + j);
         }
     }
-    if (qi < nq) part[(size_t)blockIdx.y * nq + qi] = make_int4(b.d0, b.i0, b.d1, b.i1);
-}
-// Stage 2: one lane per (query, slice); the 32 partial pairs of a query are folded by a shuffle butterfly.  The
-// fold keeps the two lexicographically smallest (distance, train index) pairs, which is exactly the strict-'<'
-// in-order scan (indices are unique), so the order of the fold does not matter.
-__device__ __forceinline__ bool pair_less(int d, int i, int e, int j) {  // (d,i) < (e,j); index -1 = empty = +inf
-    return j < 0 ? i >= 0 : (i >= 0 && (d < e || (d == e && i < j)));
-}
-__global__ __launch_bounds__(256) void k_knn2_merge(const int4* __restrict__ part, int nq, int32_t* __restrict__ out_idx,
-                                                    int32_t* __restrict__ out_dist) {
-    const int s = threadIdx.x & 31;
-    const int qi = blockIdx.x * 8 + (threadIdx.x >> 5);
+    // partial of (slice, query): two 8-byte {distance, index} words
+    u64* mine = part + 2 * ((size_t)blockIdx.y * nq + qc);
+    if (qi < nq) {
+        __hip_atomic_store(mine, ((u64)(uint32_t)b.i0 << 32) | (uint32_t)b.d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, ((u64)(uint32_t)b.i1 << 32) | (uint32_t)b.d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are complete before this wave is counted
+    int last = 0;
+    if (lane == 0) {
+        last = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MK_SLICES - 1;
+        if (last) __hip_atomic_store(arrive + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
+    }
+    if (!__builtin_amdgcn_readfirstlane(last)) return;
     int4 p = make_int4(INT_MAX, -1, INT_MAX, -1);
-    if (qi < nq) p = part[(size_t)s * nq + qi];
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-        int4 r;
-        r.x = __shfl_xor(p.x, o);
-        r.y = __shfl_xor(p.y, o);
-        r.z = __shfl_xor(p.z, o);
-        r.w = __shfl_xor(p.w, o);
+#pragma unroll 8
+    for (int s = 0; s < MK_SLICES; ++s) {
+        const u64* src = part + 2 * ((size_t)s * nq + qc);
+        const u64 w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int4 r = make_int4((int)(uint32_t)w0, (int)(uint32_t)(w0 >> 32), (int)(uint32_t)w1, (int)(uint32_t)(w1 >> 32));
         // merge two sorted pairs (p.x,p.y)<=(p.z,p.w) and (r.x,r.y)<=(r.z,r.w)
         const bool pf = pair_less(p.x, p.y, r.x, r.y);
         const int b0d = pf ? p.x : r.x, b0i = pf ? p.y : r.y;          // overall best
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(256) void k_knn2_merge(const int4* __restrict__ par
         const bool sf = pair_less(cd, ci, nd, ni);
         p = make_int4(b0d, b0i, sf ? cd : nd, sf ? ci : ni);
     }
-    if (s == 0 && qi < nq) {
+    if (qi < nq) {
         out_idx[2 * qi] = p.y;
         out_idx[2 * qi + 1] = p.w;
         out_dist[2 * qi] = p.y >= 0 ? p.x : INT_MAX;
@@ -143,23 +151,16 @@ __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__
 }
 
 // d_out: device scratch (partials behind nq x 4 int32); final (optional): where the merged (idx, dist) block goes --
-// a pinned host buffer lets the merge kernel deliver the result itself (no copy dispatch on the frame's critical path)
+// a pinned host buffer lets the kernel deliver the result itself (no copy dispatch on the frame's critical path)
 int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out,
                       int32_t* final_out) {
     if (nq <= 0) return MVO_OK;
-    // d_part: MK_SLICES x nq int4 partials live behind the nq x 4 int32 result block
-    int4* d_part = reinterpret_cast<int4*>(d_out + 4 * (size_t)nq);
-    {
-        ProfScope ps(ctx, "k_knn2_partial");
-        hipLaunchKernelGGL(k_knn2_partial, dim3((nq + 63) / 64, MK_SLICES), dim3(64), 0, ctx->stream, (const uint4*)d_q,
-                           nq, (const uint4*)d_t, nt, d_part);
-    }
-    {
-        ProfScope ps(ctx, "k_knn2_merge");
-        int32_t* dst = final_out ? final_out : d_out;
-        hipLaunchKernelGGL(k_knn2_merge, dim3((nq + 7) / 8), dim3(256), 0, ctx->stream, d_part, nq, dst,
-                           dst + 2 * (size_t)nq);
-    }
+    // MK_SLICES x nq 16-byte partials live behind the nq x 4 int32 result block
+    u64* d_part = reinterpret_cast<u64*>(d_out + 4 * (size_t)nq);
+    int32_t* dst = final_out ? final_out : d_out;
+    ProfScope ps(ctx, "k_knn2");
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, MK_SLICES), dim3(64), 0, ctx->stream, (const uint4*)d_q, nq,
+                       (const uint4*)d_t, nt, d_part, ctx->d_marrive, dst, dst + 2 * (size_t)nq);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

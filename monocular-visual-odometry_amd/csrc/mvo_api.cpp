@@ -87,7 +87,7 @@ void mvo_destroy(mvo_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     track_release(ctx);
     ba_pool_release(ctx);
-    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_score, ctx->d_tabs, ctx->d_cell_mask, ctx->d_cell_cnt, ctx->d_cell_off,
+    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_score, ctx->d_tabs, ctx->d_cell_mask, ctx->d_arrivals,
                    ctx->d_hdr, ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
                    ctx->d_mout};
     for (void* p : dev)
@@ -198,7 +198,7 @@ int mvo_calc_descriptors(mvo_ctx* ctx, const uint8_t* image, int w, int h, int s
     MVO_HIP(hipSetDevice(ctx->device));
     int r;
     if (reuse_pyramid) {
-        if (!ctx->pyr_valid || !ctx->blur_valid || ctx->img_w != w || ctx->img_h != h)
+        if (!ctx->pyr_valid || ctx->img_w != w || ctx->img_h != h)
             return mvo_set_err(ctx, MVO_ERR_STATE, "reuse_pyramid without a cached pyramid of this size", hipSuccess);
         if (rgb && (r = check_image(ctx, image, w, h, stride, ch))) return r;
     } else {
@@ -212,9 +212,8 @@ int mvo_calc_descriptors(mvo_ctx* ctx, const uint8_t* image, int w, int h, int s
         if ((r = upload_image(ctx, image, h, stride))) return r;
         ctx->pyr_valid = ctx->blur_valid = false;
         if ((r = orb_launch_pyramid(ctx, ctx->d_img, stride, ch, need))) return r;
-        if ((r = orb_launch_blur(ctx, need))) return r;
         ctx->pyr_levels_built = need;
-        ctx->pyr_valid = ctx->blur_valid = true;
+        ctx->pyr_valid = true;
     }
     std::vector<mvo_keypoint> v;
     if ((r = describe_common(ctx, w, h, kps, n, desc, v))) return r;
@@ -237,7 +236,7 @@ int mvo_calc_descriptors(mvo_ctx* ctx, const uint8_t* image, int w, int h, int s
 int mvo_calc_descriptors_dev(mvo_ctx* ctx, mvo_keypoint* kps, int* n, uint8_t* desc, const void** d_desc_out) {
     if (!ctx || !kps || !n || *n < 0) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
     MVO_HIP(hipSetDevice(ctx->device));
-    if (!ctx->pyr_valid || !ctx->blur_valid)
+    if (!ctx->pyr_valid)
         return mvo_set_err(ctx, MVO_ERR_STATE, "no cached pyramid: call mvo_calc_keypoints[_dev] first", hipSuccess);
     std::vector<mvo_keypoint> v;
     int r = describe_common(ctx, ctx->img_w, ctx->img_h, kps, n, desc, v);
@@ -270,7 +269,11 @@ static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
         int cap = std::max(4096, nq + nq / 2);
         MVO_HIP(hipMalloc((void**)&ctx->d_mq, (size_t)cap * 32));
         MVO_HIP(hipMalloc((void**)&ctx->d_mqxy, (size_t)cap * 8));
-        MVO_HIP(hipMalloc((void**)&ctx->d_mout, (size_t)cap * (16 + 32 * 16)));  // results + 32 slices of partials
+        // results + 32 slices of partials + one arrival counter per group of 64 queries (self re-arming, zeroed once)
+        const size_t body = (size_t)cap * (16 + 32 * 16), ctr = ((size_t)cap / 64 + 2) * 4;
+        MVO_HIP(hipMalloc((void**)&ctx->d_mout, body + ctr));
+        ctx->d_marrive = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctx->d_mout) + body);
+        MVO_HIP(hipMemsetAsync(ctx->d_marrive, 0, ctr, ctx->stream));
         ctx->m_cap_q = cap;
     }
     if (nt > ctx->m_cap_t) {
@@ -562,7 +565,6 @@ int mvo_debug_get_ba_phases(mvo_ctx* ctx, long long* cycles, int n, int* wgs) {
 int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int cap, int* w, int* h, int* stride) {
     if (!ctx || !ctx->pyr_valid || level < 0 || level >= ctx->pyr_levels_built)
         return mvo_set_err(ctx, MVO_ERR_STATE, "no such cached level", hipSuccess);
-    if (blurred && !ctx->blur_valid) return mvo_set_err(ctx, MVO_ERR_STATE, "no blurred pyramid", hipSuccess);
     const LevelInfo& L = ctx->pyr.lv[level];
     const size_t bytes = (size_t)L.stride * (L.h + 2 * MVO_BORDER);
     if (w) *w = L.w;
@@ -571,6 +573,10 @@ int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int 
     if (!out) return MVO_OK;
     if ((size_t)cap < bytes) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "level buffer too small", hipSuccess);
     MVO_HIP(hipSetDevice(ctx->device));
+    if (blurred && !ctx->blur_valid) {  // the product path blurs per keypoint window; the whole level only on request
+        int r = orb_launch_blur(ctx, ctx->pyr_levels_built);
+        if (r) return r;
+    }
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     MVO_HIP(hipMemcpy(out, (blurred ? ctx->d_blur : ctx->d_raw) + L.off, bytes, hipMemcpyDeviceToHost));
     return MVO_OK;

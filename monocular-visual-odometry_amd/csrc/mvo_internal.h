@@ -26,6 +26,8 @@ struct LevelInfo {
     int btiles_y;
     int btile_off;
     int tab_off;     // offset of this level's resize tables: [x entries w][y entries h]
+    int pblk_x;      // pyramid kernel: workgroups (256 px x 4 rows) per bordered row band
+    int pblk_off;    // first pyramid workgroup of this level in the flattened list
     float scale;     // layerScale[level]
 };
 struct PyrInfo {
@@ -33,6 +35,7 @@ struct PyrInfo {
     int n_cells;
     int n_tiles;
     int n_btiles;
+    int n_pblk;
     LevelInfo lv[MVO_MAX_LEVELS];
 };
 
@@ -95,8 +98,7 @@ struct mvo_ctx {
     size_t pyr_bytes = 0;
     ResizeEntry* d_tabs = nullptr;
     unsigned long long* d_cell_mask = nullptr;
-    int32_t* d_cell_cnt = nullptr;
-    int32_t* d_cell_off = nullptr;
+    int32_t* d_arrivals = nullptr;  // k_fast_nms: [0] arrival tickets, [1 ..] survivors per cell run (self re-arming)
     CandHeader* d_hdr = nullptr;
     DevCandidate* d_cand = nullptr;
     int cand_cap = 0;
@@ -113,6 +115,7 @@ struct mvo_ctx {
     uint8_t *d_mq = nullptr, *d_mt = nullptr;
     float *d_mqxy = nullptr, *d_mtxy = nullptr;
     int32_t* d_mout = nullptr;
+    int32_t* d_marrive = nullptr;  // k_knn2 arrival counters (inside the d_mout allocation)
     int m_cap_q = 0, m_cap_t = 0;
     // --- tracking rows
     mvo_track_state* track = nullptr;
@@ -155,9 +158,9 @@ int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes);
 
 // orb_kernels.hip
 int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int channels, int nlevels);
-int orb_launch_detect(mvo_ctx* ctx);
+int orb_launch_detect(mvo_ctx* ctx, uint8_t* host);
 int orb_launch_blur(mvo_ctx* ctx, int nlevels);
-int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps);
+int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps, uint8_t* desc_host);
 // match_kernels.hip
 int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out,
                       int32_t* final_out);

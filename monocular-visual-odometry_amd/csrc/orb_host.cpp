@@ -122,7 +122,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     PyrInfo P{};
     P.nlevels = p.nlevels;
     size_t off = 256, tab = 0;
-    int cells = 0, tiles = 0, btiles = 0;
+    int cells = 0, tiles = 0, btiles = 0, pblk = 0;
     for (int l = 0; l < p.nlevels; ++l) {
         LevelInfo& L = P.lv[l];
         L.scale = layer_scale(p, l);
@@ -144,7 +144,11 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
         btiles += L.btiles_x * L.btiles_y;
         L.tab_off = (int)tab;
         tab += L.w + L.h;
+        L.pblk_x = (L.stride / 4 + 63) / 64;
+        L.pblk_off = pblk;
+        pblk += L.pblk_x * ((L.h + 2 * MVO_BORDER + 3) / 4);
     }
+    P.n_pblk = pblk;
     P.n_cells = cells;
     P.n_tiles = tiles;
     P.n_btiles = btiles;
@@ -154,8 +158,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     free_dev(ctx->d_score);
     free_dev(ctx->d_tabs);
     free_dev(ctx->d_cell_mask);
-    free_dev(ctx->d_cell_cnt);
-    free_dev(ctx->d_cell_off);
+    free_dev(ctx->d_arrivals);
     MVO_HIP(hipMalloc((void**)&ctx->d_raw, bytes));
     MVO_HIP(hipMalloc((void**)&ctx->d_blur, bytes));
     MVO_HIP(hipMalloc((void**)&ctx->d_score, bytes));
@@ -164,8 +167,8 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     MVO_HIP(hipMemsetAsync(ctx->d_score, 0, bytes, ctx->stream));
     MVO_HIP(hipMalloc((void**)&ctx->d_tabs, tab * sizeof(ResizeEntry)));
     MVO_HIP(hipMalloc((void**)&ctx->d_cell_mask, (size_t)cells * 8));
-    MVO_HIP(hipMalloc((void**)&ctx->d_cell_cnt, (size_t)cells * 4 + 64));
-    MVO_HIP(hipMalloc((void**)&ctx->d_cell_off, (size_t)cells * 4 + 64));
+    MVO_HIP(hipMalloc((void**)&ctx->d_arrivals, 64));
+    MVO_HIP(hipMemsetAsync(ctx->d_arrivals, 0, 64, ctx->stream));
     std::vector<ResizeEntry> tabs(tab);
     for (int l = 1; l < p.nlevels; ++l) {
         fill_resize_tab(&tabs[P.lv[l].tab_off], P.lv[l - 1].w, P.lv[l].w, ctx->orb.pyramid_interpolation != 0);
@@ -231,8 +234,7 @@ int orb_grid_select(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int image_rows
     return MVO_OK;
 }
 
-// cv::ORB::detect on an image already in device memory; leaves the raw pyramid (and a speculatively blurred
-// copy) cached in the ctx.
+// cv::ORB::detect on an image already in device memory; leaves the raw pyramid cached in the ctx.
 int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int channels,
                       std::vector<mvo_keypoint>& out) {
     int r = orb_setup_geometry(ctx, w, h);
@@ -240,23 +242,14 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     const PyrInfo& P = ctx->pyr;
     ctx->pyr_valid = ctx->blur_valid = false;
     if ((r = orb_launch_pyramid(ctx, d_img, stride, channels, P.nlevels))) return r;
-    if ((r = orb_launch_detect(ctx))) return r;
-    const int chunk = std::min(ctx->cand_cap, 16384);
-    const size_t first = sizeof(CandHeader) + (size_t)chunk * sizeof(DevCandidate);
+    // the kernels deliver the header and the finished candidate records into the pinned buffer themselves
     if ((r = mvo_ensure_pinned(ctx, sizeof(CandHeader) + (size_t)ctx->cand_cap * sizeof(DevCandidate)))) return r;
-    MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_hdr, first, hipMemcpyDeviceToHost, ctx->stream));
+    if ((r = orb_launch_detect(ctx, ctx->h_pin))) return r;
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
-    // the blur does not depend on the selection: it runs while the host selects
-    if ((r = orb_launch_blur(ctx, P.nlevels))) return r;
     MVO_HIP(hipEventSynchronize(ctx->ev));
     const CandHeader* hdr = (const CandHeader*)ctx->h_pin;
     const int n_total = hdr->n_total;
     if (n_total > ctx->cand_cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "candidate buffer overflow", hipSuccess);
-    if (n_total > chunk) {
-        MVO_HIP(hipMemcpyAsync(ctx->h_pin + first, (const char*)ctx->d_hdr + first,
-                               (size_t)(n_total - chunk) * sizeof(DevCandidate), hipMemcpyDeviceToHost, ctx->stream));
-        MVO_HIP(hipStreamSynchronize(ctx->stream));
-    }
     const DevCandidate* cand = (const DevCandidate*)(ctx->h_pin + sizeof(CandHeader));
     out.clear();
     std::vector<DevCandidate> lv;
@@ -279,12 +272,11 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
         }
     }
     ctx->pyr_valid = true;
-    ctx->blur_valid = true;
     ctx->pyr_levels_built = P.nlevels;
     return MVO_OK;
 }
 
-// cv::ORB::compute given keypoints; the blurred pyramid must be valid for levels < nlevels_needed.
+// cv::ORB::compute given keypoints; the raw pyramid must be valid for levels < nlevels_needed.
 int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int h, uint8_t* desc_host) {
     const PyrInfo& P = ctx->pyr;
     const int n = (int)kps.size();
@@ -307,17 +299,13 @@ int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int
         if (hk[i].cx < -12 || hk[i].cx > L.w + 11 || hk[i].cy < -12 || hk[i].cy > L.h + 11)
             return mvo_set_err(ctx, MVO_ERR_INVALID, "keypoint outside its pyramid level", hipSuccess);
     }
-    // the kernel reads the 16-byte keypoint records straight from the pinned staging buffer (one load per wave): no
-    // upload dispatch on the frame's critical path; the buffer is not touched again before the synchronisation below
-    if ((r = orb_launch_brief(ctx, n, hk))) return r;
-    if (desc_host) {
-        uint8_t* hd = ctx->h_pin + (size_t)n * sizeof(DevDescKp);
-        MVO_HIP(hipMemcpyAsync(hd, ctx->d_desc, (size_t)n * 32, hipMemcpyDeviceToHost, ctx->stream));
-        MVO_HIP(hipStreamSynchronize(ctx->stream));
-        std::memcpy(desc_host, hd, (size_t)n * 32);
-    } else {
-        MVO_HIP(hipStreamSynchronize(ctx->stream));
-    }
+    // the kernel reads the 16-byte keypoint records straight from the pinned staging buffer (one load per wave) and
+    // writes the descriptors into it as well as into device memory: no copy dispatch on the frame's critical path; the
+    // buffer is not touched again before the synchronisation below
+    uint8_t* hd = desc_host ? ctx->h_pin + (size_t)n * sizeof(DevDescKp) : nullptr;
+    if ((r = orb_launch_brief(ctx, n, hk, hd))) return r;
+    MVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (desc_host) std::memcpy(desc_host, hd, (size_t)n * 32);
     (void)w;
     (void)h;
     return MVO_OK;

@@ -5,21 +5,25 @@
 // 32-px BORDER_REFLECT_101 frame, row stride rounded up to 64 B so that every tile row starts dword-aligned and
 // a 64-lane wave reads one aligned 64-B segment per row.  All kernels are integer/byte work bounded by HBM/L2
 // traffic; each is a single streaming pass with the neighbourhood staged in LDS:
-//   k_gray_border   BGR -> gray + frame of level 0                      (1 B in x c, 1 B out per pixel)
-//   k_resize_border level l from level l-1 (fixed-point bilinear) + frame
-//   k_fast_nms      FAST-9/16 score + 3x3 NMS + 31-px border; one 64x16 tile per workgroup; emits one 64-bit
-//                   survivor mask per (row, 64-px column) cell via wave ballot
-//   k_scan_cells    exclusive scan of the cell counts (one workgroup) -> per-cell offsets + per-level starts
-//   k_emit_cells    one thread per cell expands its mask into the canonical (level,row,col) candidate list
-//   k_harris_angle  one WAVE per candidate: 7x7 Harris (49 lanes) + IC angle over the 749-px disc, wave
-//                   shuffle reductions
-//   k_blur          separable 7x7 fixed-point Gaussian through LDS, frame copied unblurred
-//   k_brief         one WAVE per keypoint: 39x48 window staged in LDS, 512 rotated taps, 4 ballots = 256 bits
+//   k_pyramid       every level of a group of up to four levels in ONE launch: a pixel of level l is evaluated by
+//                   walking the bilinear chain down to the group's base (the BGR image, or the last level of the
+//                   previous group) -- 4^depth base samples per pixel, all of them cache hits; no level waits for
+//                   another one, so there is no inter-workgroup dependency and no launch per level
+//   k_fast_nms      FAST-9/16 score + 3x3 NMS + 31-px border; one 64x16 tile per workgroup; one 64-bit survivor mask
+//                   per (row, 64-px column) cell via wave ballot.  The workgroup that finishes LAST (arrival counter)
+//                   scans the cell counts and expands the masks into the canonical (level, row, col) candidate list:
+//                   no scan / emit launches
+//   k_harris_angle  one WAVE per candidate: 7x7 Harris (49 lanes) + IC angle over the 749-px disc, wave shuffle
+//                   reductions; the finished 16-byte record also goes to the pinned host mirror (no copy dispatch)
+//   k_brief         one WAVE per keypoint: the 45x56 raw window is staged in LDS, blurred there (separable 7x7
+//                   fixed-point Gaussian, the keypoint's window only) and sampled: 512 rotated taps, 4 ballots = 256 bits
+//   k_blur          whole-level blur, kept for mvo_debug_get_level(blurred) only
 // Compiled with -ffp-contract=off: the float expressions (Harris response, fastAtan2, tap rotation) are
 // canonical arithmetic and must round exactly like the oracle.
 #include "mvo_internal.h"
 #include "orb_pattern_31.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 
@@ -35,60 +39,87 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return i;
 }
 
-// ------------------------------------------------------------------------------------------------ gray
-// cv::cvtColor(BGR2GRAY) 8-bit: (1868 B + 9617 G + 4899 R + 2^13) >> 14.  One thread = 4 bordered pixels.
-__global__ __launch_bounds__(256) void k_gray_border(const uint8_t* __restrict__ img, int istride, int ch,
-                                                     uint8_t* __restrict__ raw, LevelInfo L) {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int by = blockIdx.y * 4 + threadIdx.y;
+// ------------------------------------------------------------------------------------------------ pyramid
+// Where inter-workgroup results are handed over inside a launch (k_fast_nms' tail, the matcher's merge) the producer
+// stores write-through at agent scope and the consumer loads at agent scope: per-XCD L2s are not coherent.
+__device__ __forceinline__ void st_agent(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint8_t ld_agent(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The base of a level group: the caller's image (gray conversion on the fly) or an already built pyramid level.
+struct PyrBase {
+    const uint8_t* img;  // BGR / BGRA / gray image, or nullptr: the base is raw level `level`
+    int istride, ch;
+    int level;
+};
+
+// Interior pixel (x, y) of level l, D levels above the base.  cv::cvtColor(BGR2GRAY) 8-bit: (1868 B + 9617 G +
+// 4899 R + 2^13) >> 14; cv::resize 8-bit fixed point with the per-geometry coefficient tables -- exact:
+// INTER_LINEAR_EXACT (8-bit coefficients, one rounding), else INTER_LINEAR (11-bit coefficients, OpenCV's truncating
+// vertical pass).  Every level is rounded to 8 bits exactly as if it had been stored, so the value does not depend on
+// how many levels are evaluated in one go.
+template <int D>
+__device__ __forceinline__ int pyr_px(const PyrBase& B, const uint8_t* __restrict__ raw, const PyrInfo& P,
+                                      const ResizeEntry* __restrict__ tabs, int l, int x, int y, int exact) {
+    if constexpr (D == 0) {
+        if (B.img) {
+            const uint8_t* px = B.img + (size_t)y * B.istride + x * B.ch;
+            return B.ch == 1 ? (int)px[0] : (px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14;
+        }
+        const LevelInfo& L = P.lv[l];
+        return raw[L.off + (size_t)(y + MVO_BORDER) * L.stride + MVO_BORDER + x];
+    } else {
+        const LevelInfo& Dl = P.lv[l];
+        const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
+        const ResizeEntry tx = tabs[Dl.tab_off + x], ty = tabs[Dl.tab_off + Dl.w + y];
+        const int sx1 = min(tx.ofs + 1, sw - 1), sy1 = min(ty.ofs + 1, sh - 1);
+        const int p00 = pyr_px<D - 1>(B, raw, P, tabs, l - 1, tx.ofs, ty.ofs, exact);
+        const int p01 = pyr_px<D - 1>(B, raw, P, tabs, l - 1, sx1, ty.ofs, exact);
+        const int p10 = pyr_px<D - 1>(B, raw, P, tabs, l - 1, tx.ofs, sy1, exact);
+        const int p11 = pyr_px<D - 1>(B, raw, P, tabs, l - 1, sx1, sy1, exact);
+        const int h0 = p00 * tx.c0 + p01 * tx.c1, h1 = p10 * tx.c0 + p11 * tx.c1;
+        return exact ? ((ty.c0 * h0 + ty.c1 * h1 + 32768) >> 16) & 0xff
+                     : ((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+    }
+}
+
+// One thread = 4 bordered pixels (one dword) of one level; a workgroup covers 256 px x 4 rows; the levels
+// l0 .. l0 + nl - 1 of the group follow each other in the grid (pblk_off).  The 32-px frame is BORDER_REFLECT_101 of
+// the interior, evaluated through the same chain at the reflected coordinate.
+#define PYR_GROUP 4
+__global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
+                                                 const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
+    int l = l0;
+    for (int k = 1; k < PYR_GROUP; ++k)
+        if (k < nl && (int)blockIdx.x >= P.lv[l0 + k].pblk_off - P.lv[l0].pblk_off) l = l0 + k;
+    const LevelInfo L = P.lv[l];
+    const int b = blockIdx.x - (L.pblk_off - P.lv[l0].pblk_off);
+    const int bx = b % L.pblk_x, by4 = b / L.pblk_x;
+    const int x4 = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int by = by4 * 4 + (threadIdx.x >> 6);
     if (x4 >= L.stride || by >= L.h + 2 * MVO_BORDER) return;
-    const int sy = reflect101(by - MVO_BORDER, L.h);
-    const uint8_t* row = img + (size_t)sy * istride;
+    const int y = reflect101(by - MVO_BORDER, L.h);
+    const int depth = l - B.level;  // workgroup-uniform
     uint32_t out = 0;
-#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        int bx = x4 + k;
+        const int bxk = x4 + k;
         uint32_t g = 0;
-        if (bx < L.w + 2 * MVO_BORDER) {
-            int sx = reflect101(bx - MVO_BORDER, L.w);
-            const uint8_t* px = row + sx * ch;
-            g = ch == 1 ? px[0] : (uint32_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14);
+        if (bxk < L.w + 2 * MVO_BORDER) {
+            const int x = reflect101(bxk - MVO_BORDER, L.w);
+            switch (depth) {
+                case 0: g = (uint32_t)pyr_px<0>(B, raw, P, tabs, l, x, y, exact); break;
+                case 1: g = (uint32_t)pyr_px<1>(B, raw, P, tabs, l, x, y, exact); break;
+                case 2: g = (uint32_t)pyr_px<2>(B, raw, P, tabs, l, x, y, exact); break;
+                case 3: g = (uint32_t)pyr_px<3>(B, raw, P, tabs, l, x, y, exact); break;
+                default: g = (uint32_t)pyr_px<4>(B, raw, P, tabs, l, x, y, exact); break;
+            }
         }
         out |= g << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)by * L.stride + x4) = out;
-}
-
-// ------------------------------------------------------------------------------------------------ resize
-// cv::resize 8-bit fixed point; coefficient tables are built on the host once per geometry.  exact: INTER_LINEAR_EXACT
-// (8-bit coefficients, one rounding), else INTER_LINEAR (11-bit coefficients, OpenCV's truncating vertical pass).
-__global__ __launch_bounds__(256) void k_resize_border(uint8_t* __restrict__ raw, LevelInfo S, LevelInfo D,
-                                                       const ResizeEntry* __restrict__ tabs, int exact) {
-    const int x4 = (blockIdx.x * 64 + threadIdx.x) * 4;
-    const int by = blockIdx.y * 4 + threadIdx.y;
-    if (x4 >= D.stride || by >= D.h + 2 * MVO_BORDER) return;
-    const int dy = reflect101(by - MVO_BORDER, D.h);
-    const ResizeEntry ty = tabs[D.tab_off + D.w + dy];
-    const int sy1 = min(ty.ofs + 1, S.h - 1);
-    const uint8_t* r0 = raw + S.off + (size_t)(ty.ofs + MVO_BORDER) * S.stride + MVO_BORDER;
-    const uint8_t* r1 = raw + S.off + (size_t)(sy1 + MVO_BORDER) * S.stride + MVO_BORDER;
-    uint32_t out = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int bx = x4 + k;
-        uint32_t g = 0;
-        if (bx < D.w + 2 * MVO_BORDER) {
-            int dx = reflect101(bx - MVO_BORDER, D.w);
-            const ResizeEntry tx = tabs[D.tab_off + dx];
-            int sx1 = min(tx.ofs + 1, S.w - 1);
-            int h0 = r0[tx.ofs] * tx.c0 + r0[sx1] * tx.c1;
-            int h1 = r1[tx.ofs] * tx.c0 + r1[sx1] * tx.c1;
-            g = exact ? (uint32_t)((ty.c0 * h0 + ty.c1 * h1 + 32768) >> 16) & 0xff
-                      : (uint32_t)((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
-        }
-        out |= g << (8 * k);
-    }
-    *reinterpret_cast<uint32_t*>(raw + D.off + (size_t)by * D.stride + x4) = out;
 }
 
 // ------------------------------------------------------------------------------------------------ FAST + NMS
@@ -156,12 +187,93 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
     return best > thr ? best - 1 : 0;
 }
 
+// The tail of k_fast_nms, run by the workgroup that arrives last: exclusive scan of the per-cell survivor counts in
+// the canonical order (level, row, 64-px column) and expansion of the ballot masks into the candidate list.  The cell
+// list is cut into FT_CHUNKS equal runs, one per wave; the producers have already summed the survivors of every run
+// (chunk_total), so a wave knows where its run starts and walks it 64 cells at a time -- coalesced mask loads, eight
+// in flight, a shuffle prefix per step.  Everything the other workgroups produced is read at agent scope (they stored
+// it write-through); the FAST score of a candidate is filled in by k_harris_angle.
+#define FT_CHUNKS 4
+__device__ void scan_emit_tail(const u64* __restrict__ cell_mask, int32_t* __restrict__ chunk_total,
+                               DevCandidate* __restrict__ cand, CandHeader* __restrict__ hdr,
+                               CandHeader* __restrict__ hdr_host, const PyrInfo& P, int cand_cap) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = P.n_cells, q = (n + FT_CHUNKS - 1) / FT_CHUNKS;
+    int carry = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < FT_CHUNKS; ++w) {
+        const int v = ld_agent(chunk_total + w);
+        if (w < wave) carry += v;
+        total += v;
+    }
+    const int c_begin = wave * q, c_end = min(n, c_begin + q);
+    for (int cb = c_begin; cb < c_end; cb += 8 * 64) {
+        u64 m[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cb + 64 * k + lane;
+            m[k] = c < c_end ? ld_agent(cell_mask + c) : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = cb + 64 * k + lane;
+            if (cb + 64 * k >= c_end) break;  // wave-uniform
+            const int cnt = __popcll(m[k]);
+            int incl = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            int off = carry + incl - cnt;
+            carry += __shfl(incl, 63);
+            if (c >= c_end) continue;
+            const int lvl = find_level_by(P, c, 1);
+            const LevelInfo& L = P.lv[lvl];
+            if (c == L.cell_off) {
+                hdr->level_start[lvl] = off;
+                hdr_host->level_start[lvl] = off;
+            }
+            const int rc = c - L.cell_off;
+            const int y = rc / L.tiles_x, tx = rc - y * L.tiles_x;
+            u64 mm = m[k];
+            while (mm) {
+                const int bit = __ffsll((long long)mm) - 1;
+                mm &= mm - 1;
+                if (off < cand_cap) {
+                    DevCandidate cd;
+                    cd.x = (int16_t)(tx * FT_W + bit);
+                    cd.y = (int16_t)y;
+                    cd.level_score = lvl << 16;
+                    cd.harris = 0.f;
+                    cd.angle = 0.f;
+                    cand[off] = cd;
+                }
+                ++off;
+            }
+        }
+    }
+    __syncthreads();  // (every wave has read the run totals)
+    if (tid < FT_CHUNKS) st_agent(chunk_total + tid, 0);  // re-armed for the next launch
+    if (tid == 0) {
+        hdr->n_total = total;
+        hdr->level_start[P.nlevels] = total;
+        hdr_host->n_total = total;
+        hdr_host->level_start[P.nlevels] = total;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ raw, uint8_t* __restrict__ score,
-                                                  u64* __restrict__ cell_mask, int32_t* __restrict__ cell_cnt,
-                                                  PyrInfo P, int thr) {
+                                                  u64* __restrict__ cell_mask, PyrInfo P, int thr,
+                                                  int32_t* __restrict__ arrivals,  // [0] tickets, [1 ..] run totals
+                                                  DevCandidate* __restrict__ cand, CandHeader* __restrict__ hdr,
+                                                  CandHeader* __restrict__ hdr_host, int cand_cap) {
     __shared__ uint32_t pix[FT_PH * (FT_PW / 4)];
     __shared__ uint8_t sc[FT_SH * 68];
+    __shared__ int sred[8];
     const int tid = threadIdx.x;
+    if (tid < 8) sred[tid] = 0;  // (ordered before the survivor counting by the staging barriers below)
+    const int chunk_q = (P.n_cells + FT_CHUNKS - 1) / FT_CHUNKS;
     const int lvl = find_level_by(P, blockIdx.x, 0);
     const LevelInfo L = P.lv[lvl];
     const int t = blockIdx.x - L.tile_off;
@@ -201,109 +313,24 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ ra
         if (flag) score[L.off + (size_t)(gy + MVO_BORDER) * L.stride + MVO_BORDER + gx] = (uint8_t)v;
         if (lane == 0 && gy < L.h) {
             int cell = L.cell_off + gy * L.tiles_x + tx;
-            cell_mask[cell] = mask;
-            cell_cnt[cell] = __popcll(mask);
+            st_agent(cell_mask + cell, mask);
+            if (mask) atomicAdd(&sred[cell / chunk_q], __popcll(mask));
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------ scan + emit
-// k_scan_cells: ONE workgroup turns the per-cell survivor counts into exclusive offsets (canonical order = level,
-// row, 64-px column) and fills the header; k_emit_cells: one thread per cell expands its ballot mask.
-__global__ __launch_bounds__(1024) void k_scan_cells(const int32_t* __restrict__ cell_cnt, int32_t* __restrict__ cell_off,
-                                                     CandHeader* __restrict__ hdr, PyrInfo P) {
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = P.n_cells;
-    // every thread owns CH consecutive cells, held in registers (int4 loads / stores); CH*1024 >= n is guaranteed
-    // by the launcher (it picks the instantiation)
-    constexpr int CH = 16;
-    const int passes = (n + CH * 1024 - 1) / (CH * 1024);
-    int carry = 0;
-    for (int ps = 0; ps < passes; ++ps) {
-        const int c0 = (ps * 1024 + tid) * CH;
-        int cnt[CH];
-#pragma unroll
-        for (int k = 0; k < CH; k += 4) {
-            int4 v = make_int4(0, 0, 0, 0);
-            if (c0 + k + 4 <= n) {
-                v = *reinterpret_cast<const int4*>(cell_cnt + c0 + k);
-            } else {
-                if (c0 + k < n) v.x = cell_cnt[c0 + k];
-                if (c0 + k + 1 < n) v.y = cell_cnt[c0 + k + 1];
-                if (c0 + k + 2 < n) v.z = cell_cnt[c0 + k + 2];
-            }
-            cnt[k] = v.x;
-            cnt[k + 1] = v.y;
-            cnt[k + 2] = v.z;
-            cnt[k + 3] = v.w;
-        }
-        int local = 0;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) local += cnt[k];
-        int incl = local;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            int v = __shfl_up(incl, o);
-            if (lane >= o) incl += v;
-        }
-        __syncthreads();
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        int wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            int sv = wsum[w];
-            if (w < wave) wbase += sv;
-            total += sv;
-        }
-        int off = carry + wbase + incl - local;
-#pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            const int c = c0 + k;
-            if (c < n) {
-#pragma unroll
-                for (int l = 0; l < MVO_MAX_LEVELS; ++l)
-                    if (l < P.nlevels && c == P.lv[l].cell_off) hdr->level_start[l] = off;
-                cell_off[c] = off;
-            }
-            off += cnt[k];
-        }
-        carry += total;
-    }
+    __syncthreads();
+    if (tid < FT_CHUNKS && sred[tid])
+        __hip_atomic_fetch_add(arrivals + 1 + tid, sred[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // ---- arrival: the write-through stores above are complete (vmcnt) before this workgroup is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (tid == 0) {
-        hdr->n_total = carry;
-        hdr->level_start[P.nlevels] = carry;
+        const int ticket = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sred[4] = ticket == (int)gridDim.x - 1;
+        if (sred[4]) st_agent(arrivals, 0);  // re-armed for the next launch
     }
-}
-
-__global__ __launch_bounds__(256) void k_emit_cells(const u64* __restrict__ cell_mask, const int32_t* __restrict__ cell_off,
-                                                    const uint8_t* __restrict__ score, DevCandidate* __restrict__ cand,
-                                                    PyrInfo P, int cand_cap) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= P.n_cells) return;
-    u64 m = cell_mask[c];
-    if (!m) return;
-    int off = cell_off[c];
-    const int lvl = find_level_by(P, c, 1);
-    const LevelInfo L = P.lv[lvl];
-    const int rc = c - L.cell_off;
-    const int y = rc / L.tiles_x, tx = rc - y * L.tiles_x;
-    while (m) {
-        const int b = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const int x = tx * FT_W + b;
-        if (off < cand_cap) {
-            DevCandidate cd;
-            cd.x = (int16_t)x;
-            cd.y = (int16_t)y;
-            cd.level_score = (lvl << 16) | score[L.off + (size_t)(y + MVO_BORDER) * L.stride + MVO_BORDER + x];
-            cd.harris = 0.f;
-            cd.angle = 0.f;
-            cand[off] = cd;
-        }
-        ++off;
-    }
+    __syncthreads();
+    if (!sred[4]) return;
+    scan_emit_tail(cell_mask, arrivals + 1, cand, hdr, hdr_host, P, cand_cap);
 }
 
 // ------------------------------------------------------------------------------------------------ Harris + angle
@@ -336,18 +363,22 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ raw,
+                                                      const uint8_t* __restrict__ score,
                                                       DevCandidate* __restrict__ cand,
-                                                      const CandHeader* __restrict__ hdr, PyrInfo P, int cand_cap) {
+                                                      const CandHeader* __restrict__ hdr, PyrInfo P, int cand_cap,
+                                                      DevCandidate* __restrict__ cand_host) {
     const int lane = threadIdx.x & 63;
     const int wave_id = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int nwaves = gridDim.x * 4;
     const int n = min(hdr->n_total, cand_cap);
     const int ndisc = c_disc_n;
     for (int ci = wave_id; ci < n; ci += nwaves) {
-        const DevCandidate cd = cand[ci];
+        DevCandidate cd = cand[ci];
         const LevelInfo L = P.lv[cd.level_score >> 16];
         const int step = L.stride;
-        const uint8_t* ctr = raw + L.off + (size_t)(cd.y + MVO_BORDER) * step + MVO_BORDER + cd.x;
+        const size_t at = L.off + (size_t)(cd.y + MVO_BORDER) * step + MVO_BORDER + cd.x;
+        const uint8_t* ctr = raw + at;
+        cd.level_score |= score[at];  // the FAST score k_fast_nms left at the survivor's pixel
         // HarrisResponses, blockSize 7: lanes 0..48 take one block position each
         int a = 0, b = 0, c = 0;
         if (lane < 49) {
@@ -376,8 +407,11 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
             float scale = 1.f / ((1 << 2) * 7 * 255.f);
             float scale_sq_sq = scale * scale * scale * scale;
             float fa = (float)a, fb = (float)b, fc = (float)c;
-            cand[ci].harris = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
-            cand[ci].angle = fast_atan2_deg((float)m01, (float)m10);
+            DevCandidate out = cd;
+            out.harris = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+            out.angle = fast_atan2_deg((float)m01, (float)m10);
+            cand[ci] = out;
+            cand_host[ci] = out;  // the host selects from this pinned mirror: no device-to-host copy dispatch
         }
     }
 }
@@ -435,28 +469,83 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ raw, u
 }
 
 // ------------------------------------------------------------------------------------------------ rBRIEF
+// cv::ORB::compute blurs every level (GaussianBlur 7x7, sigma 2, over the level ROI: the 32-px frame stays unblurred)
+// and samples the blurred level around each keypoint.  Only the 39-row window around a keypoint is ever sampled, so the
+// wave blurs exactly that window in LDS: raw rows cy-22 .. cy+22 are staged, the horizontal pass keeps 8.8 fixed point
+// (the kernel {18,34,48,56,48,34,18} sums to 256), the vertical pass rounds (+2^15) >> 16 -- the same integers as the
+// whole-level k_blur, without its launch and without the 2 x pyramid bytes of traffic.
 #define BW_R 19
 #define BW_ROWS (2 * BW_R + 1)
 #define BW_STRIDE 48
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blur, const DevDescKp* __restrict__ kps,
-                                               uint8_t* __restrict__ desc, PyrInfo P, int n) {
-    __shared__ uint32_t win[4][BW_ROWS * (BW_STRIDE / 4)];
+#define BW_RAW_ROWS (BW_ROWS + 6)
+#define BW_RAW_DW 14  // 56 bytes per staged row: 4 bytes left of the window, 4 right
+struct BriefLds {
+    uint32_t raw[BW_RAW_ROWS * BW_RAW_DW];
+    uint16_t hb[BW_RAW_ROWS * BW_STRIDE];
+    uint32_t out[BW_ROWS * (BW_STRIDE / 4)];
+};
+__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ rawpyr, const DevDescKp* __restrict__ kps,
+                                               uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host, PyrInfo P,
+                                               int n) {
+    __shared__ BriefLds lds[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ki = blockIdx.x * 4 + wave;
     if (ki >= n) return;
     const DevDescKp kp = kps[ki];
     const LevelInfo L = P.lv[kp.level];
     const int cxb = kp.cx + MVO_BORDER, cyb = kp.cy + MVO_BORDER;  // bordered coordinates
-    const int x0 = (cxb - BW_R) & ~3;
-    const uint8_t* src = blur + L.off + (size_t)(cyb - BW_R) * L.stride + x0;
-    uint32_t* w = win[wave];
-    for (int i = lane; i < BW_ROWS * (BW_STRIDE / 4); i += 64) {
-        int r = i / (BW_STRIDE / 4), c = i - r * (BW_STRIDE / 4);
-        w[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)r * L.stride + 4 * c);
+    const int x0 = (cxb - BW_R) & ~3, y0 = cyb - BW_R;             // window origin (bordered)
+    const int rows = L.h + 2 * MVO_BORDER, dwords = L.stride / 4;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(rawpyr + L.off);
+    BriefLds& W = lds[wave];
+    // clamped reads: a clamped row / dword only ever feeds the taps of frame pixels, which are copied, not blurred
+    for (int i = lane; i < BW_RAW_ROWS * BW_RAW_DW; i += 64) {
+        const int r = i / BW_RAW_DW, c = i - r * BW_RAW_DW;
+        const int yy = min(max(y0 - 3 + r, 0), rows - 1);
+        const int xx = min(max(x0 / 4 - 1 + c, 0), dwords - 1);
+        W.raw[i] = src[(size_t)yy * dwords + xx];
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const uint8_t* wb = reinterpret_cast<const uint8_t*>(w) + BW_R * BW_STRIDE + (cxb - x0);
+    constexpr int G[7] = {18, 34, 48, 56, 48, 34, 18};
+    const uint8_t* rb = reinterpret_cast<const uint8_t*>(W.raw);
+    // horizontal pass: one item = 4 adjacent columns of one staged row
+    for (int i = lane; i < BW_RAW_ROWS * (BW_STRIDE / 4); i += 64) {
+        const int r = i / (BW_STRIDE / 4), c4 = (i - r * (BW_STRIDE / 4)) * 4;
+        const uint8_t* p = rb + r * (BW_RAW_DW * 4) + c4 + 4;  // window column c4 sits 4 bytes into the staged row
+        int px[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) px[k] = p[k - 3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc += G[j] * px[k + j];
+            W.hb[r * BW_STRIDE + c4 + k] = (uint16_t)acc;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // vertical pass + the unblurred frame
+    for (int i = lane; i < BW_ROWS * (BW_STRIDE / 4); i += 64) {
+        const int r = i / (BW_STRIDE / 4), c4 = (i - r * (BW_STRIDE / 4)) * 4;
+        const int gy = y0 + r - MVO_BORDER;
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) acc += G[j] * W.hb[(r + j) * BW_STRIDE + c4 + k];
+            const int gx = x0 + c4 + k - MVO_BORDER;
+            const uint32_t v = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? (uint32_t)((acc + 32768) >> 16)
+                                                                            : (uint32_t)rb[(r + 3) * (BW_RAW_DW * 4) + c4 + k + 4];
+            o |= v << (8 * k);
+        }
+        W.out[i] = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint8_t* wb = reinterpret_cast<const uint8_t*>(W.out) + BW_R * BW_STRIDE + (cxb - x0);
     const float a = kp.a, b = kp.b;
     u64 words[4];
 #pragma unroll
@@ -471,7 +560,10 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ blur,
         int t1 = wb[iy1 * BW_STRIDE + ix1];
         words[k] = __ballot(t0 < t1);
     }
-    if (lane < 4) reinterpret_cast<u64*>(desc + (size_t)ki * 32)[lane] = words[lane];
+    if (lane < 4) {
+        reinterpret_cast<u64*>(desc + (size_t)ki * 32)[lane] = words[lane];
+        if (desc_host) reinterpret_cast<u64*>(desc_host + (size_t)ki * 32)[lane] = words[lane];  // pinned mirror: no copy dispatch
+    }
 }
 
 // ================================================================================================ launchers
@@ -511,60 +603,58 @@ int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int chann
     int r = upload_constant_tables(ctx);
     if (r) return r;
     const PyrInfo& P = ctx->pyr;
-    {
-        const LevelInfo& L = P.lv[0];
-        dim3 blk(64, 4), grd((L.stride / 4 + 63) / 64, (L.h + 2 * MVO_BORDER + 3) / 4);
-        ProfScope ps(ctx, "k_gray_border");
-        hipLaunchKernelGGL(k_gray_border, grd, blk, 0, ctx->stream, d_img, stride, channels, ctx->d_raw, L);
-    }
-    for (int l = 1; l < nlevels; ++l) {
-        const LevelInfo& D = P.lv[l];
-        dim3 blk(64, 4), grd((D.stride / 4 + 63) / 64, (D.h + 2 * MVO_BORDER + 3) / 4);
-        ProfScope ps(ctx, "k_resize_border");
-        hipLaunchKernelGGL(k_resize_border, grd, blk, 0, ctx->stream, ctx->d_raw, P.lv[l - 1], D, ctx->d_tabs, ctx->orb.pyramid_interpolation != 0 ? 1 : 0);
+    const int exact = ctx->orb.pyramid_interpolation != 0 ? 1 : 0;
+    // groups of up to PYR_GROUP levels per launch: the first group hangs off the image, the next ones off the last level
+    // of the group before (the reference's level_pyramid 4 is ONE launch)
+    for (int l0 = 0; l0 < nlevels; l0 += PYR_GROUP) {
+        const int nl = std::min(PYR_GROUP, nlevels - l0);
+        PyrBase B{l0 == 0 ? d_img : nullptr, stride, channels, l0 == 0 ? 0 : l0 - 1};
+        const int nblk = (l0 + nl < P.nlevels ? P.lv[l0 + nl].pblk_off : P.n_pblk) - P.lv[l0].pblk_off;
+        ProfScope ps(ctx, "k_pyramid");
+        hipLaunchKernelGGL(k_pyramid, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
     }
     MVO_HIP(hipGetLastError());
+    ctx->blur_valid = false;
     return MVO_OK;
 }
 
-int orb_launch_detect(mvo_ctx* ctx) {
+// detection: FAST + NMS + candidate list (one launch), Harris + angle (one launch).  The header and the finished
+// candidate records land in the pinned buffer `host` = [CandHeader][DevCandidate x cand_cap].
+int orb_launch_detect(mvo_ctx* ctx, uint8_t* host) {
     const PyrInfo& P = ctx->pyr;
+    CandHeader* hdr_host = reinterpret_cast<CandHeader*>(host);
+    DevCandidate* cand_host = reinterpret_cast<DevCandidate*>(host + sizeof(CandHeader));
     {
         ProfScope ps(ctx, "k_fast_nms");
         hipLaunchKernelGGL(k_fast_nms, dim3(P.n_tiles), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_score,
-                           ctx->d_cell_mask, ctx->d_cell_cnt, P, ctx->orb.fast_threshold);
-    }
-    {
-        ProfScope ps(ctx, "k_scan_cells");
-        hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, ctx->stream, ctx->d_cell_cnt, ctx->d_cell_off, ctx->d_hdr, P);
-    }
-    {
-        ProfScope ps(ctx, "k_emit_cells");
-        hipLaunchKernelGGL(k_emit_cells, dim3((P.n_cells + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_cell_mask,
-                           ctx->d_cell_off, ctx->d_score, ctx->d_cand, P, ctx->cand_cap);
+                           ctx->d_cell_mask, P, ctx->orb.fast_threshold, ctx->d_arrivals, ctx->d_cand, ctx->d_hdr,
+                           hdr_host, ctx->cand_cap);
     }
     {
         ProfScope ps(ctx, "k_harris_angle");
-        hipLaunchKernelGGL(k_harris_angle, dim3(1024), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_cand,
-                           ctx->d_hdr, P, ctx->cand_cap);
+        hipLaunchKernelGGL(k_harris_angle, dim3(1024), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_score, ctx->d_cand,
+                           ctx->d_hdr, P, ctx->cand_cap, cand_host);
     }
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }
 
+// whole-level blur into d_blur: mvo_debug_get_level(blurred) only (the product path blurs inside k_brief)
 int orb_launch_blur(mvo_ctx* ctx, int nlevels) {
     const PyrInfo& P = ctx->pyr;
     int nb = nlevels < P.nlevels ? P.lv[nlevels].btile_off : P.n_btiles;
     ProfScope ps(ctx, "k_blur");
     hipLaunchKernelGGL(k_blur, dim3(nb), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_blur, P, nlevels);
     MVO_HIP(hipGetLastError());
+    ctx->blur_valid = true;
     return MVO_OK;
 }
 
-int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps) {
+int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps, uint8_t* desc_host) {
     if (n <= 0) return MVO_OK;
     ProfScope ps(ctx, "k_brief");
-    hipLaunchKernelGGL(k_brief, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_blur, kps, ctx->d_desc, ctx->pyr, n);
+    hipLaunchKernelGGL(k_brief, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_raw, kps, ctx->d_desc, desc_host,
+                       ctx->pyr, n);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }
