@@ -87,8 +87,8 @@ void mvo_destroy(mvo_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     track_release(ctx);
     ba_pool_release(ctx);
-    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_score, ctx->d_tabs, ctx->d_cell_mask, ctx->d_arrivals,
-                   ctx->d_hdr, ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
+    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_tabs,
+                   ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
                    ctx->d_mout};
     for (void* p : dev)
         if (p) (void)hipFree(p);
@@ -548,6 +548,10 @@ int mvo_debug_set(const char* key, int value) {
         g_ba_wgs = value;
         return MVO_OK;
     }
+    if (key && !std::strcmp(key, "pyr_force_chain")) {
+        g_pyr_force_chain = value;
+        return MVO_OK;
+    }
     if (key && !std::strcmp(key, "pnp_replay_skew")) {
         g_pnp_replay_skew = value;
         return MVO_OK;
@@ -586,13 +590,10 @@ int mvo_debug_get_candidates(mvo_ctx* ctx, void* out, int cap, int* n) {
     if (!ctx || !ctx->pyr_valid || !n) return mvo_set_err(ctx, MVO_ERR_STATE, "no detection cached", hipSuccess);
     MVO_HIP(hipSetDevice(ctx->device));
     MVO_HIP(hipStreamSynchronize(ctx->stream));
-    CandHeader hdr;
-    MVO_HIP(hipMemcpy(&hdr, ctx->d_hdr, sizeof(hdr), hipMemcpyDeviceToHost));
-    *n = hdr.n_total;
+    *n = (int)ctx->last_cand.size();
     if (!out) return MVO_OK;
-    if (hdr.n_total > cap || hdr.n_total > ctx->cand_cap)
-        return mvo_set_err(ctx, MVO_ERR_CAPACITY, "candidate buffer too small", hipSuccess);
-    MVO_HIP(hipMemcpy(out, ctx->d_cand, (size_t)hdr.n_total * sizeof(DevCandidate), hipMemcpyDeviceToHost));
+    if (*n > cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "candidate buffer too small", hipSuccess);
+    std::copy(ctx->last_cand.begin(), ctx->last_cand.end(), static_cast<DevCandidate*>(out));
     return MVO_OK;
 }
 

@@ -26,8 +26,6 @@ struct LevelInfo {
     int btiles_y;
     int btile_off;
     int tab_off;     // offset of this level's resize tables: [x entries w][y entries h]
-    int pblk_x;      // pyramid kernel: workgroups (256 px x 4 rows) per bordered row band
-    int pblk_off;    // first pyramid workgroup of this level in the flattened list
     float scale;     // layerScale[level]
 };
 struct PyrInfo {
@@ -35,7 +33,6 @@ struct PyrInfo {
     int n_cells;
     int n_tiles;
     int n_btiles;
-    int n_pblk;
     LevelInfo lv[MVO_MAX_LEVELS];
 };
 
@@ -57,11 +54,51 @@ struct ResizeEntry {
     int16_t c0, c1;
 };
 
-struct CandHeader {
-    int32_t n_total;
-    int32_t level_start[MVO_MAX_LEVELS + 1];
-    int32_t pad[3];
+// Pyramid kernel (k_pyramid): 64 x 16 output tiles; the source regions of a tile, level by level down to the base of
+// its level group, are staged in LDS.  pyr_regions() is the one statement of that footprint arithmetic: the device
+// uses it per tile, the host uses it to check that every tile of a group fits PYR_LDS_BYTES (otherwise the group runs
+// the per-pixel chain kernel).
+#define PT_W 64
+#define PT_H 16
+#define PYR_LDS_BYTES 32768
+struct PyrRegion {
+    int x0, y0, w, h;  // interior coordinates of its level
 };
+#ifdef __HIPCC__
+#define MVO_HD __host__ __device__
+#else
+#define MVO_HD
+#endif
+// reg[d] (d = 1 .. depth) = region of level l-d needed for the interior box [xlo, xhi] x [ylo, yhi] of level l;
+// off[d] = its byte offset in the LDS pool.  Returns the pool bytes used.
+MVO_HD inline int pyr_regions(const PyrInfo& P, const ResizeEntry* tabs, int l, int depth, int xlo, int xhi, int ylo,
+                              int yhi, PyrRegion* reg, int* off) {
+    int used = 0;
+    for (int d = 1; d <= depth; ++d) {
+        const int m = l - d + 1;  // destination level of this step; the region lives on level m-1
+        const ResizeEntry* tx = tabs + P.lv[m].tab_off;
+        const ResizeEntry* ty = tx + P.lv[m].w;
+        const int sw = P.lv[m - 1].w, sh = P.lv[m - 1].h;
+        const int x0 = tx[xlo].ofs, x1 = tx[xhi].ofs + 1 < sw - 1 ? tx[xhi].ofs + 1 : sw - 1;
+        const int y0 = ty[ylo].ofs, y1 = ty[yhi].ofs + 1 < sh - 1 ? ty[yhi].ofs + 1 : sh - 1;
+        reg[d].x0 = x0;
+        reg[d].y0 = y0;
+        reg[d].w = x1 - x0 + 1;
+        reg[d].h = y1 - y0 + 1;
+        off[d] = used;
+        used += (reg[d].w * reg[d].h + 15) & ~15;
+        xlo = x0, xhi = x1, ylo = y0, yhi = y1;
+    }
+    return used;
+}
+
+// k_fast_harris output: every 64 x 16 tile owns FT_TILE_CAP record slots (3x3 NMS leaves at most one survivor per
+// 2 x 2 pixels: 256 per tile) and one count, in pinned host memory
+#define FT_TILE_CAP 256
+inline size_t orb_detect_counts_bytes(int n_tiles) { return ((size_t)n_tiles * 4 + 63) / 64 * 64; }
+inline size_t orb_detect_host_bytes(int n_tiles) {
+    return orb_detect_counts_bytes(n_tiles) + (size_t)n_tiles * FT_TILE_CAP * sizeof(DevCandidate);
+}
 
 // tracking rows (track_kernels.hip / track_host.cpp)
 struct TrackCamera {
@@ -91,17 +128,14 @@ struct mvo_ctx {
     PyrInfo pyr{};
     std::vector<int> quota;
     bool pyr_valid = false, blur_valid = false;
+    bool pyr_group_tiled[MVO_MAX_LEVELS] = {false};  // per level group: every tile's regions fit the LDS pool
     int pyr_levels_built = 0;
     uint8_t* d_img = nullptr;
     size_t d_img_cap = 0;
-    uint8_t *d_raw = nullptr, *d_blur = nullptr, *d_score = nullptr;
+    uint8_t *d_raw = nullptr, *d_blur = nullptr;
     size_t pyr_bytes = 0;
     ResizeEntry* d_tabs = nullptr;
-    unsigned long long* d_cell_mask = nullptr;
-    int32_t* d_arrivals = nullptr;  // k_fast_nms: [0] arrival tickets, [1 ..] survivors per cell run (self re-arming)
-    CandHeader* d_hdr = nullptr;
-    DevCandidate* d_cand = nullptr;
-    int cand_cap = 0;
+    std::vector<DevCandidate> last_cand;  // canonical candidate list of the last detection (debug getter)
     DevDescKp* d_kp = nullptr;
     uint8_t* d_desc = nullptr;      // descriptors of the current extraction (one of the two halves below)
     uint8_t* d_desc_buf = nullptr;  // 2 x kp_cap x 32: ping-pong so that frame i-1 survives frame i
@@ -182,6 +216,7 @@ int track_launch_em_hypotheses(mvo_ctx* ctx, const double* d_q1, const double* d
                                int n_hyp, float thr2, double* d_E, int32_t* d_nm, int32_t* d_counts);
 int track_launch_em_mask(mvo_ctx* ctx, const double* d_q1, const double* d_q2, int n, const double* d_E, float thr2,
                          uint8_t* d_mask);
+extern int g_pyr_force_chain;  // test hook (orb_kernels.hip)
 extern int g_pnp_replay_skew;  // test hook: the device replays the RANSAC loop with a wrong confidence
 // track_host.cpp
 void track_release(mvo_ctx* ctx);

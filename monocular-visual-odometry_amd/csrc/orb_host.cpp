@@ -122,7 +122,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     PyrInfo P{};
     P.nlevels = p.nlevels;
     size_t off = 256, tab = 0;
-    int cells = 0, tiles = 0, btiles = 0, pblk = 0;
+    int cells = 0, tiles = 0, btiles = 0;
     for (int l = 0; l < p.nlevels; ++l) {
         LevelInfo& L = P.lv[l];
         L.scale = layer_scale(p, l);
@@ -144,43 +144,53 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
         btiles += L.btiles_x * L.btiles_y;
         L.tab_off = (int)tab;
         tab += L.w + L.h;
-        L.pblk_x = (L.stride / 4 + 63) / 64;
-        L.pblk_off = pblk;
-        pblk += L.pblk_x * ((L.h + 2 * MVO_BORDER + 3) / 4);
     }
-    P.n_pblk = pblk;
     P.n_cells = cells;
     P.n_tiles = tiles;
     P.n_btiles = btiles;
     const size_t bytes = off + 4096;
     free_dev(ctx->d_raw);
     free_dev(ctx->d_blur);
-    free_dev(ctx->d_score);
     free_dev(ctx->d_tabs);
-    free_dev(ctx->d_cell_mask);
-    free_dev(ctx->d_arrivals);
     MVO_HIP(hipMalloc((void**)&ctx->d_raw, bytes));
     MVO_HIP(hipMalloc((void**)&ctx->d_blur, bytes));
-    MVO_HIP(hipMalloc((void**)&ctx->d_score, bytes));
     MVO_HIP(hipMemsetAsync(ctx->d_raw, 0, bytes, ctx->stream));
     MVO_HIP(hipMemsetAsync(ctx->d_blur, 0, bytes, ctx->stream));
-    MVO_HIP(hipMemsetAsync(ctx->d_score, 0, bytes, ctx->stream));
     MVO_HIP(hipMalloc((void**)&ctx->d_tabs, tab * sizeof(ResizeEntry)));
-    MVO_HIP(hipMalloc((void**)&ctx->d_cell_mask, (size_t)cells * 8));
-    MVO_HIP(hipMalloc((void**)&ctx->d_arrivals, 64));
-    MVO_HIP(hipMemsetAsync(ctx->d_arrivals, 0, 64, ctx->stream));
     std::vector<ResizeEntry> tabs(tab);
     for (int l = 1; l < p.nlevels; ++l) {
         fill_resize_tab(&tabs[P.lv[l].tab_off], P.lv[l - 1].w, P.lv[l].w, ctx->orb.pyramid_interpolation != 0);
         fill_resize_tab(&tabs[P.lv[l].tab_off + P.lv[l].w], P.lv[l - 1].h, P.lv[l].h, ctx->orb.pyramid_interpolation != 0);
     }
     MVO_HIP(hipMemcpy(ctx->d_tabs, tabs.data(), tab * sizeof(ResizeEntry), hipMemcpyHostToDevice));
-    if (!ctx->d_hdr) {
-        ctx->cand_cap = 1 << 16;
-        void* blk = nullptr;
-        MVO_HIP(hipMalloc(&blk, sizeof(CandHeader) + (size_t)ctx->cand_cap * sizeof(DevCandidate)));
-        ctx->d_hdr = (CandHeader*)blk;
-        ctx->d_cand = (DevCandidate*)((char*)blk + sizeof(CandHeader));
+    // which level groups can run the LDS-tiled pyramid kernel: every tile's source regions must fit its LDS pool
+    auto reflect = [](int i, int n) {
+        if (n == 1) return 0;
+        while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+        return i;
+    };
+    for (int l0 = 0; l0 < p.nlevels; l0 += 4) {
+        bool fits = true;
+        const int base = l0 == 0 ? 0 : l0 - 1;
+        for (int l = std::max(l0, 1); l < std::min(l0 + 4, p.nlevels) && fits; ++l) {
+            const LevelInfo& L = P.lv[l];
+            for (int ty = 0; ty < L.btiles_y && fits; ++ty)
+                for (int tx = 0; tx < L.btiles_x && fits; ++tx) {
+                    int xlo = 1 << 30, xhi = -1, ylo = 1 << 30, yhi = -1;
+                    for (int i = 0; i < PT_W; ++i) {
+                        const int x = reflect(std::min(tx * PT_W + i, L.w + 2 * MVO_BORDER - 1) - MVO_BORDER, L.w);
+                        xlo = std::min(xlo, x), xhi = std::max(xhi, x);
+                    }
+                    for (int i = 0; i < PT_H; ++i) {
+                        const int y = reflect(std::min(ty * PT_H + i, L.h + 2 * MVO_BORDER - 1) - MVO_BORDER, L.h);
+                        ylo = std::min(ylo, y), yhi = std::max(yhi, y);
+                    }
+                    PyrRegion reg[8];
+                    int off[8];
+                    fits = pyr_regions(P, tabs.data(), l, l - base, xlo, xhi, ylo, yhi, reg, off) <= PYR_LDS_BYTES;
+                }
+        }
+        ctx->pyr_group_tiled[l0 / 4] = fits;
     }
     ctx->pyr = P;
     ctx->pyr_bytes = bytes;
@@ -242,19 +252,48 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     const PyrInfo& P = ctx->pyr;
     ctx->pyr_valid = ctx->blur_valid = false;
     if ((r = orb_launch_pyramid(ctx, d_img, stride, channels, P.nlevels))) return r;
-    // the kernels deliver the header and the finished candidate records into the pinned buffer themselves
-    if ((r = mvo_ensure_pinned(ctx, sizeof(CandHeader) + (size_t)ctx->cand_cap * sizeof(DevCandidate)))) return r;
+    // the kernel delivers per-tile survivor counts and finished records into the pinned buffer itself
+    if ((r = mvo_ensure_pinned(ctx, orb_detect_host_bytes(P.n_tiles)))) return r;
     if ((r = orb_launch_detect(ctx, ctx->h_pin))) return r;
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
     MVO_HIP(hipEventSynchronize(ctx->ev));
-    const CandHeader* hdr = (const CandHeader*)ctx->h_pin;
-    const int n_total = hdr->n_total;
-    if (n_total > ctx->cand_cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "candidate buffer overflow", hipSuccess);
-    const DevCandidate* cand = (const DevCandidate*)(ctx->h_pin + sizeof(CandHeader));
+    // canonical order (level, row, column) = the order cv::FAST emits: inside a tile row the tiles interleave line by
+    // line; every tile's slot is row-major already, so one cursor per tile column restores it
+    const int32_t* counts = (const int32_t*)ctx->h_pin;
+    const DevCandidate* slots = (const DevCandidate*)(ctx->h_pin + orb_detect_counts_bytes(P.n_tiles));
+    std::vector<DevCandidate>& all = ctx->last_cand;
+    all.clear();
+    int level_start[MVO_MAX_LEVELS + 1] = {0};
+    int cursor[512];
+    for (int l = 0; l < P.nlevels; ++l) {
+        const LevelInfo& L = P.lv[l];
+        level_start[l] = (int)all.size();
+        if (L.tiles_x > 512) return mvo_set_err(ctx, MVO_ERR_INVALID, "image too wide", hipSuccess);
+        for (int ty = 0; ty < L.tiles_y; ++ty) {
+            const int t0 = L.tile_off + ty * L.tiles_x;
+            int left = 0;
+            for (int tx = 0; tx < L.tiles_x; ++tx) {
+                cursor[tx] = 0;
+                left += counts[t0 + tx];
+            }
+            for (int y = ty * 16; left > 0 && y < ty * 16 + 16; ++y)
+                for (int tx = 0; tx < L.tiles_x; ++tx) {
+                    const DevCandidate* sl = slots + (size_t)(t0 + tx) * FT_TILE_CAP;
+                    const int cnt = counts[t0 + tx];
+                    int& c = cursor[tx];
+                    while (c < cnt && sl[c].y == y) {
+                        all.push_back(sl[c++]);
+                        --left;
+                    }
+                }
+        }
+    }
+    level_start[P.nlevels] = (int)all.size();
+    const DevCandidate* cand = all.data();
     out.clear();
     std::vector<DevCandidate> lv;
     for (int l = 0; l < P.nlevels; ++l) {
-        lv.assign(cand + hdr->level_start[l], cand + hdr->level_start[l + 1]);
+        lv.assign(cand + level_start[l], cand + level_start[l + 1]);
         // FAST score first (keep 2x), then Harris (cv::ORB computeKeyPoints)
         retain_best(lv, 2 * ctx->quota[l], [](const DevCandidate& a) { return (float)(a.level_score & 0xffff); });
         retain_best(lv, ctx->quota[l], [](const DevCandidate& a) { return a.harris; });

@@ -40,15 +40,6 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 // ------------------------------------------------------------------------------------------------ pyramid
-// Where inter-workgroup results are handed over inside a launch (k_fast_nms' tail, the matcher's merge) the producer
-// stores write-through at agent scope and the consumer loads at agent scope: per-XCD L2s are not coherent.
-__device__ __forceinline__ void st_agent(int32_t* p, int32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int32_t ld_agent(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u64 ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ uint8_t ld_agent(const uint8_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // The base of a level group: the caller's image (gray conversion on the fly) or an already built pyramid level.
 struct PyrBase {
     const uint8_t* img;  // BGR / BGRA / gray image, or nullptr: the base is raw level `level`
@@ -86,21 +77,21 @@ __device__ __forceinline__ int pyr_px(const PyrBase& B, const uint8_t* __restric
     }
 }
 
-// One thread = 4 bordered pixels (one dword) of one level; a workgroup covers 256 px x 4 rows; the levels
-// l0 .. l0 + nl - 1 of the group follow each other in the grid (pblk_off).  The 32-px frame is BORDER_REFLECT_101 of
-// the interior, evaluated through the same chain at the reflected coordinate.
+// Fallback form (k_pyramid_chain): one thread = 4 bordered pixels (one dword) of one level, every pixel walks the whole
+// chain itself (4^depth base samples).  Used when a level group's source regions do not fit the LDS budget of the
+// tiled kernel below (scale factors far above the reference's 1.2) and by the tests as a second implementation.
 #define PYR_GROUP 4
-__global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
-                                                 const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
+__global__ __launch_bounds__(256) void k_pyramid_chain(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
+                                                       const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
     int l = l0;
     for (int k = 1; k < PYR_GROUP; ++k)
-        if (k < nl && (int)blockIdx.x >= P.lv[l0 + k].pblk_off - P.lv[l0].pblk_off) l = l0 + k;
+        if (k < nl && (int)blockIdx.x >= P.lv[l0 + k].btile_off - P.lv[l0].btile_off) l = l0 + k;
     const LevelInfo L = P.lv[l];
-    const int b = blockIdx.x - (L.pblk_off - P.lv[l0].pblk_off);
-    const int bx = b % L.pblk_x, by4 = b / L.pblk_x;
-    const int x4 = (bx * 64 + (threadIdx.x & 63)) * 4;
-    const int by = by4 * 4 + (threadIdx.x >> 6);
-    if (x4 >= L.stride || by >= L.h + 2 * MVO_BORDER) return;
+    const int b = blockIdx.x - (L.btile_off - P.lv[l0].btile_off);
+    const int tx = b % L.btiles_x, ty = b / L.btiles_x;
+    const int x4 = tx * PT_W + (threadIdx.x & 15) * 4;
+    const int by = ty * PT_H + (threadIdx.x >> 4);
+    if (by >= L.h + 2 * MVO_BORDER) return;
     const int y = reflect101(by - MVO_BORDER, L.h);
     const int depth = l - B.level;  // workgroup-uniform
     uint32_t out = 0;
@@ -120,6 +111,111 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
         out |= g << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)by * L.stride + x4) = out;
+}
+
+// k_pyramid: one workgroup = one 64 x 16 tile (bordered coordinates) of one level of the group.  The tile's interior
+// footprint (after BORDER_REFLECT_101) is traced down the bilinear chain to the base: the base region is converted /
+// fetched ONCE into LDS, every intermediate level's region is built in LDS from the one below, and the tile is written
+// from the region of level l-1.  A level-3 tile re-derives ~10 base-level pixels per output instead of 64 and never
+// touches global memory in between; no workgroup depends on another one.
+__device__ __forceinline__ int pyr_sample(const uint8_t* __restrict__ S, const PyrRegion& R, int sw, int sh,
+                                          const ResizeEntry tx, const ResizeEntry ty, int exact) {
+    const int sx1 = min(tx.ofs + 1, sw - 1), sy1 = min(ty.ofs + 1, sh - 1);
+    const uint8_t* r0 = S + (ty.ofs - R.y0) * R.w - R.x0;
+    const uint8_t* r1 = S + (sy1 - R.y0) * R.w - R.x0;
+    const int h0 = r0[tx.ofs] * tx.c0 + r0[sx1] * tx.c1, h1 = r1[tx.ofs] * tx.c0 + r1[sx1] * tx.c1;
+    return exact ? ((ty.c0 * h0 + ty.c1 * h1 + 32768) >> 16) & 0xff
+                 : ((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+}
+
+__global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
+                                                 const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
+    __shared__ uint8_t lds[PYR_LDS_BYTES];
+    __shared__ int sbox[4];
+    const int tid = threadIdx.x;
+    int l = l0;
+    for (int k = 1; k < PYR_GROUP; ++k)
+        if (k < nl && (int)blockIdx.x >= P.lv[l0 + k].btile_off - P.lv[l0].btile_off) l = l0 + k;
+    const LevelInfo L = P.lv[l];
+    const int b = blockIdx.x - (L.btile_off - P.lv[l0].btile_off);
+    const int tx = b % L.btiles_x, ty = b / L.btiles_x;
+    const int bx0 = tx * PT_W, by0 = ty * PT_H;
+    const int bw = L.w + 2 * MVO_BORDER, bh = L.h + 2 * MVO_BORDER;
+    const int depth = l - B.level;  // workgroup-uniform
+    const int ox4 = bx0 + (tid & 15) * 4, oy = by0 + (tid >> 4);  // this thread's output dword
+    if (depth == 0) {  // level 0 straight from the image
+        if (oy >= bh) return;
+        const int y = reflect101(oy - MVO_BORDER, L.h);
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ox4 + k < bw) out |= (uint32_t)pyr_px<0>(B, raw, P, tabs, l, reflect101(ox4 + k - MVO_BORDER, L.w), y, exact) << (8 * k);
+        *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)oy * L.stride + ox4) = out;
+        return;
+    }
+    // ---- interior footprint of the tile: bounding box of the reflected coordinates
+    if (tid < 64) {
+        const int x = reflect101(min(bx0 + tid, bw - 1) - MVO_BORDER, L.w);
+        int lo = x, hi = x;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (tid == 0) sbox[0] = lo, sbox[1] = hi;
+    } else if (tid < 128) {
+        const int y = reflect101(min(by0 + min(tid - 64, PT_H - 1), bh - 1) - MVO_BORDER, L.h);
+        int lo = y, hi = y;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (tid == 64) sbox[2] = lo, sbox[3] = hi;
+    }
+    __syncthreads();
+    // ---- the regions of the levels l-1 .. l-depth (same arithmetic as the host's LDS check, pyr_regions())
+    __shared__ PyrRegion reg[PYR_GROUP + 1];
+    __shared__ int regoff[PYR_GROUP + 1];
+    if (tid == 0) pyr_regions(P, tabs, l, depth, sbox[0], sbox[1], sbox[2], sbox[3], reg, regoff);
+    __syncthreads();
+    // ---- base region
+    {
+        const PyrRegion R = reg[depth];
+        uint8_t* dst = lds + regoff[depth];
+        for (int i = tid; i < R.w * R.h; i += 256) {
+            const int ry = i / R.w, rx = i - ry * R.w;
+            dst[i] = (uint8_t)pyr_px<0>(B, raw, P, tabs, B.level, R.x0 + rx, R.y0 + ry, exact);
+        }
+    }
+    __syncthreads();
+    // ---- intermediate levels, bottom-up: the region of level l-d from the region of level l-d-1
+    for (int d = depth - 1; d >= 1; --d) {
+        const int m = l - d;  // level being produced
+        const PyrRegion R = reg[d], S = reg[d + 1];
+        const uint8_t* src = lds + regoff[d + 1];
+        uint8_t* dst = lds + regoff[d];
+        const int sw = P.lv[m - 1].w, sh = P.lv[m - 1].h, toff = P.lv[m].tab_off, mw = P.lv[m].w;
+        for (int i = tid; i < R.w * R.h; i += 256) {
+            const int ry = i / R.w, rx = i - ry * R.w;
+            dst[i] = (uint8_t)pyr_sample(src, S, sw, sh, tabs[toff + R.x0 + rx], tabs[toff + mw + R.y0 + ry], exact);
+        }
+        __syncthreads();
+    }
+    // ---- the tile itself, frame included
+    if (oy >= bh) return;
+    {
+        const PyrRegion S = reg[1];
+        const uint8_t* src = lds + regoff[1];
+        const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
+        const ResizeEntry tyE = tabs[L.tab_off + L.w + reflect101(oy - MVO_BORDER, L.h)];
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ox4 + k < bw)
+                out |= (uint32_t)pyr_sample(src, S, sw, sh, tabs[L.tab_off + reflect101(ox4 + k - MVO_BORDER, L.w)], tyE, exact) << (8 * k);
+        *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)oy * L.stride + ox4) = out;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ FAST + NMS
@@ -187,93 +283,51 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
     return best > thr ? best - 1 : 0;
 }
 
-// The tail of k_fast_nms, run by the workgroup that arrives last: exclusive scan of the per-cell survivor counts in
-// the canonical order (level, row, 64-px column) and expansion of the ballot masks into the candidate list.  The cell
-// list is cut into FT_CHUNKS equal runs, one per wave; the producers have already summed the survivors of every run
-// (chunk_total), so a wave knows where its run starts and walks it 64 cells at a time -- coalesced mask loads, eight
-// in flight, a shuffle prefix per step.  Everything the other workgroups produced is read at agent scope (they stored
-// it write-through); the FAST score of a candidate is filled in by k_harris_angle.
-#define FT_CHUNKS 4
-__device__ void scan_emit_tail(const u64* __restrict__ cell_mask, int32_t* __restrict__ chunk_total,
-                               DevCandidate* __restrict__ cand, CandHeader* __restrict__ hdr,
-                               CandHeader* __restrict__ hdr_host, const PyrInfo& P, int cand_cap) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = P.n_cells, q = (n + FT_CHUNKS - 1) / FT_CHUNKS;
-    int carry = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < FT_CHUNKS; ++w) {
-        const int v = ld_agent(chunk_total + w);
-        if (w < wave) carry += v;
-        total += v;
+// cv::fastAtan2 (degrees)
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
+    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
+    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
+    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
     }
-    const int c_begin = wave * q, c_end = min(n, c_begin + q);
-    for (int cb = c_begin; cb < c_end; cb += 8 * 64) {
-        u64 m[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = cb + 64 * k + lane;
-            m[k] = c < c_end ? ld_agent(cell_mask + c) : 0ull;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = cb + 64 * k + lane;
-            if (cb + 64 * k >= c_end) break;  // wave-uniform
-            const int cnt = __popcll(m[k]);
-            int incl = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int v = __shfl_up(incl, o);
-                if (lane >= o) incl += v;
-            }
-            int off = carry + incl - cnt;
-            carry += __shfl(incl, 63);
-            if (c >= c_end) continue;
-            const int lvl = find_level_by(P, c, 1);
-            const LevelInfo& L = P.lv[lvl];
-            if (c == L.cell_off) {
-                hdr->level_start[lvl] = off;
-                hdr_host->level_start[lvl] = off;
-            }
-            const int rc = c - L.cell_off;
-            const int y = rc / L.tiles_x, tx = rc - y * L.tiles_x;
-            u64 mm = m[k];
-            while (mm) {
-                const int bit = __ffsll((long long)mm) - 1;
-                mm &= mm - 1;
-                if (off < cand_cap) {
-                    DevCandidate cd;
-                    cd.x = (int16_t)(tx * FT_W + bit);
-                    cd.y = (int16_t)y;
-                    cd.level_score = lvl << 16;
-                    cd.harris = 0.f;
-                    cd.angle = 0.f;
-                    cand[off] = cd;
-                }
-                ++off;
-            }
-        }
-    }
-    __syncthreads();  // (every wave has read the run totals)
-    if (tid < FT_CHUNKS) st_agent(chunk_total + tid, 0);  // re-armed for the next launch
-    if (tid == 0) {
-        hdr->n_total = total;
-        hdr->level_start[P.nlevels] = total;
-        hdr_host->n_total = total;
-        hdr_host->level_start[P.nlevels] = total;
-    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
 }
 
-__global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ raw, uint8_t* __restrict__ score,
-                                                  u64* __restrict__ cell_mask, PyrInfo P, int thr,
-                                                  int32_t* __restrict__ arrivals,  // [0] tickets, [1 ..] run totals
-                                                  DevCandidate* __restrict__ cand, CandHeader* __restrict__ hdr,
-                                                  CandHeader* __restrict__ hdr_host, int cand_cap) {
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// k_fast_harris: one 64 x 16 tile per workgroup, everything cv::ORB::detect computes per corner in ONE launch:
+//   1. FAST-9/16 score of the tile + 1-px ring (LDS), 3x3 non-maximum suppression, 31-px image border: one 64-bit
+//      survivor mask per tile row via wave ballot;
+//   2. the tile's survivors, row-major (= the order cv::FAST emits inside the tile), one WAVE per survivor round-robin:
+//      7x7 Harris response (49 lanes, Sobel sums) and the intensity-centroid angle over the 749-px disc, wave shuffle
+//      reductions -- the same integer sums and float expressions as the stand-alone form had;
+//   3. the finished 16-byte records go straight into the tile's slot of the pinned host buffer, the count beside them.
+// No candidate list is compacted on the device: the global order (level, row, column) interleaves the tiles of a tile
+// row line by line, which the host restores while it copies the ~10^4 records out of the slots (orb_host.cpp) -- a
+// device-wide scan would need a second launch or a serial single-workgroup tail (tried: 40-100 us of exposed latency).
+__global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__ raw, PyrInfo P, int thr,
+                                                     int32_t* __restrict__ tile_count, DevCandidate* __restrict__ slots) {
     __shared__ uint32_t pix[FT_PH * (FT_PW / 4)];
     __shared__ uint8_t sc[FT_SH * 68];
-    __shared__ int sred[8];
+    __shared__ u64 rowmask[FT_H];
+    __shared__ int rowstart[FT_H + 1];
     const int tid = threadIdx.x;
-    if (tid < 8) sred[tid] = 0;  // (ordered before the survivor counting by the staging barriers below)
-    const int chunk_q = (P.n_cells + FT_CHUNKS - 1) / FT_CHUNKS;
     const int lvl = find_level_by(P, blockIdx.x, 0);
     const LevelInfo L = P.lv[lvl];
     const int t = blockIdx.x - L.tile_off;
@@ -309,81 +363,46 @@ __global__ __launch_bounds__(256) void k_fast_nms(const uint8_t* __restrict__ ra
         bool flag = v > 0 && v > s[-1] && v > s[1] && v > s[-69] && v > s[-68] && v > s[-67] && v > s[67] &&
                     v > s[68] && v > s[69];
         flag = flag && gx >= 31 && gx < L.w - 31 && gy >= 31 && gy < L.h - 31;
-        u64 mask = __ballot(flag);
-        if (flag) score[L.off + (size_t)(gy + MVO_BORDER) * L.stride + MVO_BORDER + gx] = (uint8_t)v;
-        if (lane == 0 && gy < L.h) {
-            int cell = L.cell_off + gy * L.tiles_x + tx;
-            st_agent(cell_mask + cell, mask);
-            if (mask) atomicAdd(&sred[cell / chunk_q], __popcll(mask));
+        const u64 mask = __ballot(flag);
+        if (lane == 0) rowmask[ly] = mask;
+    }
+    __syncthreads();
+    if (tid < 64) {  // exclusive scan of the 16 row counts
+        const int cnt = tid < FT_H ? (int)__popcll(rowmask[tid]) : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < FT_H; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (tid < FT_H) rowstart[tid] = inc - cnt;
+        if (tid == FT_H - 1) {
+            rowstart[FT_H] = inc;
+            tile_count[blockIdx.x] = inc;
         }
     }
     __syncthreads();
-    if (tid < FT_CHUNKS && sred[tid])
-        __hip_atomic_fetch_add(arrivals + 1 + tid, sred[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // ---- arrival: the write-through stores above are complete (vmcnt) before this workgroup is counted
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sred[4] = ticket == (int)gridDim.x - 1;
-        if (sred[4]) st_agent(arrivals, 0);  // re-armed for the next launch
-    }
-    __syncthreads();
-    if (!sred[4]) return;
-    scan_emit_tail(cell_mask, arrivals + 1, cand, hdr, hdr_host, P, cand_cap);
-}
-
-// ------------------------------------------------------------------------------------------------ Harris + angle
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-// cv::fastAtan2 (degrees)
-__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
-    const float p1 = 0.9997878412794807f * (float)(180 / M_PI);
-    const float p3 = -0.3258083974640975f * (float)(180 / M_PI);
-    const float p5 = 0.1555786518463281f * (float)(180 / M_PI);
-    const float p7 = -0.04432655554792128f * (float)(180 / M_PI);
-    float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
-    if (x < 0) a = 180.f - a;
-    if (y < 0) a = 360.f - a;
-    return a;
-}
-
-__global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict__ raw,
-                                                      const uint8_t* __restrict__ score,
-                                                      DevCandidate* __restrict__ cand,
-                                                      const CandHeader* __restrict__ hdr, PyrInfo P, int cand_cap,
-                                                      DevCandidate* __restrict__ cand_host) {
-    const int lane = threadIdx.x & 63;
-    const int wave_id = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int nwaves = gridDim.x * 4;
-    const int n = min(hdr->n_total, cand_cap);
+    const int total = rowstart[FT_H];
+    DevCandidate* out = slots + (size_t)blockIdx.x * FT_TILE_CAP;
+    const int step = L.stride;
     const int ndisc = c_disc_n;
-    for (int ci = wave_id; ci < n; ci += nwaves) {
-        DevCandidate cd = cand[ci];
-        const LevelInfo L = P.lv[cd.level_score >> 16];
-        const int step = L.stride;
-        const size_t at = L.off + (size_t)(cd.y + MVO_BORDER) * step + MVO_BORDER + cd.x;
-        const uint8_t* ctr = raw + at;
-        cd.level_score |= score[at];  // the FAST score k_fast_nms left at the survivor's pixel
+    for (int i = wave; i < total; i += 4) {
+        // survivor i -> (row, i-th set bit of the row's mask)
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k < FT_H; ++k)
+            if (i >= rowstart[k]) r = k;
+        const u64 m = rowmask[r];
+        const int kth = i - rowstart[r];
+        const bool me = ((m >> lane) & 1) && (int)__popcll(m & ((1ull << lane) - 1)) == kth;
+        const int lx = __ffsll((long long)__ballot(me)) - 1;
+        const int gx = x0 + lx, gy = y0 + r;
+        const uint8_t* ctr = base + (size_t)(gy + MVO_BORDER) * step + MVO_BORDER + gx;
         // HarrisResponses, blockSize 7: lanes 0..48 take one block position each
         int a = 0, b = 0, c = 0;
         if (lane < 49) {
-            int i = lane / 7 - 3, j = lane % 7 - 3;
-            const uint8_t* p = ctr + i * step + j;
+            int bi = lane / 7 - 3, bj = lane % 7 - 3;
+            const uint8_t* p = ctr + bi * step + bj;
             int Ix = ((int)p[1] - p[-1]) * 2 + ((int)p[-step + 1] - p[-step - 1]) + ((int)p[step + 1] - p[step - 1]);
             int Iy = ((int)p[step] - p[-step]) * 2 + ((int)p[step - 1] - p[-step - 1]) + ((int)p[step + 1] - p[-step + 1]);
             a = Ix * Ix;
@@ -407,11 +426,13 @@ __global__ __launch_bounds__(256) void k_harris_angle(const uint8_t* __restrict_
             float scale = 1.f / ((1 << 2) * 7 * 255.f);
             float scale_sq_sq = scale * scale * scale * scale;
             float fa = (float)a, fb = (float)b, fc = (float)c;
-            DevCandidate out = cd;
-            out.harris = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
-            out.angle = fast_atan2_deg((float)m01, (float)m10);
-            cand[ci] = out;
-            cand_host[ci] = out;  // the host selects from this pinned mirror: no device-to-host copy dispatch
+            DevCandidate cd;
+            cd.x = (int16_t)gx;
+            cd.y = (int16_t)gy;
+            cd.level_score = (lvl << 16) | sc[(r + 1) * 68 + (lx + 1)];
+            cd.harris = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
+            cd.angle = fast_atan2_deg((float)m01, (float)m10);
+            out[i] = cd;
         }
     }
 }
@@ -492,7 +513,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ rawpy
     const int ki = blockIdx.x * 4 + wave;
     if (ki >= n) return;
     const DevDescKp kp = kps[ki];
-    const LevelInfo L = P.lv[kp.level];
+    const LevelInfo L = P.lv[__builtin_amdgcn_readfirstlane(kp.level)];  // (wave-uniform: scalar loads)
     const int cxb = kp.cx + MVO_BORDER, cyb = kp.cy + MVO_BORDER;  // bordered coordinates
     const int x0 = (cxb - BW_R) & ~3, y0 = cyb - BW_R;             // window origin (bordered)
     const int rows = L.h + 2 * MVO_BORDER, dwords = L.stride / 4;
@@ -568,6 +589,7 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ rawpy
 
 // ================================================================================================ launchers
 static bool g_tables_ready[16] = {false};
+int g_pyr_force_chain = 0;  // test hook: the per-pixel chain kernel instead of the LDS-tiled one
 
 static int upload_constant_tables(mvo_ctx* ctx) {
     if (ctx->device < 16 && g_tables_ready[ctx->device]) return MVO_OK;
@@ -609,32 +631,28 @@ int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int chann
     for (int l0 = 0; l0 < nlevels; l0 += PYR_GROUP) {
         const int nl = std::min(PYR_GROUP, nlevels - l0);
         PyrBase B{l0 == 0 ? d_img : nullptr, stride, channels, l0 == 0 ? 0 : l0 - 1};
-        const int nblk = (l0 + nl < P.nlevels ? P.lv[l0 + nl].pblk_off : P.n_pblk) - P.lv[l0].pblk_off;
-        ProfScope ps(ctx, "k_pyramid");
-        hipLaunchKernelGGL(k_pyramid, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
+        const int nblk = (l0 + nl < P.nlevels ? P.lv[l0 + nl].btile_off : P.n_btiles) - P.lv[l0].btile_off;
+        const bool tiled = ctx->pyr_group_tiled[l0 / PYR_GROUP] && !g_pyr_force_chain;
+        ProfScope ps(ctx, tiled ? "k_pyramid" : "k_pyramid_chain");
+        if (tiled)
+            hipLaunchKernelGGL(k_pyramid, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
+        else
+            hipLaunchKernelGGL(k_pyramid_chain, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
     }
     MVO_HIP(hipGetLastError());
     ctx->blur_valid = false;
     return MVO_OK;
 }
 
-// detection: FAST + NMS + candidate list (one launch), Harris + angle (one launch).  The header and the finished
-// candidate records land in the pinned buffer `host` = [CandHeader][DevCandidate x cand_cap].
+// detection: FAST + NMS + Harris + angle in one launch; per-tile survivor counts and records land in the pinned buffer
+// `host` = [int32 count x n_tiles (padded to 64 B)][DevCandidate x n_tiles x FT_TILE_CAP]
 int orb_launch_detect(mvo_ctx* ctx, uint8_t* host) {
     const PyrInfo& P = ctx->pyr;
-    CandHeader* hdr_host = reinterpret_cast<CandHeader*>(host);
-    DevCandidate* cand_host = reinterpret_cast<DevCandidate*>(host + sizeof(CandHeader));
-    {
-        ProfScope ps(ctx, "k_fast_nms");
-        hipLaunchKernelGGL(k_fast_nms, dim3(P.n_tiles), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_score,
-                           ctx->d_cell_mask, P, ctx->orb.fast_threshold, ctx->d_arrivals, ctx->d_cand, ctx->d_hdr,
-                           hdr_host, ctx->cand_cap);
-    }
-    {
-        ProfScope ps(ctx, "k_harris_angle");
-        hipLaunchKernelGGL(k_harris_angle, dim3(1024), dim3(256), 0, ctx->stream, ctx->d_raw, ctx->d_score, ctx->d_cand,
-                           ctx->d_hdr, P, ctx->cand_cap, cand_host);
-    }
+    int32_t* counts = reinterpret_cast<int32_t*>(host);
+    DevCandidate* slots = reinterpret_cast<DevCandidate*>(host + orb_detect_counts_bytes(P.n_tiles));
+    ProfScope ps(ctx, "k_fast_harris");
+    hipLaunchKernelGGL(k_fast_harris, dim3(P.n_tiles), dim3(256), 0, ctx->stream, ctx->d_raw, P, ctx->orb.fast_threshold,
+                       counts, slots);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

@@ -48,6 +48,24 @@ def test_pyramid_blur_candidates_bit_exact(mvo, O, ctx, w, h, ch):
     _cand_cmp(mvo, ctx.debug_candidates(), O.candidates(img, p))
 
 
+@pytest.mark.parametrize("nlevels,sf", [(4, 1.2), (8, 1.2), (3, 2.0)])
+def test_both_pyramid_kernels_bit_exact(mvo, O, ctx, nlevels, sf):
+    """The LDS-tiled pyramid kernel and the per-pixel chain kernel (the fallback for level groups whose source regions
+    do not fit the LDS pool) are two implementations of the same integers: both equal the oracle's levels, on a
+    gray and on a BGR image, also for the second level group (levels 4-7 hang off level 3)."""
+    for ch, seed in ((3, 5), (1, 6)):
+        img = mvo.synth.small_test_image(seed, 333, 251, channels=ch)
+        p = _cfg(mvo, O, ctx, nlevels=nlevels, scale_factor=sf, max_keypoints=2000, nfeatures=3000)
+        for force in (0, 1):
+            mvo.debug_set("pyr_force_chain", force)
+            try:
+                ctx.calc_keypoints(img, cap=8192)
+                for l in range(p.nlevels):
+                    assert np.array_equal(ctx.debug_level(l, False), O.pyramid_level(img, p, l, False)), (ch, force, l)
+            finally:
+                mvo.debug_set("pyr_force_chain", 0)
+
+
 def test_legacy_inter_linear_pyramid_bit_exact(mvo, O, ctx):
     """pyramid_interpolation = 0: cv::INTER_LINEAR as cv::ORB of OpenCV < 3.4 resampled (11-bit coefficients, truncating
     vertical pass) -- the other flavour of the oracle; every level, the candidates and the descriptors follow."""
