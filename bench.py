@@ -90,7 +90,8 @@ class FrameLoopCfg(C.Structure):  # host/driver/frame_loop.cpp: struct frame_loo
 class FrameLoopState(C.Structure):
     _fields_ = [("frame_no", C.c_int32), ("n_kp", C.c_int32), ("n_match", C.c_int32), ("n_inliers", C.c_int32),
                 ("n_tri", C.c_int32), ("ba_trials", C.c_int64), ("ba_iterations", C.c_int64), ("ba_solves", C.c_int64),
-                ("ba_edges", C.c_int64)]
+                ("ba_edges", C.c_int64), ("ns_extract", C.c_int64), ("ns_restore", C.c_int64), ("ns_build", C.c_int64),
+                ("ns_begin", C.c_int64), ("ns_end", C.c_int64)]
 
 
 _frame_loop = None
@@ -427,6 +428,14 @@ def main(argv=None, env=None):
             dt = timed_run([one], nsingle, env.sync)
             secondary["single_sequence_fps"] = nsingle / dt
             secondary["single_sequence_note"] = "1 shard, extraction+matching of frame i+1 overlapped with the BA of frame i (2 ctx)"
+            st1 = one.state()
+            nf = max(1, st1.frame_no)
+            secondary["single_sequence_host_us_per_frame"] = {
+                k: round(getattr(st1, "ns_" + k) / nf / 1e3, 1) for k in ("extract", "restore", "build", "begin", "end")}
+            secondary["single_sequence_host_note"] = ("wall-clock of the loop's stages: extract = extract+match call (runs "
+                "between begin and end, i.e. during the solve), restore = bench scaffolding that puts the window's Frame/MapPoint "
+                "objects back to their initial state, build = buildBundleAdjustmentWindow marshalling, begin = flatten + plan + "
+                "upload + submit, end = wait for the solve + scatter into the objects")
             one_serial = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", False, frames=frames0, pool=s0.pool)
             one_serial.run(max(5, args.warmup))
             dt = timed_run([one_serial], nsingle, env.sync)

@@ -153,7 +153,8 @@ void BaService::run() {
                 const auto now = std::chrono::steady_clock::now();
                 for (auto it = seen.begin(); it != seen.end();)
                     it = (now - it->second > std::chrono::milliseconds(10)) ? seen.erase(it) : std::next(it);
-                const size_t want = std::min<size_t>(BA_MAX_BATCH, seen.size());
+                const size_t fit = (size_t)std::max(1, cus / std::max(1, q.front()->ws->plan.G));  // windows per grid
+                const size_t want = std::min<size_t>(std::min<size_t>(BA_MAX_BATCH, fit), seen.size());
                 if (q.size() < want)
                     cv_work.wait_for(lk, std::chrono::microseconds(250), [&] { return q.size() >= want; });
             }
@@ -181,7 +182,10 @@ void BaService::run() {
             maxG = std::max(maxG, ws->plan.G);
             lds = std::max(lds, ws->plan.lds);
         }
-        b.stride = maxG <= 32 && cus >= 256 ? BA_MAX_BATCH : nj;
+        // window = block % stride: with the dispatcher's round-robin (block b on XCD b % 8) a stride of 8 or 16 keeps
+        // every window's workgroups on ONE XCD (a window of > 32 workgroups does not fit an XCD's 32 CUs anyway)
+        b.stride = cus >= 256 && maxG <= 16 ? 16 : (cus >= 256 && maxG <= 32 ? 8 : nj);
+        if (b.stride < nj) b.stride = nj;
         b.use_mfma = jobs[0]->use_mfma;
         b.same_l2_ok = g_ba_same_l2;
         (void)hipEventRecord(e0, stream);

@@ -26,7 +26,7 @@ typedef unsigned long long ba_u64;
 //                                  so that one-lane-per-edge / per-landmark accesses spread over the LDS banks
 #define BA_LDS_BUDGET (157 * 1024)  // dynamic part; the static part (descriptor, flags: < 1.5 KB) comes on top (160 KB per CU)
 #define BA_MAX_WGS 256
-#define BA_MAX_BATCH 8              // windows per launch (8 x 32 workgroups = one workgroup per CU)
+#define BA_MAX_BATCH 16             // windows per launch (8 x 32 or 16 x 16 workgroups = one workgroup per CU)
 #define BA_NPHASE 16
 #define BA_TRACE_MAX 512            // LM trials recorded per solve (50 iterations x at most 10 trials)
 #define BA_HP 28                    // packed lower triangle of the 7 x 7 pose block [H_pp | -b_p; . | e^T e]

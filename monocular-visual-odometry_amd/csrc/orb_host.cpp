@@ -276,6 +276,14 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
                 cursor[tx] = 0;
                 left += counts[t0 + tx];
             }
+            // the slots are 4 KB apart and freshly written by the device: pull the next tile row's lines in while this
+            // one is merged (the hardware prefetcher cannot follow the slot pattern)
+            if (ty + 1 < L.tiles_y)
+                for (int tx = 0; tx < L.tiles_x; ++tx) {
+                    const char* base = (const char*)(slots + (size_t)(t0 + L.tiles_x + tx) * FT_TILE_CAP);
+                    for (int b = 0, nb = counts[t0 + L.tiles_x + tx] * (int)sizeof(DevCandidate); b < nb; b += 64)
+                        __builtin_prefetch(base + b);
+                }
             for (int y = ty * 16; left > 0 && y < ty * 16 + 16; ++y)
                 for (int tx = 0; tx < L.tiles_x; ++tx) {
                     const DevCandidate* sl = slots + (size_t)(t0 + tx) * FT_TILE_CAP;

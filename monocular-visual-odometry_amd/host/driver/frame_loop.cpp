@@ -13,6 +13,7 @@
 // frame i (ctx_ba): both are independent of each other, the results are the same as in the serial order.
 // Built into host/driver/libmvo_frame_loop.so; links only libmvo_hip.so.
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -50,11 +51,20 @@ struct frame_loop_state {  // progress counters, read back by the caller
     int32_t frame_no;
     int32_t n_kp, n_match, n_inliers, n_tri;
     int64_t ba_trials, ba_iterations, ba_solves, ba_edges;
+    // host wall-clock per stage, nanoseconds, accumulated: extract+match call, window restore (bench scaffolding),
+    // window marshalling (buildBundleAdjustmentWindow), job.begin (flatten + plan + upload + submit), job.end (wait for
+    // the solve + scatter); in pipeline mode the extraction of frame i+1 sits between begin and end
+    int64_t ns_extract, ns_restore, ns_build, ns_begin, ns_end;
 };
 
 }  // extern "C"
 
 namespace {
+
+using Clock = std::chrono::steady_clock;
+inline int64_t ns_since(Clock::time_point t0) {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t0).count();
+}
 
 // One BA window as the reference holds it: frames_buff_ (vo.h:64) with keypoints_, inliers_to_mappt_connections_ and
 // T_w_c_, a Map with the MapPoints, plus the initial state to restore before every solve.
@@ -209,9 +219,14 @@ int frame_loop_run(void* h, int steps, double* traj) {
                 n = L.next_n;
                 nm = L.next_match;
                 L.have_next = false;
-            } else if ((r = extract_and_match(L, st.frame_no, &d_desc, &n, &nm))) {
-                status = r;
-                break;
+            } else {
+                const auto t0 = Clock::now();
+                r = extract_and_match(L, st.frame_no, &d_desc, &n, &nm);
+                st.ns_extract += ns_since(t0);
+                if (r) {
+                    status = r;
+                    break;
+                }
             }
             st.n_kp = n;
             st.n_match = nm;
@@ -255,20 +270,31 @@ int frame_loop_run(void* h, int steps, double* traj) {
                     }
                     st.ba_edges += w0.E;
                 } else {
+                    auto t0 = Clock::now();
                     restore(w);  // the state this window had when it was "new"
+                    st.ns_restore += ns_since(t0);
                     // VisualOdometry::callBundleAdjustment_ (vo.cpp:384-478) in two halves
+                    t0 = Clock::now();
                     L.pending = vo::buildBundleAdjustmentWindow(w.frames_buff, w.map, w.F);
+                    st.ns_build += ns_since(t0);
+                    t0 = Clock::now();
                     L.job.begin(L.pending.v_pts_2d, L.pending.v_pts_2d_to_3d_idx, L.K, L.pending.um_pts_3d_in_prev_frames,
                                 L.pending.v_camera_poses, L.info, c.fix_points != 0, c.fix_points == 0);
+                    st.ns_begin += ns_since(t0);
                     if (c.pipeline && s + 1 < steps) {  // run ahead: features of the next frame while the window is solved
-                        if ((r = extract_and_match(L, st.frame_no + 1, &L.next_desc, &L.next_n, &L.next_match))) {
+                        t0 = Clock::now();
+                        r = extract_and_match(L, st.frame_no + 1, &L.next_desc, &L.next_n, &L.next_match);
+                        st.ns_extract += ns_since(t0);
+                        if (r) {
                             L.job.end();
                             status = r;
                             break;
                         }
                         L.have_next = true;
                     }
+                    t0 = Clock::now();
                     L.job.end();
+                    st.ns_end += ns_since(t0);
                     bs = L.job.last;
                     Tnew = &w.frames_buff.back()->T_w_c_;
                     st.ba_edges += w.E;

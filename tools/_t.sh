@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -8
-bash tools/_dbg.sh
+timeout 200 python bench.py --steps 50 --warmup 5 --streams 1 --no-cpu-baseline 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['secondary'])"
