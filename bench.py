@@ -350,6 +350,8 @@ def run_benchmark(args, env):
     shards[0].ctx.ba_launch_stats(reset=True)
     elapsed_local = timed_run(shards, args.steps, barrier)
     launch = shards[0].ctx.ba_launch_stats()
+    launch["service_ms"] = shards[0].ctx.ba_service_times()
+    launch["elapsed_ms"] = elapsed_local * 1e3
     st_after = [s.state() for s in shards]
     elapsed = max_over_ranks(dist, elapsed_local, env.device)
     frames_total = world * args.streams * args.steps
@@ -387,7 +389,8 @@ def main(argv=None, env=None):
             roof.update(kernel="k_ba_lm", avg_launch_ms=avg_ms, launches=launch["launches"],
                         windows_per_launch=launch["windows"] / max(launch["launches"], 1),
                         algorithmic_per_launch=flops / max(launch["launches"], 1),
-                        trials_per_solve=trials / max(solves, 1))
+                        trials_per_solve=trials / max(solves, 1), launch_thread_ms=launch.get("service_ms"),
+                        timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2))
             tr = pmc_traffic("k_ba_lm")
             # HBM-side bytes per launch from the rocprofv3 PMC passes of this workload; the hand-offs are 8-byte accesses, a
             # width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported uncorrected

@@ -230,6 +230,9 @@ int mvo_invert_pose(const double* T, double* T_inv);
 /* BA launches issued on `device` by this process since the last reset: number of launches, windows solved by them,
  * and the sum of the launch durations (HIP events on the launch stream, milliseconds). */
 int mvo_ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset);
+/* Wall-clock (ms, since the last reset of mvo_ba_launch_stats) the launch thread spent: [0] waiting for work, [1] waiting
+ * for a full batch, [2] building + issuing launches, [3] waiting for the kernels, [4] publishing results. */
+int mvo_debug_ba_service_times(int device, double* out5);
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per
  * kernel name until reset. */
 int mvo_profile_enable(mvo_ctx* ctx, int on);

@@ -453,6 +453,12 @@ class Context:
         self.lib.mvo_ba_launch_stats(self.device, C.byref(a), C.byref(b), C.byref(ms), int(reset))
         return dict(launches=a.value, windows=b.value, ms=ms.value)
 
+    def ba_service_times(self):
+        """Wall-clock of the BA launch thread's stages since the last stats reset (ms)."""
+        t = (C.c_double * 5)()
+        self.lib.mvo_debug_ba_service_times(self.device, t)
+        return dict(zip(("wait_for_work", "wait_for_batch", "issue", "wait_for_kernel", "publish"), [round(v, 3) for v in t]))
+
     def debug_ba_phases(self):
         arr = (C.c_longlong * 16)()
         g = C.c_int()

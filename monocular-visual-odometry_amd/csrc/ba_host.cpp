@@ -125,6 +125,7 @@ struct BaService {
     // statistics (mvo_ba_launch_stats)
     long long launches = 0, windows = 0;
     double ms = 0;
+    double t_idle = 0, t_batch = 0, t_launch = 0, t_sync = 0, t_post = 0;  // wall-clock of the loop's stages, ms
     void run();
 };
 // heap-allocated and never destroyed: the detached launch threads wait on these condition variables until the
@@ -142,13 +143,23 @@ void BaService::run() {
     (void)ba_kernel_set_lds_limit();
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
-    // (Queuing a second launch behind the running one was tried: it splits batches and lowered the frame rate.)
+    // (Queuing a second launch behind the running one was tried twice, the second time only for FULL batches with 24
+    // clients: back-to-back solver launches own every CU -- 2 waves x 256 VGPRs per SIMD, ~150 KB LDS -- and the extraction
+    // kernels of the other clients only run in the gaps between them; closing the gaps starved the clients and lowered the
+    // frame rate from ~2800 to ~2600.)
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&tp](double& acc) {
+        const auto now = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double, std::milli>(now - tp).count();
+        tp = now;
+    };
     for (;;) {
         BaJob* jobs[BA_MAX_BATCH];
         int nj = 0;
         {
             std::unique_lock<std::mutex> lk(m);
             cv_work.wait(lk, [&] { return !q.empty(); });
+            lap(t_idle);
             {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
                 const auto now = std::chrono::steady_clock::now();
                 for (auto it = seen.begin(); it != seen.end();)
@@ -170,6 +181,7 @@ void BaService::run() {
                 q.pop_front();
             }
         }
+        lap(t_batch);
         BaBatch b{};
         b.nwin = nj;
         int maxG = 1;
@@ -191,7 +203,9 @@ void BaService::run() {
         (void)hipEventRecord(e0, stream);
         hipError_t le = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, ba_solver_class(jobs[0]->ws->plan.n));
         (void)hipEventRecord(e1, stream);
+        lap(t_launch);
         hipError_t se = hipStreamSynchronize(stream);
+        lap(t_sync);
         float t = 0;
         if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&t, e0, e1);
         else (void)hipGetLastError();
@@ -208,6 +222,7 @@ void BaService::run() {
             }
         }
         cv_done.notify_all();
+        lap(t_post);
     }
 }
 BaService& service_for(int device) {
@@ -718,6 +733,19 @@ int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg
         for (int i = 0; i <= ws->plan.G && i < cap; ++i) wg_pt[i] = ws->plan.wg_pt[i];
     return MVO_OK;
 }
+// wall-clock of the launch thread's stages since the last reset: waiting for work, waiting for a full batch, building +
+// issuing the launch, waiting for the kernel, publishing the results (ms)
+void ba_service_times(int device, double* out5) {
+    for (int i = 0; i < 5; ++i) out5[i] = 0;
+    BaService* sp;
+    {
+        std::lock_guard<std::mutex> lk(*g_service_start);
+        sp = g_service[device & 15];
+    }
+    if (!sp) return;
+    std::lock_guard<std::mutex> lk(sp->m);
+    out5[0] = sp->t_idle, out5[1] = sp->t_batch, out5[2] = sp->t_launch, out5[3] = sp->t_sync, out5[4] = sp->t_post;
+}
 void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
     if (launches) *launches = 0;
     if (windows) *windows = 0;
@@ -736,5 +764,6 @@ void ba_launch_stats(int device, long long* launches, long long* windows, double
     if (reset) {
         s.launches = s.windows = 0;
         s.ms = 0;
+        s.t_idle = s.t_batch = s.t_launch = s.t_sync = s.t_post = 0;
     }
 }

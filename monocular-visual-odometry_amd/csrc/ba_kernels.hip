@@ -1018,14 +1018,15 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                         const double* A = W.M + BA_MSTRIDE * el;
                         const double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4], c5 = cc[5];
                         const double x0 = X[0], x1 = X[1], x2 = X[2], x3 = X[3], x4 = X[4], x5 = X[5];
-                        const double Y[6] = {x0 * c0 + x1 * c1 + x2 * c3, x1 * c2 + x2 * c4, x2 * c5,
-                                             x3 * c0 + x4 * c1 + x5 * c3, x4 * c2 + x5 * c4, x5 * c5};
                         double a0[6], a1[6];
 #pragma unroll
                         for (int c = 0; c < 6; ++c) {
                             a0[c] = A[c];
                             a1[c] = A[7 + c];
                         }
+                        __builtin_amdgcn_sched_barrier(0);  // (all 24 operands in flight before the first use)
+                        const double Y[6] = {x0 * c0 + x1 * c1 + x2 * c3, x1 * c2 + x2 * c4, x2 * c5,
+                                             x3 * c0 + x4 * c1 + x5 * c3, x4 * c2 + x5 * c4, x5 * c5};
 #pragma unroll
                         for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -1155,9 +1156,19 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     __syncthreads();
                     STAMP(8);
                     for (int el = tid; el < sln; el += BA_THREADS) {
+                        // sum over the workgroups in order; the operands are fetched eight at a time (left to the
+                        // compiler every add waits for its own LDS read: 32 round trips)
                         double sum = 0;
-#pragma unroll 8
-                        for (int w = 0; w < G; ++w) sum += W.SL[w * sln + el];
+                        int w = 0;
+                        for (; w + 8 <= G; w += 8) {
+                            double t8[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) t8[k] = W.SL[(w + k) * sln + el];
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) sum += t8[k];
+                        }
+                        for (; w < G; ++w) sum += W.SL[w * sln + el];
                         gstore_d(B.xR + 2 * (size_t)(sl0 + el), tag0 + tagA, sum, same_l2);
                     }
                     STAMP(9);
@@ -1332,8 +1343,19 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 if (sFlag[2]) error = 1;
                 tempChi = 0;
                 scale = 0;
-#pragma unroll 8
-                for (int w = 0; w < G; ++w) {
+                int w = 0;
+                for (; w + 8 <= G; w += 8) {  // (operands fetched eight pairs at a time, summed in workgroup order)
+                    double t8[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) t8[k] = sX[2 * w + k];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        tempChi += t8[2 * k];
+                        scale += t8[2 * k + 1];
+                    }
+                }
+                for (; w < G; ++w) {
                     tempChi += sX[2 * w];
                     scale += sX[2 * w + 1];
                 }

@@ -477,6 +477,12 @@ void mvo_ba_release(mvo_ctx* ctx, mvo_ba_handle* handle) {
     }
     ba_release_device(ctx, handle);
 }
+int mvo_debug_ba_service_times(int device, double* out5) {
+    if (!out5) return MVO_ERR_INVALID;
+    ba_service_times(device, out5);
+    return MVO_OK;
+}
+
 int mvo_ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
     if (device < 0 || device > 15) return MVO_ERR_INVALID;
     ba_launch_stats(device, launches, windows, ms, reset);
