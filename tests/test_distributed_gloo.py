@@ -40,6 +40,7 @@ WORKER = textwrap.dedent("""
     import time, types
     class StubCtx:
         def ba_launch_stats(self, reset=False): return dict(launches=1, windows=1, ms=1.0)
+        def ba_service_times(self): return {}
         def synchronize(self): pass
     class StubShard:
         def __init__(self, sid):
