@@ -280,24 +280,31 @@ def algorithmic_work(args):
     P = sum(a * b for a, b in lv)
     return {
         "k_pyramid": ("hbm", w * h * 3 + P),                           # BGR in, every level out (frames excluded)
-        "k_fast_nms": ("hbm", P + 8 * 12400 + 16 * 8000),              # levels in, cell masks + candidate list out
-        "k_harris_angle": ("hbm", (81 + 749) * 8000),
+        "k_fast_harris": ("hbm", P + (81 + 749) * 8000 + 16 * 8000),   # levels in, Harris/IC windows in, records out
         "k_brief": ("hbm", (45 * 56 + 32 + 16) * K),                   # raw window in, descriptor out
         "k_knn2": ("valu", 16.0 * K * K),
     }
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/r*_pmc_*.csv:
-    separate --pmc FETCH_SIZE / WRITE_SIZE passes; columns kernel, fetch_kb, write_kb per dispatch).  None if absent."""
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
+    (profiles/r*_pmc_fetch_write_size_per_kernel.csv, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes; columns located by the header line).  None if absent."""
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_size_per_kernel.csv"))):
         try:
+            cols = None
             for line in open(path):
+                if line.startswith("#"):
+                    continue
                 f = [x.strip().strip('"') for x in line.split(",")]
-                if len(f) >= 3 and f[0].startswith(kernel):
-                    best = ((float(f[1]) + float(f[2])) * 1024.0, os.path.relpath(path, ROOT))
-        except (OSError, ValueError):
+                if cols is None:
+                    cols = {name: i for i, name in enumerate(f)}
+                    continue
+                if f[0].startswith(kernel):
+                    kb = float(f[cols["FETCH_SIZE_KB_avg"]]) + float(f[cols["WRITE_SIZE_KB_avg"]])
+                    best = (kb * 1024.0, os.path.relpath(path, ROOT))
+        except (OSError, ValueError, KeyError, IndexError):
             pass
     return best
 
@@ -392,19 +399,26 @@ def main(argv=None, env=None):
                         trials_per_solve=trials / max(solves, 1), launch_thread_ms=launch.get("service_ms"),
                         timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2))
             tr = pmc_traffic("k_ba_lm")
-            # HBM-side bytes per launch from the rocprofv3 PMC passes of this workload; the hand-offs are 8-byte accesses, a
-            # width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported uncorrected
+            # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command (tools/collect_evidence.sh); the
+            # hand-offs are 8-byte accesses, a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported
+            # uncorrected
             roof["traffic"], roof["traffic_source"] = (tr[0], tr[1]) if tr else (None, None)
             per_kernel["k_ba_lm"] = launch["ms"] / max(args.steps * args.streams, 1)
         else:
             roof = None
-        # ---- per-kernel durations of the other kernels: HIP events on the ctx stream of one shard (mvo_profile_*)
-        s0.ctx.profile_enable(True)
-        s0.ctx.profile_reset()
+        # ---- per-kernel durations of the other kernels: HIP events on the ctx stream of ONE shard running the serial loop
+        # with nothing else on the GPU (next to a running solver launch a kernel's blocks wait for its CUs -- 2 waves x
+        # 256 VGPRs per SIMD -- and the events would show the wait, not the kernel)
+        kshard = env.make_shard(shard_ids(rank, args.streams)[0], args, args.ba_mode, False,
+                                frames=(s0.host_frames, s0.dev_frames), pool=s0.pool)
+        kshard.run(3)
+        kshard.ctx.profile_enable(True)
+        kshard.ctx.profile_reset()
         nprof = min(20, max(args.steps, 5))
-        s0.run(nprof)
-        prof = s0.ctx.profile_get()
-        s0.ctx.profile_enable(False)
+        kshard.run(nprof)
+        prof = kshard.ctx.profile_get()
+        kshard.ctx.profile_enable(False)
+        kshard.close()
         work = algorithmic_work(args)
         kern = {}
         for k, (n_, ms) in prof.items():

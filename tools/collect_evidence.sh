@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round evidence on the GPU box: rocprofv3 kernel stats, PMC passes (each in its own run, --kernel-trace only), bench JSON
+# lines.  Usage: bash tools/collect_evidence.sh <round tag, e.g. r02>; results under gpurun_out/<tag>/ (copy the
+# summaries into profiles/).
+set -u
+TAG=${1:-rXX}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+ONE="python bench.py --steps 10 --warmup 2 --streams 1 --pipeline 0 --no-cpu-baseline --no-secondary"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -o bench -- python bench.py --no-cpu-baseline --no-secondary > $OUT/prof_default.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_streams1 -o bench -- python bench.py --steps 40 --warmup 5 --streams 1 --pipeline 0 --no-cpu-baseline --no-secondary > $OUT/prof_streams1.log 2>&1
+timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- $ONE > $OUT/pmc_fetch.log 2>&1
+timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- $ONE > $OUT/pmc_write.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- $ONE > $OUT/pmc_mfma.log 2>&1
+python tools/pmc_summary.py fetch_write $OUT/pmc_fetch/bench_counter_collection.csv $OUT/pmc_write/bench_counter_collection.csv $OUT/pmc_streams1_fetch_write_size.csv "$ONE"
+# the same two passes on the DEFAULT command (24 shards: the solver launches hold ~8 windows): what bench.py's
+# roofline.traffic reads
+DEF="python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-secondary"
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_default -o bench -- $DEF > $OUT/pmc_fetch_default.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_default -o bench -- $DEF > $OUT/pmc_write_default.log 2>&1
+python tools/pmc_summary.py fetch_write $OUT/pmc_fetch_default/bench_counter_collection.csv $OUT/pmc_write_default/bench_counter_collection.csv $OUT/pmc_fetch_write_size_per_kernel.csv "$DEF"
+python tools/pmc_summary.py table $OUT/pmc_mfma/bench_counter_collection.csv $OUT/pmc_mfma_busy.txt "$ONE"
+timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 200 python bench.py --track --no-cpu-baseline --no-secondary > $OUT/bench_track.json 2> $OUT/bench_track.err
+timeout 200 python bench.py --width 1242 --height 375 --max-kp 4000 --ba-poses 10 --ba-points 4000 --streams 4 --steps 30 --warmup 3 --no-cpu-baseline --no-secondary > $OUT/bench_config4.json 2> $OUT/bench_config4.err
+ls -la $OUT | head -30
+cat $OUT/pmc_fetch_write_size_per_kernel.csv $OUT/pmc_streams1_fetch_write_size.csv $OUT/pmc_mfma_busy.txt
+tail -c 600 $OUT/bench_default.json
