@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <thread>
 
 #include "my_slam/geometry/feature_match.h"
 #include "my_slam/optimization/g2o_ba.h"
@@ -57,6 +58,28 @@ int main(int argc, char** argv) {
         if (k2.size() != f0->keypoints_.size() || memcmp(d2.data, f0->descriptors_.data, k2.size() * 32)) {
             fprintf(stderr, "free functions disagree with Frame methods\n");
             return 3;
+        }
+        // ---- a second host thread has its own ctx (hot_path_ctx() is thread_local): the Config parameters must be
+        // latched into THAT ctx as well -- with a process-wide latch it would extract with the built-in defaults
+        // (1500 keypoints instead of the configured 1000) and silently differ from the reference
+        {
+            vector<cv::KeyPoint> kt;
+            cv::Mat dt;
+            std::string err;
+            std::thread th([&] {
+                try {
+                    geometry::calcKeyPoints(f0->rgb_img_, kt);
+                    geometry::calcDescriptors(f0->rgb_img_, kt, dt);
+                } catch (const std::exception& e) {
+                    err = e.what();
+                }
+            });
+            th.join();
+            if (!err.empty() || kt.size() != f0->keypoints_.size() || kt.size() > 1001 ||
+                memcmp(dt.data, f0->descriptors_.data, kt.size() * 32)) {
+                fprintf(stderr, "second host thread: %zu keypoints vs %zu (%s)\n", kt.size(), f0->keypoints_.size(), err.c_str());
+                return 7;
+            }
         }
         // ---- vo_addFrame.cpp:42-46: matchFeatures with each method
         for (int method = 1; method <= 3; ++method) {
