@@ -5,10 +5,37 @@
 // reference's selectUniformKptsByGrid (src/geometry/feature_match.cpp:51-84) is first-come, so the *set* of
 // surviving keypoints depends on libstdc++'s element order; <= 10^4 items, ~0.1 ms.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "mvo_internal.h"
+
+// MVO_HOST_TIMING=1: per-stage wall clock of the host half (printed every 200 frames to stderr; development aid)
+struct HostTimes {
+    double acc[8] = {0};
+    long n = 0;
+    std::chrono::steady_clock::time_point t;
+    bool on = std::getenv("MVO_HOST_TIMING") != nullptr;
+    void start() {
+        if (on) t = std::chrono::steady_clock::now();
+    }
+    void lap(int k) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+    }
+    void frame(const char* const* names, int cnt) {
+        if (!on || ++n % 200) return;
+        std::fprintf(stderr, "[mvo host us/frame]");
+        for (int k = 0; k < cnt; ++k) std::fprintf(stderr, " %s %.1f", names[k], acc[k] / 200), acc[k] = 0;
+        std::fprintf(stderr, "\n");
+    }
+};
+static thread_local HostTimes g_ht_detect, g_ht_describe;
 
 namespace {
 
@@ -247,6 +274,8 @@ int orb_grid_select(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int image_rows
 // cv::ORB::detect on an image already in device memory; leaves the raw pyramid cached in the ctx.
 int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int channels,
                       std::vector<mvo_keypoint>& out) {
+    HostTimes& ht = g_ht_detect;
+    ht.start();
     int r = orb_setup_geometry(ctx, w, h);
     if (r) return r;
     const PyrInfo& P = ctx->pyr;
@@ -256,7 +285,9 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     if ((r = mvo_ensure_pinned(ctx, orb_detect_host_bytes(P.n_tiles)))) return r;
     if ((r = orb_launch_detect(ctx, ctx->h_pin))) return r;
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
+    ht.lap(0);
     MVO_HIP(hipEventSynchronize(ctx->ev));
+    ht.lap(1);
     // canonical order (level, row, column) = the order cv::FAST emits: inside a tile row the tiles interleave line by
     // line; every tile's slot is row-major already, so one cursor per tile column restores it
     const int32_t* counts = (const int32_t*)ctx->h_pin;
@@ -298,6 +329,7 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     }
     level_start[P.nlevels] = (int)all.size();
     const DevCandidate* cand = all.data();
+    ht.lap(2);
     out.clear();
     std::vector<DevCandidate> lv;
     for (int l = 0; l < P.nlevels; ++l) {
@@ -320,6 +352,9 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     }
     ctx->pyr_valid = true;
     ctx->pyr_levels_built = P.nlevels;
+    ht.lap(3);
+    static const char* const names[] = {"launch", "wait", "merge", "retain"};
+    ht.frame(names, 4);
     return MVO_OK;
 }
 
@@ -328,6 +363,8 @@ int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int
     const PyrInfo& P = ctx->pyr;
     const int n = (int)kps.size();
     if (n == 0) return MVO_OK;
+    HostTimes& ht = g_ht_describe;
+    ht.start();
     int r = ensure_kp_cap(ctx, n);
     if (r) return r;
     if ((r = mvo_ensure_pinned(ctx, (size_t)n * (sizeof(DevDescKp) + 32)))) return r;
@@ -350,9 +387,15 @@ int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int
     // writes the descriptors into it as well as into device memory: no copy dispatch on the frame's critical path; the
     // buffer is not touched again before the synchronisation below
     uint8_t* hd = desc_host ? ctx->h_pin + (size_t)n * sizeof(DevDescKp) : nullptr;
+    ht.lap(0);
     if ((r = orb_launch_brief(ctx, n, hk, hd))) return r;
+    ht.lap(1);
     MVO_HIP(hipStreamSynchronize(ctx->stream));
+    ht.lap(2);
     if (desc_host) std::memcpy(desc_host, hd, (size_t)n * 32);
+    ht.lap(3);
+    static const char* const names[] = {"prep", "launch", "wait", "copy"};
+    ht.frame(names, 4);
     (void)w;
     (void)h;
     return MVO_OK;
