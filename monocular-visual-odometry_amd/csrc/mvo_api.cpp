@@ -269,8 +269,8 @@ static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
         int cap = std::max(4096, nq + nq / 2);
         MVO_HIP(hipMalloc((void**)&ctx->d_mq, (size_t)cap * 32));
         MVO_HIP(hipMalloc((void**)&ctx->d_mqxy, (size_t)cap * 8));
-        // results + 32 slices of partials + one arrival counter per group of 64 queries (self re-arming, zeroed once)
-        const size_t body = (size_t)cap * (16 + 32 * 16), ctr = ((size_t)cap / 64 + 2) * 4;
+        // results + up to 64 slices of partials + one arrival counter per group of 64 queries (self re-arming, zeroed once)
+        const size_t body = (size_t)cap * (16 + 64 * 16), ctr = ((size_t)cap / 64 + 2) * 4;
         MVO_HIP(hipMalloc((void**)&ctx->d_mout, body + ctr));
         ctx->d_marrive = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctx->d_mout) + body);
         MVO_HIP(hipMemsetAsync(ctx->d_marrive, 0, ctr, ctx->stream));

@@ -146,6 +146,20 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
     if (depth == 0) {  // level 0 straight from the image
         if (oy >= bh) return;
         const int y = reflect101(oy - MVO_BORDER, L.h);
+        const int xi = ox4 - MVO_BORDER;  // interior x of the first of the four pixels (a multiple of 4)
+        if (B.ch == 3 && xi >= 0 && xi + 4 <= L.w) {
+            // four interior BGR pixels = 12 consecutive bytes: three dword loads when the row is dword-aligned
+            const uint8_t* px = B.img + (size_t)y * B.istride + 3 * xi;
+            if ((reinterpret_cast<uintptr_t>(px) & 3) == 0) {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(px);
+                const uint32_t w0 = q[0], w1 = q[1], w2 = q[2];
+                auto g = [](uint32_t b, uint32_t gg, uint32_t r) { return (b * 1868u + gg * 9617u + r * 4899u + 8192u) >> 14; };
+                const uint32_t o = g(w0 & 255, (w0 >> 8) & 255, (w0 >> 16) & 255) | g(w0 >> 24, w1 & 255, (w1 >> 8) & 255) << 8 |
+                                   g((w1 >> 16) & 255, w1 >> 24, w2 & 255) << 16 | g((w2 >> 8) & 255, (w2 >> 16) & 255, w2 >> 24) << 24;
+                *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)oy * L.stride + ox4) = o;
+                return;
+            }
+        }
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -386,6 +400,17 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     DevCandidate* out = slots + (size_t)blockIdx.x * FT_TILE_CAP;
     const int step = L.stride;
     const int ndisc = c_disc_n;
+    // this lane's pixels of the intensity-centroid disc (k = lane, lane + 64, ...): offsets and (u, v) once per workgroup,
+    // not once per survivor
+    constexpr int DISC_IT = (768 + 63) / 64;
+    int doff[DISC_IT], duv[DISC_IT];
+#pragma unroll
+    for (int q = 0; q < DISC_IT; ++q) {
+        const int k = lane + 64 * q;
+        const int u = k < ndisc ? c_disc[2 * k] : 0, v = k < ndisc ? c_disc[2 * k + 1] : 0;
+        doff[q] = k < ndisc ? v * step + u : 0;
+        duv[q] = k < ndisc ? (int)((unsigned)(u & 0xffff) | ((unsigned)v << 16)) : 0;  // (a padded lane re-reads the centre with weight 0)
+    }
     for (int i = wave; i < total; i += 4) {
         // survivor i -> (row, i-th set bit of the row's mask)
         int r = 0;
@@ -414,11 +439,11 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         c = wave_sum(c);
         // IC_Angle: m10 = sum u*I, m01 = sum v*I over the disc
         int m10 = 0, m01 = 0;
-        for (int k = lane; k < ndisc; k += 64) {
-            int u = c_disc[2 * k], v = c_disc[2 * k + 1];
-            int val = ctr[v * step + u];
-            m10 += u * val;
-            m01 += v * val;
+#pragma unroll
+        for (int q = 0; q < DISC_IT; ++q) {
+            const int val = ctr[doff[q]];
+            m10 += (int)(int16_t)(duv[q] & 0xffff) * val;
+            m01 += (duv[q] >> 16) * val;
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
