@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ raw, u
 #define BW_STRIDE 48
 #define BW_RAW_ROWS (BW_ROWS + 6)
 #define BW_RAW_DW 14  // 56 bytes per staged row: 4 bytes left of the window, 4 right
-struct BriefLds {
+struct __attribute__((aligned(16))) BriefLds {
     uint32_t raw[BW_RAW_ROWS * BW_RAW_DW];
     uint16_t hb[BW_RAW_ROWS * BW_STRIDE];
     uint32_t out[BW_ROWS * (BW_STRIDE / 4)];
@@ -554,37 +554,52 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ rawpy
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     constexpr int G[7] = {18, 34, 48, 56, 48, 34, 18};
-    const uint8_t* rb = reinterpret_cast<const uint8_t*>(W.raw);
-    // horizontal pass: one item = 4 adjacent columns of one staged row
+    // horizontal pass: one item = 4 adjacent columns of one staged row; the 10 source bytes come as three dwords
     for (int i = lane; i < BW_RAW_ROWS * (BW_STRIDE / 4); i += 64) {
-        const int r = i / (BW_STRIDE / 4), c4 = (i - r * (BW_STRIDE / 4)) * 4;
-        const uint8_t* p = rb + r * (BW_RAW_DW * 4) + c4 + 4;  // window column c4 sits 4 bytes into the staged row
-        int px[10];
+        const int r = i / (BW_STRIDE / 4), cq = i - r * (BW_STRIDE / 4);  // window columns 4 cq .. 4 cq + 3
+        const uint32_t* q = W.raw + r * BW_RAW_DW + cq;  // staged bytes 4 cq .. 4 cq + 11 = window columns 4 cq - 4 .. 4 cq + 7
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        // px[k] = window column 4 cq - 3 + k = staged byte 4 cq + 1 + k
+        const int px[10] = {(int)((d0 >> 8) & 255), (int)((d0 >> 16) & 255), (int)(d0 >> 24), (int)(d1 & 255), (int)((d1 >> 8) & 255),
+                            (int)((d1 >> 16) & 255), (int)(d1 >> 24), (int)(d2 & 255), (int)((d2 >> 8) & 255), (int)((d2 >> 16) & 255)};
+        uint32_t h01, h23;
+        {
+            int acc[4];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) px[k] = p[k - 3];
+            for (int k = 0; k < 4; ++k) {
+                acc[k] = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int acc = 0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) acc += G[j] * px[k + j];
-            W.hb[r * BW_STRIDE + c4 + k] = (uint16_t)acc;
+                for (int j = 0; j < 7; ++j) acc[k] += G[j] * px[k + j];
+            }
+            h01 = (uint32_t)acc[0] | ((uint32_t)acc[1] << 16);
+            h23 = (uint32_t)acc[2] | ((uint32_t)acc[3] << 16);
         }
+        uint32_t* hq = reinterpret_cast<uint32_t*>(W.hb + r * BW_STRIDE + 4 * cq);
+        hq[0] = h01;
+        hq[1] = h23;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    // vertical pass + the unblurred frame
+    // vertical pass + the unblurred frame; four columns of a row = one 8-byte read per tap row
     for (int i = lane; i < BW_ROWS * (BW_STRIDE / 4); i += 64) {
-        const int r = i / (BW_STRIDE / 4), c4 = (i - r * (BW_STRIDE / 4)) * 4;
+        const int r = i / (BW_STRIDE / 4), cq = i - r * (BW_STRIDE / 4), c4 = 4 * cq;
         const int gy = y0 + r - MVO_BORDER;
+        int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            const uint2 t = *reinterpret_cast<const uint2*>(W.hb + (r + j) * BW_STRIDE + c4);
+            acc[0] += G[j] * (int)(t.x & 0xffff);
+            acc[1] += G[j] * (int)(t.x >> 16);
+            acc[2] += G[j] * (int)(t.y & 0xffff);
+            acc[3] += G[j] * (int)(t.y >> 16);
+        }
+        const uint32_t rawq = W.raw[(r + 3) * BW_RAW_DW + cq + 1];  // the same four pixels, unblurred
         uint32_t o = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            int acc = 0;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) acc += G[j] * W.hb[(r + j) * BW_STRIDE + c4 + k];
             const int gx = x0 + c4 + k - MVO_BORDER;
-            const uint32_t v = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? (uint32_t)((acc + 32768) >> 16)
-                                                                            : (uint32_t)rb[(r + 3) * (BW_RAW_DW * 4) + c4 + k + 4];
+            const uint32_t v = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? (uint32_t)((acc[k] + 32768) >> 16)
+                                                                            : (rawq >> (8 * k)) & 255u;
             o |= v << (8 * k);
         }
         W.out[i] = o;
