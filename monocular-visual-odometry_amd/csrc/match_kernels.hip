@@ -6,8 +6,9 @@
 // Work decomposition (wave64): one LANE per query, the query's 256 bits live in 4 x u64 VGPRs; the train
 // descriptor of the current step is wave-uniform, so it is fetched with scalar loads (s_load_dwordx8) and
 // broadcast for free; distance = 8 x (v_xor + v_bcnt_u32).  k_knn2: one wave per (64 queries, train slice) pair,
-// 32 slices -> 1024 single-wave workgroups for 2000 x 2000, each scanning its slice in index order; the last wave to
-// arrive for a query group folds the 32 partial (best, second) pairs, keeping the lexicographically smallest
+// 32 slices -> 1024 waves for 2000 x 2000 in workgroups of four, each scanning its slice in index order; LDS fold of the
+// four, then the last workgroup to arrive for a query group folds the 8 partial (best, second) pairs, keeping the
+// lexicographically smallest
 // (distance, index) pairs, which reproduces cv::batchDistance's tie rule exactly (equal distances keep the lower
 // train index).  k_radius_l1
 // keeps the single-kernel form (16 waves x 64 queries, LDS merge).  Everything is integer: results are bit-exact.
@@ -15,7 +16,6 @@
 #include "mvo_internal.h"
 
 #include <climits>
-#include <cstdlib>
 
 typedef unsigned long long u64;
 
@@ -36,30 +36,43 @@ __device__ __forceinline__ void top2_insert(Top2& t, int d, int j) {
     t.i1 = ni1;
 }
 
-// grid = (query groups of 64) x MK_SLICES train slices, ONE wave per workgroup -> 1024 waves for a 2000 x 2000 call
-// (every SIMD of the chip gets one).  The wave first parks its slice in registers -- lane j holds train descriptor j of
-// the current 64-train chunk (one coalesced 2 KB read) -- and then broadcasts descriptor j to all lanes with
-// v_readlane: no memory access and no LDS in the pair loop.  The partial (best, second) pairs go out write-through at
-// agent scope; the wave that arrives LAST for its query group (arrival counter per group) folds the 32 partials of its
-// 64 queries and delivers the result: no merge launch.  The fold keeps the two lexicographically smallest
-// (distance, train index) pairs, which is exactly the strict-'<' in-order scan (indices are unique), so the order in
-// which the slices finished does not matter.
+// grid = (query groups of 64) x MK_GROUPS; one workgroup = 4 waves (one per SIMD of its CU) = 4 of the MK_SLICES train
+// slices -> 1024 waves for a 2000 x 2000 call: every SIMD of the chip gets one, which is what the pair loop wants (it is
+// VALU-throughput bound: 16 waves x 64 queries per workgroup put 8x the work on an eighth of the SIMDs and took 44 us).
+// A wave first parks its slice in registers -- lane j holds train descriptor j of the current 64-train chunk (one
+// coalesced 2 KB read) -- and then broadcasts descriptor j to all lanes with v_readlane: no memory access and no LDS in
+// the pair loop.  The four partial (best, second) pairs of a query meet in LDS; the workgroup's partial goes out
+// write-through at agent scope and the workgroup that arrives LAST for its query group (arrival counter per group)
+// folds the MK_GROUPS partials -- one batch of loads -- and delivers the result: no merge launch.  (With one wave per
+// workgroup the last wave had 32 partials to fetch, four dependent batches: 2/3 of the call's 20 us.)  Every fold keeps
+// the two lexicographically smallest (distance, train index) pairs, which is exactly the strict-'<' in-order scan
+// (indices are unique), so the order in which the slices finished does not matter.
 #define MK_SLICES 32
-#define MK_MAX_SLICES 64
+#define MK_GROUPS (MK_SLICES / 4)
 __device__ __forceinline__ uint32_t rl(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
 __device__ __forceinline__ bool pair_less(int d, int i, int e, int j) {  // (d,i) < (e,j); index -1 = empty = +inf
     return j < 0 ? i >= 0 : (i >= 0 && (d < e || (d == e && i < j)));
 }
-__global__ __launch_bounds__(64) void k_knn2(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
-                                             u64* __restrict__ part, int32_t* __restrict__ arrive,
-                                             int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
-    const int lane = threadIdx.x;
+// merge two sorted pairs (p.x,p.y)<=(p.z,p.w) and (r.x,r.y)<=(r.z,r.w)
+__device__ __forceinline__ int4 top2_merge(int4 p, int4 r) {
+    const bool pf = pair_less(p.x, p.y, r.x, r.y);
+    const int b0d = pf ? p.x : r.x, b0i = pf ? p.y : r.y;  // overall best
+    const int cd = pf ? r.x : p.x, ci = pf ? r.y : p.y;    // loser of the heads
+    const int nd = pf ? p.z : r.z, ni = pf ? p.w : r.w;    // second of the winner's list
+    const bool sf = pair_less(cd, ci, nd, ni);
+    return make_int4(b0d, b0i, sf ? cd : nd, sf ? ci : ni);
+}
+__global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int nq, const uint4* __restrict__ t, int nt,
+                                              u64* __restrict__ part, int32_t* __restrict__ arrive,
+                                              int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+    __shared__ int4 lpart[4][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int qi = blockIdx.x * 64 + lane;
     const int qc = min(qi, nq - 1);
     const uint4 qa = q[2 * (size_t)qc], qb = q[2 * (size_t)qc + 1];
-    const int nsl = (int)gridDim.y;  // train slices (MK_SLICES, or the development override)
-    const int slice = (nt + nsl - 1) / nsl;
-    const int j0 = blockIdx.y * slice, j1 = min(nt, j0 + slice);
+    const int slice = (nt + MK_SLICES - 1) / MK_SLICES;
+    const int j0 = (blockIdx.y * 4 + wave) * slice, j1 = min(nt, j0 + slice);
     Top2 b = {INT_MAX, -1, INT_MAX, -1};
     for (int c0 = j0; c0 < j1; c0 += 64) {
         const int cn = min(64, j1 - c0);  // wave-uniform
@@ -72,35 +85,36 @@ __global__ __launch_bounds__(64) void k_knn2(const uint4* __restrict__ q, int nq
             top2_insert(b, d, c0 + j);
         }
     }
-    // partial of (slice, query): two 8-byte {distance, index} words
+    lpart[wave][lane] = make_int4(b.d0, b.i0, b.d1, b.i1);
+    __syncthreads();
+    if (wave != 0) return;
+    int4 p = lpart[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) p = top2_merge(p, lpart[w][lane]);
+    // partial of (workgroup, query): two 8-byte {distance, index} words
     u64* mine = part + 2 * ((size_t)blockIdx.y * nq + qc);
     if (qi < nq) {
-        __hip_atomic_store(mine, ((u64)(uint32_t)b.i0 << 32) | (uint32_t)b.d0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 1, ((u64)(uint32_t)b.i1 << 32) | (uint32_t)b.d1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine, ((u64)(uint32_t)p.y << 32) | (uint32_t)p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, ((u64)(uint32_t)p.w << 32) | (uint32_t)p.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are complete before this wave is counted
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are complete before this workgroup is counted
     int last = 0;
     if (lane == 0) {
-        last = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsl - 1;
+        last = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MK_GROUPS - 1;
         if (last) __hip_atomic_store(arrive + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-armed
     }
     if (!__builtin_amdgcn_readfirstlane(last)) return;
-    int4 p = make_int4(INT_MAX, -1, INT_MAX, -1);
-    // (requesting all 64 words of a query at once instead of 16 at a time made the call slower: 37 us vs 20)
-#pragma unroll 8
-    for (int s = 0; s < nsl; ++s) {
+    u64 w0[MK_GROUPS], w1[MK_GROUPS];
+#pragma unroll
+    for (int s = 0; s < MK_GROUPS; ++s) {
         const u64* src = part + 2 * ((size_t)s * nq + qc);
-        const u64 w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int4 r = make_int4((int)(uint32_t)w0, (int)(uint32_t)(w0 >> 32), (int)(uint32_t)w1, (int)(uint32_t)(w1 >> 32));
-        // merge two sorted pairs (p.x,p.y)<=(p.z,p.w) and (r.x,r.y)<=(r.z,r.w)
-        const bool pf = pair_less(p.x, p.y, r.x, r.y);
-        const int b0d = pf ? p.x : r.x, b0i = pf ? p.y : r.y;          // overall best
-        const int cd = pf ? r.x : p.x, ci = pf ? r.y : p.y;            // loser of the heads
-        const int nd = pf ? p.z : r.z, ni = pf ? p.w : r.w;            // second of the winner's list
-        const bool sf = pair_less(cd, ci, nd, ni);
-        p = make_int4(b0d, b0i, sf ? cd : nd, sf ? ci : ni);
+        w0[s] = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w1[s] = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    p = make_int4(INT_MAX, -1, INT_MAX, -1);
+#pragma unroll
+    for (int s = 0; s < MK_GROUPS; ++s)
+        p = top2_merge(p, make_int4((int)(uint32_t)w0[s], (int)(uint32_t)(w0[s] >> 32), (int)(uint32_t)w1[s], (int)(uint32_t)(w1[s] >> 32)));
     if (qi < nq) {
         out_idx[2 * qi] = p.y;
         out_idx[2 * qi + 1] = p.w;
@@ -159,16 +173,11 @@ __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__
 int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out,
                       int32_t* final_out) {
     if (nq <= 0) return MVO_OK;
-    // MK_SLICES x nq 16-byte partials live behind the nq x 4 int32 result block
+    // MK_GROUPS x nq 16-byte partials live behind the nq x 4 int32 result block
     u64* d_part = reinterpret_cast<u64*>(d_out + 4 * (size_t)nq);
     int32_t* dst = final_out ? final_out : d_out;
     ProfScope ps(ctx, "k_knn2");
-    static const int slices = [] {
-        const char* e = std::getenv("MVO_KNN_SLICES");  // development override (<= MK_MAX_SLICES: the scratch is sized for it)
-        const int v = e ? std::atoi(e) : MK_SLICES;
-        return v >= 1 && v <= MK_MAX_SLICES ? v : MK_SLICES;
-    }();
-    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, slices), dim3(64), 0, ctx->stream, (const uint4*)d_q, nq,
+    hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, MK_GROUPS), dim3(256), 0, ctx->stream, (const uint4*)d_q, nq,
                        (const uint4*)d_t, nt, d_part, ctx->d_marrive, dst, dst + 2 * (size_t)nq);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
