@@ -1,20 +1,20 @@
 // csrc/orb_kernels.hip -- gfx950 kernels for ORB extraction (replaces cv::ORB::detect / ::compute as called
 // from the reference's src/geometry/feature_match.cpp:22-23,34,45,48).
 //
-// Data layout in HBM: ONE byte buffer per pyramid flavour (raw gray, blurred), every level stored with its
-// 32-px BORDER_REFLECT_101 frame, row stride rounded up to 64 B so that every tile row starts dword-aligned and
-// a 64-lane wave reads one aligned 64-B segment per row.  All kernels are integer/byte work bounded by HBM/L2
-// traffic; each is a single streaming pass with the neighbourhood staged in LDS:
-//   k_pyramid       every level of a group of up to four levels in ONE launch: a pixel of level l is evaluated by
-//                   walking the bilinear chain down to the group's base (the BGR image, or the last level of the
-//                   previous group) -- 4^depth base samples per pixel, all of them cache hits; no level waits for
-//                   another one, so there is no inter-workgroup dependency and no launch per level
-//   k_fast_nms      FAST-9/16 score + 3x3 NMS + 31-px border; one 64x16 tile per workgroup; one 64-bit survivor mask
-//                   per (row, 64-px column) cell via wave ballot.  The workgroup that finishes LAST (arrival counter)
-//                   scans the cell counts and expands the masks into the canonical (level, row, col) candidate list:
-//                   no scan / emit launches
-//   k_harris_angle  one WAVE per candidate: 7x7 Harris (49 lanes) + IC angle over the 749-px disc, wave shuffle
-//                   reductions; the finished 16-byte record also goes to the pinned host mirror (no copy dispatch)
+// Data layout in HBM: ONE byte buffer for the raw gray pyramid (a second one for whole-level blur, filled on debug
+// request only), every level stored with its 32-px BORDER_REFLECT_101 frame, row stride rounded up to 64 B so that every
+// tile row starts dword-aligned and a 64-lane wave reads one aligned 64-B segment per row.  All kernels are integer/byte
+// work bounded by HBM/L2 traffic (in practice by latency); three launches per frame:
+//   k_pyramid       every level of a group of up to four levels in ONE launch: workgroup = one 64x16 tile of one level;
+//                   the tile's footprint is traced down the bilinear chain to the group's base (the BGR image, or the
+//                   last level of the previous group), the base region is converted once into LDS, every intermediate
+//                   level's region is built in LDS, the tile is written from the region one level below.  No level
+//                   waits for another one: no inter-workgroup dependency, no launch per level.  k_pyramid_chain (every
+//                   pixel walks the chain itself, 4^depth base samples) is the fallback when the regions do not fit LDS
+//   k_fast_harris   FAST-9/16 score + 3x3 NMS + 31-px border on a 64x16 tile (one 64-bit survivor mask per tile row via
+//                   wave ballot), then ONE WAVE per survivor of the tile: 7x7 Harris (49 lanes) + IC angle over the
+//                   749-px disc, wave shuffle reductions; the finished 16-byte records go into the tile's slot of a
+//                   pinned host buffer (no candidate compaction on the device, no copy dispatch)
 //   k_brief         one WAVE per keypoint: the 45x56 raw window is staged in LDS, blurred there (separable 7x7
 //                   fixed-point Gaussian, the keypoint's window only) and sampled: 512 rotated taps, 4 ballots = 256 bits
 //   k_blur          whole-level blur, kept for mvo_debug_get_level(blurred) only
