@@ -1,0 +1,52 @@
+"""CPU checks of the measurement plumbing: the PMC summary tool and bench.py's reader of its output, the algorithmic
+work table, the JSON contract fields that do not need a GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _counter_csv(path, counter, rows):
+    with open(path, "w") as f:
+        f.write('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size","Kernel_Id",'
+                '"Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count","Accum_VGPR_Count","SGPR_Count",'
+                '"Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n')
+        for i, (name, v) in enumerate(rows):
+            f.write('%d,%d,1,1,1,1,256,1,"%s",256,0,0,64,0,32,"%s",%s,0,1\n' % (i, i, name, counter, v))
+
+
+def test_pmc_summary_and_reader(tmp_path, monkeypatch):
+    f, w, out = tmp_path / "f.csv", tmp_path / "w.csv", tmp_path / "r99_pmc_fetch_write_size_per_kernel.csv"
+    _counter_csv(f, "FETCH_SIZE", [("void k_ba_lm<false, 32>(BaBatch)", 1000.0), ("void k_ba_lm<false, 32>(BaBatch)", 3000.0),
+                                   ("k_brief(unsigned char const*, DevDescKp const*)", 10.0)])
+    _counter_csv(w, "WRITE_SIZE", [("void k_ba_lm<false, 32>(BaBatch)", 500.0), ("k_brief(unsigned char const*, DevDescKp const*)", 1.0)])
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), "fetch_write", str(f), str(w), str(out), "cmd"])
+    text = out.read_text()
+    assert "kernel,calls,FETCH_SIZE_KB_avg,WRITE_SIZE_KB_avg" in text and "k_ba_lm,2,2000.00,500.00" in text and "k_brief,1,10.00,1.00" in text
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    os.replace(out, tmp_path / "profiles" / out.name)
+    tr = bench.pmc_traffic("k_ba_lm")
+    assert tr is not None and abs(tr[0] - 2500.0 * 1024) < 1e-6 and tr[1].endswith(out.name)
+    assert bench.pmc_traffic("k_nothing") is None
+
+
+def test_committed_pmc_summary_is_what_the_bench_reads():
+    import bench
+    tr = bench.pmc_traffic("k_ba_lm")
+    assert tr is not None and tr[1].startswith("profiles/r") and 1e5 < tr[0] < 1e8
+
+
+def test_algorithmic_work_table_names_the_kernels_of_a_frame():
+    import bench
+    args = bench.parse([])
+    work = bench.algorithmic_work(args)
+    assert set(work) == {"k_pyramid", "k_fast_harris", "k_brief", "k_knn2"}
+    assert work["k_knn2"] == ("valu", 16.0 * 2000 * 2000)
+    # BA5 is 11.2 MFLOP per LM trial
+    assert abs(bench.ba_trial_flops(9386, 2000, 5, False) / 1e6 - 11.2) < 0.3
