@@ -310,6 +310,28 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+// Correctly rounded 1 / d for the pivots of the reduced solve.  The compiler's IEEE f64 division is
+//   s = div_scale(d), n = div_scale(1), r = rcp(s), two Newton steps on r, q = n r, e = fma(-s, q, n), q = div_fmas(e, r, q),
+//   div_fixup(q)
+// -- ten dependent operations, three of which (the two scalings and the fix-up) only act on operands near the ends of
+// the exponent range, zeros, infinities and NaNs.  For a pivot inside BA_PIVOT_MIN .. BA_PIVOT_MAX they are identities
+// (scale factor 1, nothing to fix), so the shorter chain below computes the SAME intermediate values and returns the same
+// bits (every bitwise BA test runs through it).  A pivot outside that range is not a usable pivot: the solvers' "not
+// positive" check rejects the step (the blocked oracle has the same rule), so what this function returns for it never
+// reaches a result.  A range test with a fall-back to the generic division was measured too: the branch breaks the
+// overlap of the reciprocal with the row updates and costs more than the three operations save.
+#define BA_PIVOT_MIN 0x1p-500
+#define BA_PIVOT_MAX 0x1p+500
+__device__ __forceinline__ double ba_rcp_pivot(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(e, r, r);
+}
+
 // ------------------------------------------------------------------------------------------------ reduced solve
 // Solves the reduced (n x n) system with ONE wave.  SL (LDS, row pitch NR + 1) holds row i = S[i][0..i] for i < n and
 // row n = the rhs g^T: the lower triangle of the symmetric matrix [[S, g], [g^T, .]].  Right-looking LDL^T without
@@ -343,8 +365,8 @@ __device__ __forceinline__ int solve_wave(int sl_off, int cb_off, int n, int lan
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int cur = j & 1, nxt = cur ^ 1;
-            ok &= ((d > 0) & (d <= 1.7976931348623157e308)) | (j >= n);
-            const double r = 1.0 / d;
+            ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (j >= n);
+            const double r = ba_rcp_pivot(d);
             const double l = a[j] * r;
             if (j + 1 < R) {
                 a[j + 1] = __builtin_fma(-l, colbuf[cur * 64 + j + 1], a[j + 1]);
@@ -390,8 +412,8 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
     double ci = colbuf[i];
 #pragma unroll
     for (int m = 0; m < H; ++m) ck[0][m] = colbuf[2 * m + h];
-    double r = 1.0 / d;
-    ok &= (d > 0) & (d <= 1.7976931348623157e308);
+    double r = ba_rcp_pivot(d);
+    ok &= (d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX);
     double l = ci * r;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -412,8 +434,8 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
         // region B: the rest of step j; the division of step j + 1 rides along
         double rn = 0;
         if (jn < R) {
-            rn = 1.0 / d;
-            ok &= ((d > 0) & (d <= 1.7976931348623157e308)) | (jn >= n);
+            rn = ba_rcp_pivot(d);
+            ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (jn >= n);
         }
 #pragma unroll
         for (int m = mn + 1; m < H; ++m) a[m] = __builtin_fma(-l, ck[cur][m], a[m]);
@@ -447,11 +469,11 @@ __device__ __noinline__ int solve_lds(int sl_off, int cb_off, int n, int lane) {
     int ok = 1;
     for (int j = 0; j < n; ++j) {
         const double d = S[j * ld + j];
-        if (!(d > 0) || !isfinite(d)) {
+        if (!(d >= BA_PIVOT_MIN && d <= BA_PIVOT_MAX)) {
             ok = 0;
             break;
         }
-        const double r = 1.0 / d;
+        const double r = ba_rcp_pivot(d);
         for (int i = j + 1 + lane; i <= n; i += 64) col[i] = S[i * ld + j];
         __builtin_amdgcn_wave_barrier();
         for (int i = j + 1 + lane; i <= n; i += 64) {

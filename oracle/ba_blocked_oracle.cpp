@@ -557,7 +557,7 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                 }
                 for (int j = 0; j < n && ok2; ++j) {
                     const double d = S[(size_t)j * ld + j];
-                    if (!((d > 0) && (d <= 1.7976931348623157e308))) {
+                    if (!((d >= 0x1p-500) && (d <= 0x1p+500))) {  // a usable pivot (the device's reciprocal chain is exact there)
                         ok2 = 0;
                         break;
                     }
