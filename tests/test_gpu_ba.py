@@ -297,3 +297,23 @@ def test_bitwise_variants(mvo, O, ctx, case, mfma):
             _bitwise(mvo, O, ctx, mvo.synth.ba_problem(7, 1500, 31), fix_points=False)
     finally:
         mvo.debug_set("ba_mfma", 1)
+
+
+def test_batched_windows_equal_their_single_solves_bit_for_bit(mvo, ctx):
+    """mvo_ba_solve_batch: windows of different sizes in ONE call -- the launch thread packs them into grids (up to 16
+    windows, never more workgroups than CUs, one solver class per grid); every window must come out exactly as when it is
+    solved alone (same plan, same sums; which XCD it lands on only selects the hand-off flavour)."""
+    pbs = [mvo.synth.ba_problem(5, 2000, 7), mvo.synth.ba_problem(3, 300, 11), mvo.synth.ba_problem(4, 700, 21),
+           mvo.synth.ba_problem(3, 40, 77), mvo.synth.ba_problem(5, 1500, 9), mvo.synth.ba_problem(2, 150, 3)]
+    pbs = pbs + [mvo.synth.ba_problem(3, 200 + 10 * k, 100 + k) for k in range(8)]          # 14 windows
+    pbs.append(mvo.synth.ba_problem(7, 1500, 31))                                            # another solver class (n = 42)
+    singles = [ctx.bundle_adjustment(*_args(pb), fix_points=False, max_iterations=15) for pb in pbs]
+    batch = ctx.ba_solve_batch([_args(pb) for pb in pbs], fix_points=False, max_iterations=15)
+    assert len(batch) == len(pbs)
+    for k, ((P, X, st), (Pb, Xb, stb)) in enumerate(zip(singles, batch)):
+        assert np.array_equal(P, Pb) and np.array_equal(X, Xb), (k, np.abs(P - Pb).max())
+        assert st["trials"] == stb["trials"] and st["chi2_final"] == stb["chi2_final"], (k, st, stb)
+    # pose-only windows go through the same path
+    single = ctx.bundle_adjustment(*_args(pbs[0]), fix_points=True)
+    both = ctx.ba_solve_batch([_args(pbs[0]), _args(pbs[1])], fix_points=True)
+    assert np.array_equal(single[0], both[0][0])
