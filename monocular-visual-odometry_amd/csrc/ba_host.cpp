@@ -147,19 +147,21 @@ void BaService::run() {
     // clients: back-to-back solver launches own every CU -- 2 waves x 256 VGPRs per SIMD, ~150 KB LDS -- and the extraction
     // kernels of the other clients only run in the gaps between them; closing the gaps starved the clients and lowered the
     // frame rate from ~2800 to ~2600.)
+    // stage clocks of one loop iteration: kept in locals and folded into the shared statistics under the lock
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&tp](double& acc) {
         const auto now = std::chrono::steady_clock::now();
         acc += std::chrono::duration<double, std::milli>(now - tp).count();
         tp = now;
     };
+    double l_idle = 0, l_batch = 0, l_launch = 0, l_sync = 0, l_post = 0;
     for (;;) {
         BaJob* jobs[BA_MAX_BATCH];
         int nj = 0;
         {
             std::unique_lock<std::mutex> lk(m);
             cv_work.wait(lk, [&] { return !q.empty(); });
-            lap(t_idle);
+            lap(l_idle);
             {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
                 const auto now = std::chrono::steady_clock::now();
                 for (auto it = seen.begin(); it != seen.end();)
@@ -181,7 +183,7 @@ void BaService::run() {
                 q.pop_front();
             }
         }
-        lap(t_batch);
+        lap(l_batch);
         BaBatch b{};
         b.nwin = nj;
         int maxG = 1;
@@ -203,9 +205,9 @@ void BaService::run() {
         (void)hipEventRecord(e0, stream);
         hipError_t le = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, ba_solver_class(jobs[0]->ws->plan.n));
         (void)hipEventRecord(e1, stream);
-        lap(t_launch);
+        lap(l_launch);
         hipError_t se = hipStreamSynchronize(stream);
-        lap(t_sync);
+        lap(l_sync);
         float t = 0;
         if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&t, e0, e1);
         else (void)hipGetLastError();
@@ -214,6 +216,8 @@ void BaService::run() {
             ++launches;
             windows += nj;
             ms += t;
+            t_idle += l_idle, t_batch += l_batch, t_launch += l_launch, t_sync += l_sync, t_post += l_post;
+            l_idle = l_batch = l_launch = l_sync = l_post = 0;
             for (int i = 0; i < nj; ++i) {
                 jobs[i]->err = le != hipSuccess ? le : se;
                 jobs[i]->ms = t;
@@ -222,7 +226,7 @@ void BaService::run() {
             }
         }
         cv_done.notify_all();
-        lap(t_post);
+        lap(l_post);
     }
 }
 BaService& service_for(int device) {
@@ -582,6 +586,12 @@ static BaWorkspace* pool_ws(mvo_ctx* ctx, size_t i) {
 }
 void ba_pool_release(mvo_ctx* ctx) {
     if (!ctx->ba_pool) return;
+    // a ctx destroyed between mvo_bundle_adjustment_begin and _end still has a window queued or running in the launch
+    // service, which reads the workspace and writes its pinned mirrors: wait for it before anything is freed
+    mvo_ba_pool* pool = ctx->ba_pool;
+    if (pool->has_pending && pool->pending.ws && pool->pending.ws->plan.runnable && !pool->pending.done)
+        service_wait(service_for(ctx->device), &pool->pending, 1);
+    pool->has_pending = false;
     for (BaWorkspace* w : ctx->ba_pool->ws) {
         ws_free(*w);
         delete w;
@@ -737,6 +747,7 @@ int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg
 // issuing the launch, waiting for the kernel, publishing the results (ms)
 void ba_service_times(int device, double* out5) {
     for (int i = 0; i < 5; ++i) out5[i] = 0;
+    if (device < 0 || device >= 16) return;
     BaService* sp;
     {
         std::lock_guard<std::mutex> lk(*g_service_start);
@@ -750,6 +761,7 @@ void ba_launch_stats(int device, long long* launches, long long* windows, double
     if (launches) *launches = 0;
     if (windows) *windows = 0;
     if (ms) *ms = 0;
+    if (device < 0 || device >= 16) return;
     BaService* sp;
     {
         std::lock_guard<std::mutex> lk(*g_service_start);

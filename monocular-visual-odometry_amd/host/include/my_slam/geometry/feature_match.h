@@ -12,12 +12,22 @@ namespace my_slam {
 namespace geometry {
 
 namespace detail {
-// feature_match.cpp:16-19, 42-45, 56-59: parameters are read once (function-local statics in the reference)
+// State the adapters keep per ctx (a host thread may bind several ctxs one after the other through
+// hot_path_ctx_binding()): "parameters latched" and the owner of the pyramid cached inside that ctx.
+struct CtxState {
+    bool configured = false;
+    bool reuse_pyramid = false;
+    long long pyramid_token = 0;
+};
+inline CtxState& ctx_state() {
+    static thread_local std::unordered_map<mvo_ctx*, CtxState> m;
+    return m[hot_path_ctx()];
+}
+// feature_match.cpp:16-19, 42-45, 56-59: parameters are read once (function-local statics in the reference); here once
+// per ctx, so that every ctx a thread uses receives the configuration
 inline void latch_orb_params() {
-    // per host thread, like the ctx the parameters are latched into (hot_path_ctx() is thread_local): a second host
-    // thread gets its own ctx and must configure it too
-    static thread_local bool done = false;
-    if (done) return;
+    CtxState& cs = ctx_state();
+    if (cs.configured) return;
     mvo_orb_params p;
     p.nfeatures = basics::Config::get<int>("number_of_keypoints_to_extract");
     p.scale_factor = (float)basics::Config::get<double>("scale_factor");
@@ -29,20 +39,14 @@ inline void latch_orb_params() {
     // not a config.yaml key: which cv::resize flavour cv::ORB uses depends on the OpenCV version (>= 3.4: EXACT)
     p.pyramid_interpolation = basics::Config::has("orb_pyramid_interpolation") ? basics::Config::get<int>("orb_pyramid_interpolation") : 1;
     mvo_check(mvo_orb_configure(hot_path_ctx(), &p), "mvo_orb_configure");
-    done = true;
+    cs.configured = true;
 }
 // the pyramid built by calcKeyPoints may be reused by calcDescriptors when the caller guarantees it is the same
 // image (Frame::calcKeyPoints / calcDescriptors do); the free functions rebuild it by default.
-inline bool& reuse_pyramid_flag() {
-    static thread_local bool f = false;
-    return f;
-}
+inline bool& reuse_pyramid_flag() { return ctx_state().reuse_pyramid; }
 // who owns the pyramid cached in the ctx: the Frame's unique id + 1 (ids are never reused, unlike addresses), 0 after
 // any direct call of the free functions
-inline long long& pyramid_token() {
-    static thread_local long long t = 0;
-    return t;
-}
+inline long long& pyramid_token() { return ctx_state().pyramid_token; }
 }  // namespace detail
 
 inline void calcKeyPoints(const cv::Mat& image, vector<cv::KeyPoint>& keypoints) {

@@ -94,6 +94,16 @@ inline void bundleAdjustment(const vector<vector<cv::Point2f*>>& v_pts_2d, const
 // stay valid in between.  `last` keeps the statistics of the finished solve.
 class BundleAdjustmentJob {
 public:
+    BundleAdjustmentJob() = default;
+    BundleAdjustmentJob(const BundleAdjustmentJob&) = delete;
+    BundleAdjustmentJob& operator=(const BundleAdjustmentJob&) = delete;
+    // a job that goes out of scope between its two halves (exception, early return) still owns a launch that writes into
+    // the ctx's pooled workspace: wait for it; the results are dropped, errors cannot leave a destructor
+    ~BundleAdjustmentJob() {
+        if (!active_) return;
+        active_ = false;
+        (void)mvo_bundle_adjustment_end(ctx_, nullptr, nullptr);
+    }
     void begin(const vector<vector<cv::Point2f*>>& v_pts_2d, const vector<vector<int>>& v_pts_2d_to_3d_idx, const cv::Mat& K,
                std::unordered_map<int, cv::Point3f*>& pts_3d, vector<cv::Mat*>& v_camera_g2o_poses,
                const cv::Mat& information_matrix, bool is_fix_map_pts = false, bool is_update_map_pts = true) {
@@ -101,13 +111,14 @@ public:
         pts_3d_ = &pts_3d;
         poses_ = &v_camera_g2o_poses;
         update_ = is_update_map_pts;
-        mvo_check(mvo_bundle_adjustment_begin(hot_path_ctx(), &fb_.pr), "bundleAdjustment (begin)");
+        ctx_ = hot_path_ctx();
+        mvo_check(mvo_bundle_adjustment_begin(ctx_, &fb_.pr), "bundleAdjustment (begin)");
         active_ = true;
     }
     void end() {
         if (!active_) return;
         active_ = false;
-        mvo_check(mvo_bundle_adjustment_end(hot_path_ctx(), &fb_.pr, &last), "bundleAdjustment (end)");
+        mvo_check(mvo_bundle_adjustment_end(ctx_, &fb_.pr, &last), "bundleAdjustment (end)");
         fb_.scatter(*pts_3d_, *poses_, update_);
     }
     bool active() const { return active_; }
@@ -117,6 +128,7 @@ private:
     FlatBundle fb_;
     std::unordered_map<int, cv::Point3f*>* pts_3d_ = nullptr;
     vector<cv::Mat*>* poses_ = nullptr;
+    mvo_ctx* ctx_ = nullptr;  // the ctx the launch was made on (the binding of the thread may change in between)
     bool update_ = true, active_ = false;
 };
 
