@@ -52,7 +52,9 @@ def test_callsite_program_uses_every_function_and_links():
     assert "libmvo_hip.so" in ldd and "liboracle" not in ldd
 
 
-def test_orb_parameters_are_latched_per_host_thread():
-    """hot_path_ctx() is thread_local, so must be the 'parameters latched' flag."""
+def test_orb_parameters_are_latched_per_ctx():
+    """ADVICE r1 + r2: hot_path_ctx() is thread_local and a thread may bind several ctxs in turn, so the 'parameters
+    latched' flag and the pyramid-owner token are kept per (thread, ctx)."""
     fm = open(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h")).read()
-    assert re.search(r"static\s+thread_local\s+bool\s+done", fm)
+    assert re.search(r"static\s+thread_local\s+std::unordered_map<mvo_ctx\*,\s*CtxState>", fm)
+    assert "m[hot_path_ctx()]" in fm
