@@ -103,7 +103,11 @@ __device__ __forceinline__ bool gtry_d(const u64* g, unsigned tag, double& v) {
     v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
     return (unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag;
 }
+#ifndef MVO_KERNEL_SIM
 #define BA_SPIN_LIMIT (1u << 21)
+#else
+#define BA_SPIN_LIMIT (1u << 28)  // emulated workgroups run at very different speeds (tests/sim)
+#endif
 // Every thread fetches its share of `count` tagged values into LDS: item q comes from the granule pair
 // src[2 * (q / per * stride + q % per)] (per = values per producer row, stride = row pitch in values).  Four
 // independent loads in flight per thread and pass; bounded retries.
@@ -303,6 +307,17 @@ __device__ __forceinline__ void huber(double e, double delta, double& rho0, doub
     }
 }
 
+// the XCD this workgroup runs on (placement is used for speed only, never for results)
+__device__ __forceinline__ unsigned ba_xcc_id() {
+#ifndef MVO_KERNEL_SIM
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return xcc & 15u;
+#else
+    return blockIdx.x & 7u;
+#endif
+}
+
 __device__ __forceinline__ double readlane_d(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     lo = __builtin_amdgcn_readlane(lo, src);
@@ -345,7 +360,11 @@ __device__ __forceinline__ double ba_rcp_pivot(double d) {
 // (g2o: LDLT "not positive" -> the step is rejected).
 // (The LDS areas are passed as offsets into the dynamic segment: generic pointers into LDS handed to an out-of-line
 // function make hipcc 7.2 emit an illegal v_cmp against src_shared_base.)
+#ifndef MVO_KERNEL_SIM
 extern __shared__ __attribute__((aligned(16))) double ba_dyn_lds[];
+#else  // tests/sim: this source compiled for the host against tests/sim/hip_emu (a test aid; the library has no CPU path)
+#define ba_dyn_lds (static_cast<double*>(emu_dyn_lds()))
+#endif
 template <int NR>
 __device__ __forceinline__ int solve_wave(int sl_off, int cb_off, int n, int lane) {
     constexpr int R = NR - 1;      // lane / row of the rhs
@@ -377,7 +396,9 @@ __device__ __forceinline__ int solve_wave(int sl_off, int cb_off, int n, int lan
             for (int k = j + 2; k < R; ++k) a[k] = __builtin_fma(-l, colbuf[cur * 64 + k], a[k]);
             SL[j * P + lane] = l;  // column j of L (entries of the lanes <= j are never read)
         }
-        // back-substitution: lane j owns x_j
+        // back-substitution: lane j owns x_j.  (Row j of L^T was written by the other lanes: an intra-wave hand-off through
+        // LDS -- in order for a wave anyway; the barrier is no instruction, it states the dependence.)
+        __builtin_amdgcn_wave_barrier();
         double cl[NR];
 #pragma unroll
         for (int i = 1; i < R; ++i) cl[i] = SL[(lane < R ? lane : 0) * P + i];
@@ -445,7 +466,8 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
         r = rn;
         l = ln;
     }
-    // back-substitution: lane j (< 31) owns x_j
+    // back-substitution: lane j (< 31) owns x_j  (intra-wave hand-off of L^T through LDS, see solve_wave)
+    __builtin_amdgcn_wave_barrier();
     double cl[NR];
     const int lj = i < R ? i : 0;
 #pragma unroll
@@ -462,7 +484,7 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
 }
 __device__ __forceinline__ int solve_wave_64(int sl_off, int cb_off, int n, int lane) { return solve_wave<64>(sl_off, cb_off, n, lane); }
 // the same arithmetic for more than 63 unknowns (> 10 free poses): one wave, matrix in LDS (row pitch n + 2)
-__device__ __noinline__ int solve_lds(int sl_off, int cb_off, int n, int lane) {
+__device__ __attribute__((noinline)) int solve_lds(int sl_off, int cb_off, int n, int lane) {
     double* S = ba_dyn_lds + sl_off;
     double* col = ba_dyn_lds + cb_off;  // n + 1 <= 121 doubles of scratch; the solution is left in col[0 .. n)
     const int ld = n + 2;
@@ -778,9 +800,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         if (G > 1) {
             ++tagB;
             u64* slot = B.xC + (size_t)(tagB & 1) * G * 4;
-            unsigned xcc;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            xcc &= 15u;
+            const unsigned xcc = ba_xcc_id();
             if (tid == 0) {
                 gstore_d(slot + 4 * g, tag0 + tagB, c, false);
                 gstore_d(slot + 4 * g + 2, tag0 + tagB, (double)xcc, false);  // (second value: where this workgroup runs)

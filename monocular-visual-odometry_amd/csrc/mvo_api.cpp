@@ -413,94 +413,6 @@ int mvo_match_features(mvo_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d
     return MVO_OK;
 }
 
-// ---------------------------------------------------------------------------------------------- BA
-static int ba_check(mvo_ctx* ctx, const mvo_ba_problem* p) {
-    if (!ctx || !p || p->n_poses < 0 || p->n_points < 0 || p->n_edges < 0)
-        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
-    if ((p->n_poses && !p->pose_T_w_c) || (p->n_points && !p->points) ||
-        (p->n_edges && (!p->edge_pose || !p->edge_point || !p->edge_uv)))
-        return mvo_set_err(ctx, MVO_ERR_INVALID, "null array", hipSuccess);
-    for (int e = 0; e < p->n_edges; ++e)
-        if (p->edge_pose[e] < 0 || p->edge_pose[e] >= p->n_poses || p->edge_point[e] < 0 ||
-            p->edge_point[e] >= p->n_points)
-            return mvo_set_err(ctx, MVO_ERR_INVALID, "edge index out of range", hipSuccess);
-    return MVO_OK;
-}
-int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
-    int r = ba_check(ctx, p);
-    if (r) return r;
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_solve_device(ctx, p, st);
-}
-int mvo_bundle_adjustment_begin(mvo_ctx* ctx, const mvo_ba_problem* p) {
-    int r = ba_check(ctx, p);
-    if (r) return r;
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_begin_device(ctx, p);
-}
-int mvo_bundle_adjustment_end(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {
-    if (!ctx) return MVO_ERR_INVALID;
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_end_device(ctx, p, st);
-}
-int mvo_ba_solve_batch(mvo_ctx* ctx, mvo_ba_problem* problems, int n, mvo_ba_stats* stats) {
-    if (!ctx || n < 0 || (n && !problems)) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
-    for (int i = 0; i < n; ++i) {
-        int r = ba_check(ctx, &problems[i]);
-        if (r) return r;
-    }
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_solve_batch_device(ctx, problems, n, stats);
-}
-
-int mvo_ba_prepare(mvo_ctx* ctx, const mvo_ba_problem* p, mvo_ba_handle** handle) {
-    if (!handle) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
-    int r = ba_check(ctx, p);
-    if (r) return r;
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_prepare_device(ctx, p, handle);
-}
-int mvo_ba_solve_resident(mvo_ctx* ctx, mvo_ba_handle* handle) {
-    if (!ctx || !handle) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_run_device(ctx, handle);
-}
-int mvo_ba_fetch(mvo_ctx* ctx, mvo_ba_handle* handle, double* poses, double* points, mvo_ba_stats* stats) {
-    if (!ctx || !handle) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad arguments", hipSuccess);
-    MVO_HIP(hipSetDevice(ctx->device));
-    return ba_fetch_device(ctx, handle, poses, points, stats);
-}
-void mvo_ba_release(mvo_ctx* ctx, mvo_ba_handle* handle) {
-    if (ctx) {
-        (void)hipSetDevice(ctx->device);
-        (void)hipStreamSynchronize(ctx->stream);
-    }
-    ba_release_device(ctx, handle);
-}
-int mvo_debug_ba_service_times(int device, double* out5) {
-    if (!out5) return MVO_ERR_INVALID;
-    ba_service_times(device, out5);
-    return MVO_OK;
-}
-
-int mvo_ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
-    if (device < 0 || device > 15) return MVO_ERR_INVALID;
-    ba_launch_stats(device, launches, windows, ms, reset);
-    return MVO_OK;
-}
-int mvo_debug_ba_trace_enable(mvo_ctx* ctx, int on) {
-    if (!ctx) return MVO_ERR_INVALID;
-    ba_set_trace(ctx, on);
-    return MVO_OK;
-}
-int mvo_debug_get_ba_trace(mvo_ctx* ctx, mvo_ba_handle* handle, double* rows, int cap, int* n) {
-    if (!ctx) return MVO_ERR_INVALID;
-    return ba_get_trace(ctx, handle, rows, cap, n);
-}
-int mvo_debug_get_ba_plan(mvo_ctx* ctx, mvo_ba_handle* handle, int* wgs, int* nsplit, int32_t* wg_pt_start, int cap) {
-    if (!ctx) return MVO_ERR_INVALID;
-    return ba_get_plan(ctx, handle, wgs, nsplit, wg_pt_start, cap);
-}
 
 // matchFeatures with both descriptor sets already in HBM (e.g. the ping-pong buffers of mvo_calc_descriptors_dev)
 int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d_d2, int n2, int method,
@@ -536,24 +448,9 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 }
 
 // ---------------------------------------------------------------------------------------------- debug hooks
-extern int g_ba_use_mfma, g_ba_wgs, g_ba_same_l2, g_ba_profile;
+int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
 int mvo_debug_set(const char* key, int value) {
-    if (key && !std::strcmp(key, "ba_mfma")) {
-        g_ba_use_mfma = value;
-        return MVO_OK;
-    }
-    if (key && !std::strcmp(key, "ba_profile")) {
-        g_ba_profile = value;
-        return MVO_OK;
-    }
-    if (key && !std::strcmp(key, "ba_same_l2")) {
-        g_ba_same_l2 = value;
-        return MVO_OK;
-    }
-    if (key && !std::strcmp(key, "ba_wgs")) {
-        g_ba_wgs = value;
-        return MVO_OK;
-    }
+    if (key && !std::strncmp(key, "ba_", 3)) return ba_debug_set(key, value);
     if (key && !std::strcmp(key, "pyr_force_chain")) {
         g_pyr_force_chain = value;
         return MVO_OK;
@@ -563,13 +460,6 @@ int mvo_debug_set(const char* key, int value) {
         return MVO_OK;
     }
     return MVO_ERR_INVALID;
-}
-
-int mvo_debug_get_ba_phases(mvo_ctx* ctx, long long* cycles, int n, int* wgs) {
-    if (!ctx || !cycles) return MVO_ERR_INVALID;
-    for (int i = 0; i < n && i < 16; ++i) cycles[i] = ctx->ba_phase[i];
-    if (wgs) *wgs = ctx->ba_wgs;
-    return MVO_OK;
 }
 
 int mvo_debug_get_level(mvo_ctx* ctx, int level, int blurred, uint8_t* out, int cap, int* w, int* h, int* stride) {

@@ -1,0 +1,221 @@
+// tests/sim/hip_emu/hip/hip_runtime.h -- TEST AID, not a backend: a stand-in for <hip/hip_runtime.h> that lets the
+// SOURCE of a HIP kernel (and of its host side) be compiled for x86 and executed on the CPU, thread for thread:
+//   * every workgroup of a launch runs on its own OS thread; its GPU threads are fibers (own stack each) that the
+//     workgroup thread schedules cooperatively: a fiber runs until it reaches __syncthreads(), a wave operation
+//     (__shfl_xor, v_readlane, MFMA ...) or a polling pause (s_sleep), where it blocks until its workgroup / wave /
+//     nobody arrives;
+//   * wave operations are rendez-vous points of the 64 fibers of a wave: lanes deposit their operands, the last
+//     arrival releases the wave, every lane picks up what the instruction would have delivered to it;
+//   * v_mfma_f64_16x16x4_f64 is restated as what the hardware was probed to compute (tools/probes/mfma_probe.hip): per
+//     output element a chain of IEEE fused multiply-adds over the four k slots in order;
+//   * cross-workgroup traffic goes through ordinary memory with relaxed atomics; the workgroups really run
+//     concurrently (OS threads), so hand-off protocols are exercised, bounded spins can time out.
+// The fiber order inside a workgroup can be reversed or shuffled (EMU_ORDER=reverse|shuffle): a missing barrier shows
+// as a result that depends on the order.  Nothing here is ever linked into libmvo_hip.so: the product has no CPU path
+// (tests/test_abi.py checks that); the CPU suite uses this to check kernel logic bit for bit against the oracle where
+// no GPU exists.
+#ifndef MVO_HIP_EMU_RUNTIME_H
+#define MVO_HIP_EMU_RUNTIME_H
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <utility>
+
+#define MVO_KERNEL_SIM 1
+
+// ---------------------------------------------------------------------------------------------- language keywords
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local  // one OS thread per workgroup: thread-local = workgroup-local
+
+struct emu_uint3 {
+    unsigned x, y, z;
+};
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern thread_local emu_uint3 threadIdx, blockIdx, blockDim, gridDim;
+
+// ---------------------------------------------------------------------------------------------- scheduler entry points
+void emu_syncthreads();
+void emu_wave_sync();   // rendez-vous of the (live) lanes of the calling fiber's wave
+void emu_yield();       // polling pause: lets the other fibers of the workgroup (and the other workgroups) run
+long long emu_clock();
+// per-wave exchange area (valid between two emu_wave_sync of one operation)
+struct EmuWaveBuf {
+    unsigned long long u64[64];
+    double d[64][6];
+};
+EmuWaveBuf& emu_wave_buf();
+inline int emu_lane() { return (int)(threadIdx.x & 63u); }
+
+#define __syncthreads() emu_syncthreads()
+
+// ---------------------------------------------------------------------------------------------- wave operations
+inline unsigned long long emu_exchange_u64(unsigned long long v, int src_lane) {
+    EmuWaveBuf& b = emu_wave_buf();
+    b.u64[emu_lane()] = v;
+    emu_wave_sync();
+    const unsigned long long r = b.u64[src_lane & 63];
+    emu_wave_sync();
+    return r;
+}
+inline double __shfl_xor(double v, int mask) {
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    u = emu_exchange_u64(u, emu_lane() ^ mask);
+    memcpy(&v, &u, 8);
+    return v;
+}
+inline int __shfl_xor(int v, int mask) { return (int)emu_exchange_u64((unsigned)v, emu_lane() ^ mask); }
+inline int __shfl(int v, int src) { return (int)emu_exchange_u64((unsigned)v, src); }
+inline double __shfl(double v, int src) {
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    u = emu_exchange_u64(u, src);
+    memcpy(&v, &u, 8);
+    return v;
+}
+inline unsigned long long __ballot(int pred) {
+    EmuWaveBuf& b = emu_wave_buf();
+    b.u64[emu_lane()] = pred ? 1ull : 0ull;
+    emu_wave_sync();
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i) m |= (b.u64[i] & 1ull) << i;
+    emu_wave_sync();
+    return m;
+}
+#define __builtin_amdgcn_readlane(v, src) ((int)emu_exchange_u64((unsigned)(v), (src)))
+#define __builtin_amdgcn_readfirstlane(v) ((int)emu_exchange_u64((unsigned)(v), 0))
+#define __builtin_amdgcn_wave_barrier() emu_wave_sync()
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) emu_yield()
+#define __builtin_amdgcn_s_memtime() ((unsigned long long)emu_clock())
+// v_rcp_f64 is an approximation that the callers refine by Newton steps to the correctly rounded quotient; starting the
+// refinement from the correctly rounded value ends on the same bits
+#define __builtin_amdgcn_rcp(d) (1.0 / (d))
+
+typedef double emu_v4d __attribute__((ext_vector_type(4)));
+// D = A (16 x 4) * B (4 x 16) + C: lane (k = lane >> 4, i = lane & 15) supplies A[i][k] and B[k][i]; register r of lane
+// (q = lane >> 4, j = lane & 15) holds D[4 r + q][j].  Per element: fused multiply-adds over k = 0..3 in order.
+inline emu_v4d emu_mfma_f64_16x16x4(double a, double b, emu_v4d c) {
+    EmuWaveBuf& w = emu_wave_buf();
+    const int lane = emu_lane();
+    w.d[lane][0] = a;
+    w.d[lane][1] = b;
+    emu_wave_sync();
+    const int q = lane >> 4, j = lane & 15;
+    emu_v4d r;
+    for (int reg = 0; reg < 4; ++reg) {
+        const int i = 4 * reg + q;
+        double acc = c[reg];
+        for (int k = 0; k < 4; ++k) acc = __builtin_fma(w.d[16 * k + i][0], w.d[16 * k + j][1], acc);
+        r[reg] = acc;
+    }
+    emu_wave_sync();
+    return r;
+}
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4((a), (b), (c))
+
+// ---------------------------------------------------------------------------------------------- scalar helpers
+inline int __double2loint(double v) {
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    return (int)(unsigned)(u & 0xffffffffull);
+}
+inline int __double2hiint(double v) {
+    unsigned long long u;
+    memcpy(&u, &v, 8);
+    return (int)(unsigned)(u >> 32);
+}
+inline double __hiloint2double(int hi, int lo) {
+    const unsigned long long u = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    double v;
+    memcpy(&v, &u, 8);
+    return v;
+}
+inline long long __double_as_longlong(double v) {
+    long long u;
+    memcpy(&u, &v, 8);
+    return u;
+}
+inline double __longlong_as_double(long long u) {
+    double v;
+    memcpy(&v, &u, 8);
+    return v;
+}
+using std::max;
+using std::min;
+inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
+inline size_t min(size_t a, int b) { return a < (size_t)b ? a : (size_t)b; }
+inline size_t max(size_t a, int b) { return a > (size_t)b ? a : (size_t)b; }
+
+// ---------------------------------------------------------------------------------------------- atomics
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __HIP_MEMORY_SCOPE_SYSTEM 4
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_load(p, order, scope) __atomic_load_n((p), __ATOMIC_RELAXED)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
+#define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), __ATOMIC_RELAXED)
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+// ---------------------------------------------------------------------------------------------- host runtime subset
+typedef int hipError_t;
+#define hipSuccess 0
+#define hipErrorInvalidValue 1
+#define hipErrorNotReady 600
+struct EmuStream;
+struct EmuEvent;
+typedef EmuStream* hipStream_t;
+typedef EmuEvent* hipEvent_t;
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocMapped = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyHostToHost = 0 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+hipError_t hipSetDevice(int);
+hipError_t hipGetDeviceCount(int*);
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t);
+hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int device);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamQuery(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipMalloc(void** p, size_t bytes);
+hipError_t hipFree(void* p);
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostFree(void* p);
+hipError_t hipMemsetAsync(void* p, int v, size_t bytes, hipStream_t s);
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+// A launch: `body` is executed by every GPU thread of the grid; asynchronous on `stream` like the real thing.
+void emu_launch(std::function<void()> body, dim3 grid, dim3 block, size_t dyn_lds_bytes, hipStream_t stream);
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+    emu_launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (lds), (stream))
+// dynamic LDS segment of the calling workgroup
+void* emu_dyn_lds();
+
+#endif

@@ -1,0 +1,96 @@
+"""The bundle-adjustment kernel SOURCE (csrc/ba_kernels.hip) and its host side (csrc/ba_host.cpp, csrc/mvo_api_ba.cpp),
+compiled for x86 against tests/sim/hip_emu and executed thread for thread on the CPU: every GPU thread of k_ba_lm is a
+fiber, every workgroup an OS thread, wave operations (shuffles, v_readlane, the f64 MFMA) are rendez-vous points, the
+cross-workgroup hand-offs go through real shared memory.  The result must equal the oracle's blocked restatement BIT FOR
+BIT -- the same check tests/test_gpu_ba.py::test_bitwise_* makes on the MI355X, available where no GPU exists
+(pytest -m "not gpu").  The emulation is a test aid: nothing of it is linked into libmvo_hip.so (test_abi.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_gpu_ba import _args, _bitwise, _fix
+
+SIM_DIR = os.path.join(ROOT, "tests", "sim")
+SIM_LIB = os.path.join(SIM_DIR, "_build", "libmvo_ba_sim.so")
+
+
+@pytest.fixture(scope="module")
+def simlib():
+    subprocess.check_call(["make", "-C", SIM_DIR, "-s", "-j4"])
+    lib = C.CDLL(SIM_LIB)
+    lib.mvo_last_error.restype = C.c_char_p
+    lib.mvo_destroy.restype = None
+    return lib
+
+
+@pytest.fixture()
+def simctx(mvo, simlib):
+    class SimContext(mvo.Context):  # the ctypes mirror of the C-ABI, bound to the emulated build of the BA sources
+        def __init__(self):
+            self.lib = simlib
+            h = C.c_void_p()
+            assert simlib.mvo_create(C.byref(h), 0) == 0
+            self.h, self.device, self.params = h, 0, {}
+
+    c = SimContext()
+    yield c
+    simlib.mvo_debug_set(b"ba_wgs", 0)
+    simlib.mvo_debug_set(b"ba_mfma", 1)
+    c.close()
+
+
+def test_kernel_source_reproduces_the_blocked_oracle_on_the_benchmarked_window(mvo, O, simctx):
+    """BA5 as bench.py solves it: 5 poses / 2000 landmarks / ~9.4k edges, no fixed vertex, 32 workgroups x 512 threads,
+    all 50 iterations, every trial's lambda / chi2 / rho / decision, final poses and landmarks: zero difference."""
+    st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
+    assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 32
+
+
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("case", ["pose_only", "anchored", "fixed0_info", "tiny_one_range", "ragged_chain_tails", "dups"])
+def test_kernel_source_variants(mvo, O, simctx, simlib, case, mfma):
+    simlib.mvo_debug_set(b"ba_mfma", mfma)
+    if case == "pose_only":
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
+    elif case == "anchored":
+        pb = mvo.synth.ba_problem(5, 1000, 7)
+        pb["poses0"][:2] = pb["poses_gt"][:2]
+        _bitwise(mvo, O, simctx, pb, fix_points=False, pose_fixed=_fix(5, 2))
+    elif case == "fixed0_info":
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(4, 700, 21), fix_points=False, pose_fixed=_fix(4, 1),
+                 info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5)
+    elif case == "tiny_one_range":
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(3, 40, 5), fix_points=False)
+        assert plan["wgs"] == 1
+    elif case == "ragged_chain_tails":
+        for L in (37, 41, 42, 43, 150):
+            _bitwise(mvo, O, simctx, mvo.synth.ba_problem(3, L, 100 + L), fix_points=False, max_iterations=6)
+            _bitwise(mvo, O, simctx, mvo.synth.ba_problem(3, L, 200 + L), fix_points=False, max_iterations=6, pose_fixed=_fix(3, 1))
+    else:
+        pb = mvo.synth.ba_problem(3, 300, 6)
+        pb = dict(pb, edge_pose=np.concatenate([pb["edge_pose"], pb["edge_pose"][:90]]),
+                  edge_point=np.concatenate([pb["edge_point"], pb["edge_point"][:90]]),
+                  edge_uv=np.concatenate([pb["edge_uv"], pb["edge_uv"][:90] + 0.3]))
+        _bitwise(mvo, O, simctx, pb, fix_points=False, pose_fixed=_fix(3, 1))
+
+
+@pytest.mark.parametrize("order", ["reverse", "shuffle"])
+def test_result_does_not_depend_on_the_thread_order(mvo, O, simctx, order, monkeypatch):
+    """A missing barrier / hand-off shows as a result that depends on the order in which the emulated threads of a
+    workgroup run between two rendez-vous points."""
+    monkeypatch.setenv("EMU_ORDER", order)
+    _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 600, 3), fix_points=False, max_iterations=10)
+    _bitwise(mvo, O, simctx, mvo.synth.ba_problem(4, 300, 4), fix_points=True, max_iterations=10)
+
+
+def test_batched_windows_equal_their_single_solves(mvo, simctx):
+    pbs = [mvo.synth.ba_problem(5, 600, 7), mvo.synth.ba_problem(3, 300, 11), mvo.synth.ba_problem(4, 400, 21),
+           mvo.synth.ba_problem(3, 40, 77)]
+    singles = [simctx.bundle_adjustment(*_args(pb), fix_points=False, max_iterations=8) for pb in pbs]
+    batch = simctx.ba_solve_batch([_args(pb) for pb in pbs], fix_points=False, max_iterations=8)
+    for (P, X, st), (Pb, Xb, stb) in zip(singles, batch):
+        assert np.array_equal(P, Pb) and np.array_equal(X, Xb) and st["trials"] == stb["trials"]
