@@ -147,6 +147,14 @@ typedef struct {
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317; caller VisualOdometry::callBundleAdjustment_,
  * src/vo/vo.cpp:458-462). */
 int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
+/* How a window is cut into workgroups (no reference counterpart: g2o is single-threaded).  LATENCY (default): about 300
+ * observations per workgroup -- the 5-keyframe window of the benchmark runs on the 32 CUs of one XCD, shortest solve.
+ * THROUGHPUT: about 600 per workgroup -- half the CUs per window at ~15 % more time per solve, for callers that keep many
+ * sequences in flight on one GPU.  The summation order (hence the last bits of the result) follows the cut; every cut is
+ * deterministic and is what mvo_debug_get_ba_plan reports. */
+#define MVO_BA_MODE_LATENCY 0
+#define MVO_BA_MODE_THROUGHPUT 1
+int mvo_ba_set_mode(mvo_ctx* ctx, int mode);
 
 /* The same call in two halves, so that the host thread can do other work (e.g. extract the next frame on another
  * ctx) while the window is being solved: _begin builds the window, uploads it and queues the launch, _end blocks

@@ -45,8 +45,9 @@ struct Carver {
 
 // Everything the host computes for one window; offsets are relative to the start of the device block.
 struct BaPlan {
-    int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, ldu = 16,
-        nhp = 1, maxEg = 0, maxLg = 0, has_dups = 0, fix_points = 0;
+    int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
+        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0;
+    size_t uarea = 0;
     size_t lds = 0;
     std::vector<int> wg_pt;
     // device block layout
@@ -296,8 +297,6 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // packed entries of the reduced system; the exchange rows also hold the pose-block partials that ride along
     const int nlow = n * (n + 1) / 2 + n, npk = std::max(16, (nlow + nhp + 15) & ~15);
     const bool do_schur = !p->fix_points && n > 0;
-    int nsplit = do_schur ? std::max(1, BA_WAVES / npair) : 1;
-    if (const char* env = std::getenv("MVO_BA_NSPLIT")) nsplit = std::max(1, std::min(nsplit, std::atoi(env)));
     P.F = F;
     P.L = L;
     P.E = E;
@@ -307,20 +306,26 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.npair = npair;
     P.nlow = nlow;
     P.npk = npk;
-    P.nsplit = nsplit;
     P.ldu = ldu;
     P.nhp = nhp;
     P.fix_points = p->fix_points ? 1 : 0;
     P.runnable = !(F == 0 && (L == 0 || p->fix_points)) && (nfree > 0 || !p->fix_points);
-    // ---- choose G and the landmark ranges (balanced by edge count); the slice of every workgroup must fit in LDS
+    // ---- choose G and the landmark ranges (balanced by edge count).  A range's per-edge Jacobian rows live in the
+    // registers of its 512 threads (BA_EDGE_SLOTS each), its landmark state and one chunk of the Schur operands in LDS.
+    // Latency mode (default): ~300 edges per workgroup, i.e. 32 workgroups = one XCD for the 5-keyframe window of the
+    // benchmark; throughput mode: ~600 edges per workgroup, half the CUs per window at ~15 % more time per solve.
+    const int edges_per_wg = ctx->ba_throughput_mode ? 320 : 160;
     int G = 1;
-    while (G < 32 && E > 160 * G) G *= 2;  // aim at 160-320 edges per workgroup
+    while (G < 32 && E > edges_per_wg * G) G *= 2;
     if (g_ba_wgs > 0) G = g_ba_wgs;
     if (const char* env = std::getenv("MVO_BA_WGS")) G = std::max(1, std::atoi(env));
     G = std::max(1, std::min(G, BA_MAX_WGS));
+    int env_nsplit = 0;
+    if (const char* env = std::getenv("MVO_BA_NSPLIT")) env_nsplit = std::max(1, std::atoi(env));
     std::vector<int>& wg_pt = P.wg_pt;
-    std::vector<int> wg_edge;
-    int maxEg = 0, maxLg = 0;
+    std::vector<int> wg_edge, owner(L, 0), wg_pose;
+    int maxEg = 0, maxLg = 0, maxEpose = 0, nsplit = 1, npar = 1, nseq = 1;
+    size_t uarea = 0;
     for (;;) {
         wg_pt.assign(G + 1, 0);
         wg_edge.assign(G + 1, 0);
@@ -338,33 +343,53 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
             maxEg = std::max(maxEg, wg_edge[g + 1] - wg_edge[g]);
             maxLg = std::max(maxLg, wg_pt[g + 1] - wg_pt[g]);
         }
-        P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, nsplit, ldu, nfree, maxEg, maxLg, p->fix_points);
-        if (P.lds <= BA_LDS_BUDGET && maxEg < 32000 && maxLg < 32000) break;
+        // edges per (range, pose): the pose-block chains stage whole poses
+        for (int g = 0; g < G; ++g)
+            for (int ll = wg_pt[g]; ll < wg_pt[g + 1]; ++ll) owner[ll] = g;
+        wg_pose.assign((size_t)G * (F + 1), 0);
+        {
+            std::vector<int> cnt((size_t)G * std::max(F, 1), 0);
+            for (int e : act) cnt[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
+            int acc = 0;
+            maxEpose = 0;
+            for (int g = 0; g < G; ++g) {
+                for (int q = 0; q < F; ++q) {
+                    wg_pose[(size_t)g * (F + 1) + q] = acc;
+                    acc += cnt[(size_t)g * F + q];
+                    maxEpose = std::max(maxEpose, cnt[(size_t)g * F + q]);
+                }
+                wg_pose[(size_t)g * (F + 1) + F] = acc;
+            }
+        }
+        // column pieces of the Schur chains: with one chunk, as many pieces side by side as there are idle waves; otherwise
+        // one piece per chunk, as few chunks as the LDS budget allows (a wave keeps the running sums of <= 2 tile pairs)
+        const int msteps = (3 * maxLg + 3) / 4;
+        bool fits = false;
+        const int max_seq = (do_schur && npair <= 16) ? 8 : 1;
+        for (int q = 1; q <= max_seq && !fits; ++q) {
+            nseq = q;
+            npar = (do_schur && q == 1) ? std::max(1, BA_WAVES / npair) : 1;
+            if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
+            nsplit = nseq * npar;
+            const int msplit = (msteps + nsplit - 1) / nsplit;
+            uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, maxEg, maxEpose, nhp, G, p->fix_points);
+            P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea);
+            fits = P.lds <= BA_LDS_BUDGET;
+        }
+        if (fits && maxEg <= BA_EDGE_SLOTS * BA_THREADS && maxLg < 32000) break;
         if (G >= BA_MAX_WGS)
             return mvo_set_err(ctx, MVO_ERR_CAPACITY, "BA window too large for the LDS-resident solver", hipSuccess);
         G = std::min(2 * G, BA_MAX_WGS);
     }
+    P.nsplit = nsplit;
+    P.npar = npar;
+    P.nseq = nseq;
+    P.uarea = uarea;
     P.G = G;
     P.maxEg = maxEg;
     P.maxLg = maxLg;
     P.slice = (nlow + G - 1) / G;
     // ---- edges sorted by (owner workgroup, pose); adjacency tables
-    std::vector<int> owner(L, 0);
-    for (int g = 0; g < G; ++g)
-        for (int l = wg_pt[g]; l < wg_pt[g + 1]; ++l) owner[l] = g;
-    std::vector<int> wg_pose((size_t)G * (F + 1), 0);
-    {
-        std::vector<int> cnt((size_t)G * std::max(F, 1), 0);
-        for (int e : act) cnt[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
-        int acc = 0;
-        for (int g = 0; g < G; ++g) {
-            for (int q = 0; q < F; ++q) {
-                wg_pose[(size_t)g * (F + 1) + q] = acc;
-                acc += cnt[(size_t)g * F + q];
-            }
-            wg_pose[(size_t)g * (F + 1) + F] = acc;
-        }
-    }
     std::vector<int> e_pose(E), e_point(E), ptstart(L + 1, 0), ptlist(E);
     std::vector<double> e_uv(2 * (size_t)E);
     {
@@ -385,18 +410,22 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         std::vector<int> cur(ptstart.begin(), ptstart.end() - 1);
         for (int k = 0; k < E; ++k) ptlist[cur[e_point[k]]++] = k;
     }
-    std::vector<short> eof((size_t)std::max(L, 1) * std::max(nfree, 1), -1), dup(std::max(E, 1), -1);
-    int has_dups = 0;
-    for (int k = E - 1; k >= 0; --k) {  // descending so that the chains run in ascending edge order
-        const int sl = pose_slot[e_pose[k]];
-        if (sl < 0) continue;
-        const int lk = k - wg_edge[owner[e_point[k]]];
-        short& head = eof[(size_t)e_point[k] * nfree + sl];
-        dup[k] = head;
-        if (head >= 0) has_dups = 1;
-        head = (short)lk;
+    // first observation of every (landmark, pose slot) pair and the rank of every edge among the observations of its pair
+    // (ascending edge order: the order in which the oracle adds them)
+    std::vector<short> eof((size_t)std::max(L, 1) * std::max(nfree, 1), -1), dup(std::max(E, 1), 0);
+    int max_dup = 0;
+    {
+        std::vector<short> seen((size_t)std::max(L, 1) * std::max(nfree, 1), 0);
+        for (int k = 0; k < E; ++k) {
+            const int sl = pose_slot[e_pose[k]];
+            if (sl < 0) continue;
+            const size_t q = (size_t)e_point[k] * nfree + sl;
+            if (eof[q] < 0) eof[q] = (short)(k - wg_edge[owner[e_point[k]]]);
+            dup[k] = seen[q]++;
+            max_dup = std::max(max_dup, (int)dup[k]);
+        }
     }
-    P.has_dups = has_dups;
+    P.max_dup = max_dup;
     // ---- packed order of the reduced system and its place inside the 16 x 16 tile pairs
     std::vector<short> pkt((size_t)npair * 256, -1);
     {
@@ -485,11 +514,14 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.max_it = p->max_iterations;
     B.maxEg = maxEg;
     B.maxLg = maxLg;
-    B.has_dups = has_dups;
+    B.max_dup = max_dup;
     B.nlow = nlow;
     B.npk = npk;
     B.slice = P.slice;
     B.nsplit = nsplit;
+    B.npar = npar;
+    B.nseq = nseq;
+    B.uarea = (int)uarea;
     B.ldu = ldu;
     B.nhp = nhp;
     B.f = p->focal;
@@ -512,7 +544,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.pt_edge_start = (const int*)(D + P.o_ptstart);
     B.pt_edge_list = (const int*)(D + P.o_ptl);
     B.eof = (const short*)(D + P.o_eof);
-    B.dup_next = (const short*)(D + P.o_dup);
+    B.dup_rank = (const short*)(D + P.o_dup);
     B.pose_slot = (const int*)(D + P.o_slot);
     B.slot_pose = (const int*)(D + P.o_sp);
     B.pk_of_tile = (const short*)(D + P.o_pkt);

@@ -532,26 +532,29 @@ __device__ __forceinline__ void packed_ij(int idx, int n, int& i, int& j) {
     }
 }
 
-// LDS layout of one workgroup, carved from the dynamic segment.
+// LDS layout of one workgroup, carved from the dynamic segment.  What a workgroup keeps for the lifetime of the launch is
+// per LANDMARK (position + backup, H_ll, b_l, C, C^T b_l) and a few bytes per edge (measured pixel, indices); the
+// whitened Jacobian rows of an edge -- A~ (2 x 6) and X~ (2 x 3) -- live in the REGISTERS of the thread that owns the
+// edge (edge el < 512: thread el; the edges behind 512 of a fuller range keep theirs in the E2 area) and visit LDS only as
+// staging copies for the two phases that read them across threads (landmark blocks, pose-block chains).  `U` is a multi-purpose area: staging during linearisation, one
+// chunk of the Schur operands at a time during a trial, the per-edge back-substitution terms afterwards.
 struct WgLds {
-    double* SL;     // reduced system / transposed L
+    double* SL;     // reduced system / transposed L; split-chain tiles and the slice reduction are staged here as well
     double* colbuf; // 2 x 64 column broadcast + 64 scratch
     double* Rl;     // nlow + nhp (+16) packed entries of the summed Schur system (+ pose blocks)
-    double* hpl;    // nhp own pose-block partials waiting for the next Schur exchange
-    double* M;      // maxEg x 14
-    double* uv;     // maxEg x 2
+    double* hpl;    // nhp own pose-block partials (waiting for the next Schur exchange, or the only ones when G = 1)
+    double* uv;     // maxEg x 2 (u and v in separate arrays)
     double* pts;    // maxLg x 3
-    double* X;      // maxEg x 6   X~ = sqrt(rho') Lc J_point
     double* bak;    // maxLg x 3
-    double* Hll;    // maxLg x 6
+    double* Hll;    // maxLg x 6 (pitch BA_XS)
     double* bl;     // maxLg x 3
-    double* Cc;     // maxLg x 6   Cholesky factor of (H_ll + lambda I)^-1
+    double* Cc;     // maxLg x 6 (pitch BA_XS)   Cholesky factor of (H_ll + lambda I)^-1
     double* cl;     // maxLg x 3   C^T b_l
-    double* rr;     // maxLg x 3   C^T (b_l - W^T dx_p)
-    double* U;      // 3 maxLg columns x ldu rows: U_l = [W_l C_l ; (C_l^T b_l)^T ; 0]; also the exchange staging
+    double* U;      // `uarea` doubles: see above
+    double* E2;     // (maxEg - 512) x BA_E2S: rows [a0 | a1 | x] of the edges 512 .. Eg - 1
     short* epose;   // maxEg
     short* ept;     // maxEg  local landmark index
-    short* dup;     // maxEg  next local edge with the same (landmark, pose)
+    short* dup;     // maxEg  rank of the edge among the observations of its (landmark, pose): 0 for the first
     short* ptl;     // maxEg  local edge indices grouped by landmark
     short* pts0;    // maxLg + 1 offsets into ptl
     short* eof;     // maxLg x nfree
@@ -662,13 +665,29 @@ __device__ __forceinline__ v4d schur_chain(const double* U, int ldu, int ti, int
     return acc;
 }
 
+// The whitened Jacobian rows of one edge as its owner thread keeps them between the linearisation and the end of the
+// iteration's trials (EdgeProjectXYZ2UV::linearizeOplus with sqrt(rho') Lc folded in).
+struct EdgeRegs {
+    double a0[6], a1[6];  // A~ = sqrt(rho') Lc J_pose (2 x 6); zero for a fixed pose
+    double x[6];          // X~ = sqrt(rho') Lc J_point (2 x 3)
+};
+// Y = X~ C (2 x 3) for the lower-triangular C = {c00, c10, c11, c20, c21, c22}
+__device__ __forceinline__ void edge_Y(const EdgeRegs& r, const double* cc, double* Y) {
+    const double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4], c5 = cc[5];
+    Y[0] = r.x[0] * c0 + r.x[1] * c1 + r.x[2] * c3;
+    Y[1] = r.x[1] * c2 + r.x[2] * c4;
+    Y[2] = r.x[2] * c5;
+    Y[3] = r.x[3] * c0 + r.x[4] * c1 + r.x[5] * c3;
+    Y[4] = r.x[4] * c2 + r.x[5] * c4;
+    Y[5] = r.x[5] * c5;
+}
+
 // PROF: per-phase cycle counters; NR: reduced-solve flavour -- 32 / 64: register solver for n + 1 <= NR rows, 0: LDS
-// solver (any n).  Separate instantiations: the 64-row solver needs every VGPR of the wave and would push the LM
-// loop of the common 5-pose window into scratch.
+// solver (any n).  Separate instantiations: the solvers differ widely in register use.
 template <bool PROF, int NR>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
-    // window = blockIdx % stride; stride = 8 (windows of <= 32 workgroups): with the dispatcher's round-robin
-    // placement the workgroups of a window then share one XCD (one L2)
+    // window = blockIdx % stride; the stride is a multiple of 8 whenever several windows share a launch: with the
+    // dispatcher's round-robin placement (block b on XCD b % 8) the workgroups of a window then share one XCD (one L2)
     const int win = blockIdx.x % batch.stride;
     const int g = blockIdx.x / batch.stride;
     if (win >= batch.nwin) return;
@@ -713,25 +732,19 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     {
         double* d = dyn + ba_pose_doubles(B.F) + 2 * (size_t)G + 8;
         W.SL = d;
-        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.nsplit) - 3 * 64;
+        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar) - 3 * 64;
         W.colbuf = d;
         d += 3 * 64;
         W.Rl = d;
         d += nlow + B.nhp + 16;
         W.hpl = d;
         d += B.nhp + 1;
-        W.M = d;
-        d += (size_t)B.maxEg * BA_MSTRIDE;
         W.uv = d;
         d += (size_t)B.maxEg * 2;
         W.pts = d;
         d += (size_t)B.maxLg * 3;
         // (sizes are zero in pose-only mode: every pointer stays an LDS address, no null pointers in this struct)
-        // pose-block exchange staging (<= 4096 values at a time): inside the U buffer, or its own area
-        const size_t st = (size_t)B.nhp * (size_t)min(G, max(1, 4096 / B.nhp));
         const size_t full = B.fix_points ? 0 : 1;
-        W.X = d;
-        d += full * B.maxEg * BA_XS;
         W.bak = d;
         d += full * B.maxLg * 3;
         W.Hll = d;
@@ -742,12 +755,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         d += full * B.maxLg * BA_XS;
         W.cl = d;
         d += full * B.maxLg * 3;
-        W.rr = d;
-        d += full * B.maxLg * 3;
         W.U = d;
         stage = d;
-        const size_t u = full * (3 * B.maxLg + 3) * ldu;  // (+ up to three zero columns behind the last landmark)
-        d += u > st ? u : st;
+        d += B.uarea;
+        W.E2 = d;
+        d += (size_t)max(0, B.maxEg - BA_THREADS) * BA_E2S;
         short* s = reinterpret_cast<short*>(d);
         W.epose = s;
         s += B.maxEg;
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     for (int el = tid; el < Eg; el += BA_THREADS) {
         W.epose[el] = (short)B.e_pose[e_lo + el];
         W.ept[el] = (short)(B.e_point[e_lo + el] - pt_lo);
-        W.dup[el] = B.dup_next[e_lo + el];
+        W.dup[el] = B.dup_rank[e_lo + el];
         W.ptl[el] = (short)(B.pt_edge_list[e_lo + el] - e_lo);
         W.uv[el] = B.e_uv[2 * (size_t)(e_lo + el)];  // (u and v in separate arrays)
         W.uv[B.maxEg + el] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
@@ -823,125 +835,124 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     const bool any_free = nfree > 0 || !B.fix_points;
     const bool do_schur = !B.fix_points && n > 0;
     const int slice = B.slice;
-    // where the entries of this wave's first Schur chain go in the packed order (constant for the whole solve)
-    const short* pkt_g = B.pk_of_tile;
-    int pk4[4] = {-1, -1, -1, -1};
-    if (do_schur && wave < B.npair * B.nsplit) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pk4[j] = pkt_g[(wave % B.npair) * 256 + ((lane >> 4) + 4 * j) * 16 + (lane & 15)];
-    }
+    // ---- the Schur chains of this workgroup: `nsplit` consecutive column pieces of `msplit` MFMA steps each, `npar` of
+    // them side by side (on different waves) per chunk of the U area, `nseq` chunks one after the other
+    const int npar = B.npar, nseq = B.nseq;
     const int ncol = 3 * Lg;
     const int msteps = (ncol + 3) / 4;
     const int msplit = (msteps + B.nsplit - 1) / B.nsplit;
+    const int chunk_cols = 4 * npar * msplit;
+    // where the entries of this wave's first Schur chain go in the packed order (constant for the whole solve)
+    const short* pkt_g = B.pk_of_tile;
+    int pk4[4] = {-1, -1, -1, -1};
+    if (do_schur && wave < B.npair * npar) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pk4[j] = pkt_g[(wave % B.npair) * 256 + ((lane >> 4) + 4 * j) * 16 + (lane & 15)];
+    }
+    // ---- this thread's edges: edge `tid` (rows in registers) and, in ranges with more than 512 edges, edge tid + 512
+    // (rows in the E2 area)
+    EdgeRegs er;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) er.a0[c] = er.a1[c] = er.x[c] = 0;
+    const bool have0 = tid < Eg, have1 = tid + BA_THREADS < Eg;
+    const int e0_p = have0 ? W.epose[tid] : 0, e0_l = have0 ? W.ept[tid] : 0, e0_sl = have0 ? sSlot[e0_p] : -1;
+    const int e1_p = have1 ? W.epose[tid + BA_THREADS] : 0, e1_l = have1 ? W.ept[tid + BA_THREADS] : 0,
+              e1_sl = have1 ? sSlot[e1_p] : -1;
+    const int nslot = Eg > BA_THREADS ? 2 : 1;  // (uniform)
+// BA_FOR_EDGES ... BA_END_EDGES: the loop over this thread's (at most two) edges with `el` = local edge index, `r` = its
+// rows, `e_l` / `e_sl` = its landmark / pose slot.  One copy of the body, not unrolled: the kernel is short of registers,
+// not of time here.  (Spelled as a macro, element by element: behind a lambda capture the compiler parks the register-
+// resident rows in scratch memory.)
+#define BA_FOR_EDGES                                                         \
+    _Pragma("unroll 1") for (int s_ = 0; s_ < nslot; ++s_) {                 \
+        if (s_ == 0 ? !have0 : !have1) continue;                             \
+        EdgeRegs r;                                                          \
+        {                                                                    \
+            const double* q_ = W.E2 + BA_E2S * tid;                          \
+            _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {               \
+                r.a0[c_] = s_ ? q_[c_] : er.a0[c_];                          \
+                r.a1[c_] = s_ ? q_[6 + c_] : er.a1[c_];                      \
+                r.x[c_] = s_ ? q_[12 + c_] : er.x[c_];                       \
+            }                                                                \
+        }                                                                    \
+        const int el = tid + s_ * BA_THREADS, e_l = s_ ? e1_l : e0_l, e_sl = s_ ? e1_sl : e0_sl;
+#define BA_END_EDGES }
 
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
-        // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus)
+        // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus), kept in registers;
+        // X~ and e~ also go to the staging area for the landmark blocks
         PH_BEGIN();
-        for (int el = tid; el < Eg; el += BA_THREADS) {
-            double Xc[3], ew[2], r0, r1;
-            const double chi = edge_error(B, W, el, sR, sT, Xc, ew);
-            huber(chi, B.delta, r0, r1);
-            const double sw = sqrt(r1);
-            const int p = W.epose[el];
-            const double x = Xc[0], y = Xc[1], z = Xc[2], z2 = z * z, f = B.f;
-            double* Mr = W.M + BA_MSTRIDE * el;
-            if (sSlot[p] >= 0) {
-                const double J0[6] = {x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f};
-                const double J1[6] = {(1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f};
+        double ee0[2] = {0, 0}, ee1[2] = {0, 0};  // e~ of the two edges (needed again when the chain rows are staged)
+#pragma unroll 1
+        for (int s = 0; s < nslot; ++s) {
+            if (s == 0 ? !have0 : !have1) continue;
+            const int el = tid + s * BA_THREADS, p = s ? e1_p : e0_p, sl = s ? e1_sl : e0_sl;
+            EdgeRegs r;
+            double ee[2];
+            {
+                double Xc[3], ew[2], r0, r1;
+                const double chi = edge_error(B, W, el, sR, sT, Xc, ew);
+                huber(chi, B.delta, r0, r1);
+                const double sw = sqrt(r1);
+                const double x = Xc[0], y = Xc[1], z = Xc[2], z2 = z * z, f = B.f;
+                if (sl >= 0) {
+                    const double J0[6] = {x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f};
+                    const double J1[6] = {(1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f};
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        r.a0[c] = sw * (B.lc00 * J0[c] + B.lc01 * J1[c]);
+                        r.a1[c] = sw * (B.lc11 * J1[c]);
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) r.a0[c] = r.a1[c] = 0;
+                }
+                ee[0] = sw * ew[0];
+                ee[1] = sw * ew[1];
+#pragma unroll
+                for (int c = 0; c < 6; ++c) r.x[c] = 0;
+                if (!B.fix_points) {
+                    const double* R = sR + 9 * p;
+                    const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};
+                    double* Xs = stage + BA_SXS * el;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);
+                        double j1 = -1. / z * (t1[0] * R[c] + t1[1] * R[3 + c] + t1[2] * R[6 + c]);
+                        r.x[c] = sw * (B.lc00 * j0 + B.lc01 * j1);
+                        r.x[3 + c] = sw * (B.lc11 * j1);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) Xs[c] = r.x[c];
+                    Xs[6] = ee[0];
+                    Xs[7] = ee[1];
+                }
+            }
+            if (s == 0) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) er.a0[c] = r.a0[c], er.a1[c] = r.a1[c], er.x[c] = r.x[c];
+                ee0[0] = ee[0], ee0[1] = ee[1];
+            } else {
+                ee1[0] = ee[0], ee1[1] = ee[1];
+                double* q = W.E2 + BA_E2S * tid;
 #pragma unroll
                 for (int c = 0; c < 6; ++c) {
-                    Mr[c] = sw * (B.lc00 * J0[c] + B.lc01 * J1[c]);
-                    Mr[7 + c] = sw * (B.lc11 * J1[c]);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) Mr[c] = Mr[7 + c] = 0;
-            }
-            Mr[6] = sw * ew[0];
-            Mr[13] = sw * ew[1];
-            if (!B.fix_points) {
-                const double* R = sR + 9 * p;
-                const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};
-                double* Xr = W.X + BA_XS * el;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);
-                    double j1 = -1. / z * (t1[0] * R[c] + t1[1] * R[3 + c] + t1[2] * R[6 + c]);
-                    Xr[c] = sw * (B.lc00 * j0 + B.lc01 * j1);
-                    Xr[3 + c] = sw * (B.lc11 * j1);
+                    q[c] = r.a0[c];
+                    q[6 + c] = r.a1[c];
+                    q[12 + c] = r.x[c];
                 }
             }
         }
         __syncthreads();
         PH_END(0);
-        // ================= pose blocks: partial [H_pp | -b_p] = M^T M over the own edges of every free pose: wave w
-        // runs the chains of the poses w, w + 8, ...: one MFMA per 4 rows (2 edges), rows in storage order
-        // From the second iteration on the pose-block partials ride along with the first Schur exchange of the iteration
-        // (one all-to-all less per iteration); iteration 0 needs them earlier (lambda_0 = tau max |diag H|) and pose-only
-        // windows have no Schur exchange: those use the exchange of their own below.
-        const bool hp_deferred = do_schur && G > 1 && it > 0;
-        if (!hp_deferred) ++tagH;
-        {
-            const int col = lane & 15;
-            for (int p = wave; p < B.F; p += BA_WAVES) {
-                const int sl = sSlot[p];
-                if (sl < 0) continue;
-                const int s = sPoseStart[p], e = sPoseStart[p + 1];
-                if (batch.use_mfma) {
-                    const int rows = 2 * (e - s), nfull = rows / 4;
-                    const bool cv = col < 7;
-                    // row 2 s + 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
-                    const double* pm = W.M + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? col : 0);
-                    v4d acc = {0, 0, 0, 0};
-                    int st = 0;
-                    for (; st + 4 <= nfull; st += 4) {
-                        const double v0 = pm[0], v1 = pm[2 * BA_MSTRIDE], v2 = pm[4 * BA_MSTRIDE], v3 = pm[6 * BA_MSTRIDE];
-                        const double w0 = cv ? v0 : 0.0, w1 = cv ? v1 : 0.0, w2 = cv ? v2 : 0.0, w3 = cv ? v3 : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, w2, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
-                        pm += 8 * BA_MSTRIDE;
-                    }
-                    for (; 4 * st < rows; ++st) {  // remaining steps, the last one possibly with fewer than 4 rows
-                        const bool ok = cv && 4 * st + (lane >> 4) < rows;
-                        const double v = ok ? pm[0] : 0.0;
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
-                        pm += 2 * BA_MSTRIDE;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int rg = (lane >> 4) + 4 * j;  // acc[j] = entry (rg, col)
-                        if (rg < 7 && col <= rg) {
-                            const int pk = rg * (rg + 1) / 2 + col;
-                            if (hp_deferred) W.hpl[BA_HP * sl + pk] = acc[j];
-                            else if (G > 1) gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
-                            else stage[BA_HP * sl + pk] = acc[j];
-                        }
-                    }
-                } else if (lane < BA_HP) {  // validation path: the same fma chains on the vector ALU
-                    int i = 0;
-                    while ((i + 1) * (i + 2) / 2 <= lane) ++i;
-                    const int j = lane - i * (i + 1) / 2;
-                    double acc = 0;
-                    for (int r = 2 * s; r < 2 * e; ++r)
-                        acc = __builtin_fma(W.M[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + i], W.M[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + j], acc);
-                    if (hp_deferred) W.hpl[BA_HP * sl + lane] = acc;
-                    else if (G > 1) gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + lane), tag0 + tagH, acc, same_l2);
-                    else stage[BA_HP * sl + lane] = acc;
-                }
-            }
-        }
-        PH_END(1);
-        // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks
+        // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks (from the staged X~, e~)
         double maxdiag = 0;
         if (!B.fix_points) {
             for (int l = tid; l < Lg; l += BA_THREADS) {
                 double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
                 for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
-                    const int el = W.ptl[k];
-                    const double* X = W.X + BA_XS * el;
-                    const double e0 = W.M[BA_MSTRIDE * el + 6], e1 = W.M[BA_MSTRIDE * el + 13];
+                    const double* X = stage + BA_SXS * W.ptl[k];
+                    const double e0 = X[6], e1 = X[7];
                     h[0] += X[0] * X[0] + X[3] * X[3];
                     h[1] += X[0] * X[1] + X[3] * X[4];
                     h[2] += X[0] * X[2] + X[3] * X[5];
@@ -958,14 +969,97 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 for (int i = 0; i < 3; ++i) W.bl[3 * l + i] = b[i];
                 maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
             }
+            __syncthreads();  // (the staged X~ are dead: the area now takes the rows of the pose-block chains)
         }
+        PH_END(2);
+        // ================= pose blocks: partial [H_pp | -b_p] = M^T M over the own edges of every free pose, M = the rows
+        // [A~ | e~] in storage order: one MFMA per 4 rows (2 edges).  The rows are staged pose group by pose group
+        // (as many consecutive poses as the area holds), wave w of a group runs the chains of its poses w, w + 8, ...
+        // From the second iteration on the pose-block partials ride along with the first Schur exchange of the iteration
+        // (one all-to-all less per iteration); iteration 0 needs them earlier (lambda_0 = tau max |diag H|) and pose-only
+        // windows have no Schur exchange: those use the exchange of their own below.
+        const bool hp_deferred = do_schur && G > 1 && it > 0;
+        const bool hp_local = hp_deferred || G == 1;  // results stay in this workgroup's hpl
+        if (!hp_deferred) ++tagH;
+        {
+            const int col = lane & 15;
+            const int mcap = (int)(B.uarea / BA_MSTRIDE);
+            for (int p0 = 0; p0 < B.F;) {
+                int p1 = p0 + 1;
+                while (p1 < B.F && sPoseStart[p1 + 1] - sPoseStart[p0] <= mcap) ++p1;
+                const int eg0 = sPoseStart[p0], eg1 = sPoseStart[p1];
+                if (eg1 - eg0 > mcap) error = 1;  // (the planner sizes the area for the largest pose of any range)
+                if (!error) {
+                    BA_FOR_EDGES
+                    (void)e_l, (void)e_sl;
+                    if (el < eg0 || el >= eg1) continue;
+                    double* Mr = stage + BA_MSTRIDE * (el - eg0);
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        Mr[c] = r.a0[c];
+                        Mr[7 + c] = r.a1[c];
+                    }
+                    Mr[6] = s_ ? ee1[0] : ee0[0];
+                    Mr[13] = s_ ? ee1[1] : ee0[1];
+                    BA_END_EDGES
+                }
+                __syncthreads();
+                for (int p = p0 + wave; p < p1 && !error; p += BA_WAVES) {
+                    const int sl = sSlot[p];
+                    if (sl < 0) continue;
+                    const int s = sPoseStart[p] - eg0, e = sPoseStart[p + 1] - eg0;
+                    if (batch.use_mfma) {
+                        const int rows = 2 * (e - s), nfull = rows / 4;
+                        const bool cv = col < 7;
+                        // row 2 s + 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
+                        const double* pm = stage + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? col : 0);
+                        v4d acc = {0, 0, 0, 0};
+                        int st = 0;
+                        for (; st + 4 <= nfull; st += 4) {
+                            const double v0 = pm[0], v1 = pm[2 * BA_MSTRIDE], v2 = pm[4 * BA_MSTRIDE], v3 = pm[6 * BA_MSTRIDE];
+                            const double w0 = cv ? v0 : 0.0, w1 = cv ? v1 : 0.0, w2 = cv ? v2 : 0.0, w3 = cv ? v3 : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, w2, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
+                            pm += 8 * BA_MSTRIDE;
+                        }
+                        for (; 4 * st < rows; ++st) {  // remaining steps, the last one possibly with fewer than 4 rows
+                            const bool ok = cv && 4 * st + (lane >> 4) < rows;
+                            const double v = ok ? pm[0] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
+                            pm += 2 * BA_MSTRIDE;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int rg = (lane >> 4) + 4 * j;  // acc[j] = entry (rg, col)
+                            if (rg < 7 && col <= rg) {
+                                const int pk = rg * (rg + 1) / 2 + col;
+                                if (hp_local) W.hpl[BA_HP * sl + pk] = acc[j];
+                                else gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
+                            }
+                        }
+                    } else if (lane < BA_HP) {  // validation path: the same fma chains on the vector ALU
+                        int i = 0;
+                        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+                        const int j = lane - i * (i + 1) / 2;
+                        double acc = 0;
+                        for (int r = 2 * s; r < 2 * e; ++r)
+                            acc = __builtin_fma(stage[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + i], stage[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + j], acc);
+                        if (hp_local) W.hpl[BA_HP * sl + lane] = acc;
+                        else gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + lane), tag0 + tagH, acc, same_l2);
+                    }
+                }
+                __syncthreads();  // (the staged rows are dead)
+                p0 = p1;
+            }
+        }
+        PH_END(1);
         // ---- exchange: pose-block partials + the landmark max diagonal, summed in workgroup order; the partials are
         // staged `hrows` workgroups at a time (the staging area is bounded for windows with many workgroups)
-        if (hp_deferred) {
-            __syncthreads();  // (hpl complete)
-        } else {
-            const double m = block_max(maxdiag, sScr);  // (two barriers: the chains' stage[] stores are visible below)
-            const int nhp = B.nhp, hrows = min(G, max(1, 4096 / nhp));
+        if (!hp_deferred) {
+            const double m = block_max(maxdiag, sScr);
+            const int nhp = B.nhp, hrows = min(G, max(1, (int)(B.uarea / nhp)));
             double hsum = 0, mm = 0;
             if (G > 1) {
                 if (tid == 0) gstore_d(B.xH + 2 * ((size_t)g * nhp + nhp - 1), tag0 + tagH, m, same_l2);
@@ -982,7 +1076,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 }
                 if (sFlag[2]) error = 1;
             } else {
-                if (tid < nhp - 1) hsum = stage[tid];
+                if (tid < nhp - 1) hsum = W.hpl[tid];
                 if (tid == 0) mm = m;
             }
             if (tid < BA_HP * nfree) {
@@ -1012,7 +1106,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         bool hp_pending = hp_deferred;
         do {
             STAMP(0);
-            // ============= T1: (H_ll + lambda I)^-1 = C C^T, C^T b_l; U_l = [W_l C_l ; (C_l^T b_l)^T ; 0]
+            // ============= T1: (H_ll + lambda I)^-1 = C C^T and C^T b_l of the own landmarks
             if (!B.fix_points) {
                 for (int l = tid; l < Lg; l += BA_THREADS) {
                     const double* h = W.Hll + BA_XS * l;
@@ -1030,159 +1124,147 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     cc[4] = c21;
                     cc[5] = c22;
                     const double* b = W.bl + 3 * l;
-                    const double c0 = c00 * b[0] + c10 * b[1] + c20 * b[2], c1 = c11 * b[1] + c21 * b[2], c2 = c22 * b[2];
-                    W.cl[3 * l] = c0;
-                    W.cl[3 * l + 1] = c1;
-                    W.cl[3 * l + 2] = c2;
-                    if (do_schur) {
-                        W.U[u_index(3 * l, n, ldu)] = c0;
-                        W.U[u_index(3 * l + 1, n, ldu)] = c1;
-                        W.U[u_index(3 * l + 2, n, ldu)] = c2;
-                        for (int row = n + 1; row < urows; ++row)
-                            for (int k = 0; k < 3; ++k) W.U[u_index(3 * l + k, row, ldu)] = 0.0;
-                    }
+                    W.cl[3 * l] = c00 * b[0] + c10 * b[1] + c20 * b[2];
+                    W.cl[3 * l + 1] = c11 * b[1] + c21 * b[2];
+                    W.cl[3 * l + 2] = c22 * b[2];
                 }
-                STAMP(1);
-                if (do_schur)
-                    for (int q = ncol * ldu + tid; q < 4 * msteps * ldu; q += BA_THREADS) W.U[q] = 0.0;  // pad columns
                 __syncthreads();
-                STAMP(2);
-                if (do_schur && !B.has_dups) {
-                    // U rows of the pose blocks, the normal case (no two observations of one landmark from one pose): one
-                    // thread per edge computes Y = X~ C (2 x 3) and the block A~^T Y (6 x 3) of its (landmark, pose slot);
-                    // the pairs without an observation are cleared by a second sweep
-                    for (int el = tid; el < Eg; el += BA_THREADS) {
-                        const int sl = sSlot[W.epose[el]];
-                        if (sl < 0) continue;
-                        const int l = W.ept[el];
-                        const double* cc = W.Cc + BA_XS * l;
-                        const double* X = W.X + BA_XS * el;
-                        const double* A = W.M + BA_MSTRIDE * el;
-                        const double c0 = cc[0], c1 = cc[1], c2 = cc[2], c3 = cc[3], c4 = cc[4], c5 = cc[5];
-                        const double x0 = X[0], x1 = X[1], x2 = X[2], x3 = X[3], x4 = X[4], x5 = X[5];
-                        double a0[6], a1[6];
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) {
-                            a0[c] = A[c];
-                            a1[c] = A[7 + c];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);  // (all 24 operands in flight before the first use)
-                        const double Y[6] = {x0 * c0 + x1 * c1 + x2 * c3, x1 * c2 + x2 * c4, x2 * c5,
-                                             x3 * c0 + x4 * c1 + x5 * c3, x4 * c2 + x5 * c4, x5 * c5};
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-#pragma unroll
-                            for (int c = 0; c < 6; ++c)
-                                W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = 0.0 + (a0[c] * Y[k] + a1[c] * Y[3 + k]);
-                    }
-                    for (int q = tid; q < Lg * nfree; q += BA_THREADS) {
-                        if (W.eof[q] >= 0) continue;
-                        const int l = q / nfree, sl = q - l * nfree;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k)
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = 0.0;
-                    }
-                    __syncthreads();
-                } else if (do_schur) {
-                    // windows with duplicate observations: one item per (landmark, pose slot, k) walks the chain of edges of
-                    // the pair: Y_k = (X~ C)[., k] of every edge, u = sum A~^T Y_k (six values of column 3 l + k)
-                    const int n3 = 3 * nfree;
-                    for (int q = tid; q < Lg * n3; q += BA_THREADS) {
-                        const int l = q / n3, rem = q - l * n3, sl = rem / 3, k = rem - 3 * sl;
-                        const double* cc = W.Cc + BA_XS * l;
-                        // column k of the lower-triangular C: C[c][k] for c = k .. 2
-                        const double ck0 = k == 0 ? cc[0] : 0.0, ck1 = k == 0 ? cc[1] : (k == 1 ? cc[2] : 0.0),
-                                     ck2 = k == 0 ? cc[3] : (k == 1 ? cc[4] : cc[5]);
-                        double acc[6] = {0, 0, 0, 0, 0, 0};
-                        for (int el = W.eof[l * nfree + sl]; el >= 0; el = W.dup[el]) {
-                            const double* X = W.X + BA_XS * el;
-                            const double* A = W.M + BA_MSTRIDE * el;
-                            double y0, y1;
-                            if (k == 0) {
-                                y0 = X[0] * ck0 + X[1] * ck1 + X[2] * ck2;
-                                y1 = X[3] * ck0 + X[4] * ck1 + X[5] * ck2;
-                            } else if (k == 1) {
-                                y0 = X[1] * ck1 + X[2] * ck2;
-                                y1 = X[4] * ck1 + X[5] * ck2;
-                            } else {
-                                y0 = X[2] * ck2;
-                                y1 = X[5] * ck2;
-                            }
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) acc[c] = acc[c] + (A[c] * y0 + A[7 + c] * y1);
-                        }
-#pragma unroll
-                        for (int c = 0; c < 6; ++c) W.U[u_index(3 * l + k, 6 * sl + c, ldu)] = acc[c];
-                    }
-                    __syncthreads();
-                }
             }
-            STAMP(3);
+            STAMP(1);
             PH_END(3);
-            // ============= T2: partial Schur system of the own landmarks: one MFMA chain per (tile pair, split)
+            // ============= T2: partial Schur system of the own landmarks.  U_l = [W_l C_l ; (C_l^T b_l)^T ; 0] (one column per
+            // landmark coordinate) is built one CHUNK of columns at a time in the U area and consumed by the MFMA chains of that
+            // chunk: one chain per (tile pair, column piece); the pieces of a pair are added in piece order.
             if (do_schur) {
-                const int nchain = B.npair * B.nsplit;
-                double* split_stage = W.SL;  // (free until the assemble step) npair x (nsplit - 1) x 256
                 ++tagA;
-                if (batch.use_mfma) {
-                    // nsplit == 1: a wave runs its tile pairs one after the other and publishes from the accumulators;
-                    // nsplit > 1 (npair x nsplit <= 8): one chain per wave, the later splits park their tiles in LDS
-                    // and the first-split wave adds them in split order
-                    for (int a = wave; a < nchain; a += BA_WAVES) {
-                        const int pr = a % B.npair, sp = a / B.npair;
-                        int ti = 0, rem = pr;
-                        while (rem >= B.NT - ti) {
-                            rem -= B.NT - ti;
-                            ++ti;
+                double* split_stage = W.SL;  // (free until the assemble step) npair x (npar - 1) x 256
+                // running sums of this wave's first two tile pairs over the chunks (windows with more than 16 tile pairs are
+                // planned with one chunk: a wave then publishes every pair straight from the chain)
+                v4d run0 = {0, 0, 0, 0}, run1 = {0, 0, 0, 0};
+                if (!batch.use_mfma)
+                    for (int pk = tid; pk < nlow; pk += BA_THREADS) W.Rl[pk] = 0.0;  // (validation path: running sums in LDS)
+                const int nch = chunk_cols > 0 ? max(1, min(nseq, (4 * msteps + chunk_cols - 1) / chunk_cols)) : 1;
+                for (int ch = 0; ch < nch; ++ch) {
+                    const int c0 = ch * chunk_cols;                      // first column of the chunk
+                    const int c1 = min(c0 + chunk_cols, 4 * msteps);     // one past its last column (pad columns included)
+                    // ---- fill: rhs row + zero rows (and whole pad columns), zero blocks of (landmark, slot) pairs without an
+                    // observation, the blocks A~^T Y of the first observation of every pair
+                    for (int q = tid; q < c1 - c0; q += BA_THREADS) {
+                        const int colg = c0 + q;
+                        double* uc = W.U + (size_t)q * ldu;
+                        if (colg < ncol) {
+                            uc[n] = W.cl[colg];
+                        } else {
+                            for (int row = 0; row <= n; ++row) uc[row] = 0.0;
                         }
-                        v4d acc = schur_chain(W.U, ldu, ti, ti + rem, min(sp * msplit, msteps), min((sp + 1) * msplit, msteps), lane);
-                        STAMP(4);
-                        if (sp > 0) {
-                            double* dst = split_stage + ((size_t)pr * (B.nsplit - 1) + (sp - 1)) * 256;
+                        for (int row = n + 1; row < urows; ++row) uc[row] = 0.0;
+                    }
+                    {
+                        const int l0 = c0 / 3, l1 = min(Lg, (c1 + 2) / 3);  // landmarks with a column in the chunk
+                        for (int q = l0 * nfree + tid; q < l1 * nfree; q += BA_THREADS) {
+                            if (W.eof[q] >= 0) continue;
+                            const int l = q / nfree, sl = q - l * nfree;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = acc[j];
-                        }
-                        if (B.nsplit > 1) __syncthreads();  // (uniform: every wave makes exactly one trip, see below)
-                        if (sp == 0) {
-                            for (int s2 = 1; s2 < B.nsplit; ++s2) {
-                                const double* src = split_stage + ((size_t)pr * (B.nsplit - 1) + (s2 - 1)) * 256;
+                            for (int k = 0; k < 3; ++k) {
+                                const int colg = 3 * l + k;
+                                if (colg < c0 || colg >= c1) continue;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) acc[j] += src[lane * 4 + j];
+                                for (int c = 0; c < 6; ++c) W.U[u_index(colg - c0, 6 * sl + c, ldu)] = 0.0;
                             }
+                        }
+                    }
+                    for (int rank = 0; rank <= B.max_dup; ++rank) {
+                        BA_FOR_EDGES
+                        const int l = e_l, sl = e_sl;
+                        if (sl < 0 || 3 * l + 2 < c0 || 3 * l >= c1 || W.dup[el] != rank) continue;
+                        double Y[6];
+                        edge_Y(r, W.Cc + BA_XS * l, Y);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                const int r = (lane >> 4) + 4 * j, c = lane & 15;
-                                const int pk = a == wave ? pk4[j] : pkt_g[pr * 256 + r * 16 + c];
-                                if (pk >= 0) {
-                                    if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, acc[j], same_l2);
-                                    else W.Rl[pk] = acc[j];
+                        for (int k = 0; k < 3; ++k) {
+                            const int colg = 3 * l + k;
+                            if (colg < c0 || colg >= c1) continue;
+#pragma unroll
+                            for (int c = 0; c < 6; ++c) {
+                                double* u = W.U + u_index(colg - c0, 6 * sl + c, ldu);
+                                const double v = r.a0[c] * Y[k] + r.a1[c] * Y[3 + k];
+                                *u = (rank == 0 ? 0.0 : *u) + v;
+                            }
+                        }
+                        BA_END_EDGES
+                        __syncthreads();
+                    }
+                    STAMP(3);
+                    // ---- chains of this chunk; after the last chunk the sums are published (or kept when the window has
+                    // one workgroup)
+                    const int st0 = ch * npar * msplit;  // first MFMA step of the chunk
+                    const bool last = ch == nch - 1;
+                    if (batch.use_mfma) {
+                        const int nchain = B.npair * npar;
+                        int ai = 0;
+                        for (int a = wave; a < nchain; a += BA_WAVES, ++ai) {
+                            const int pr = a % B.npair, sp = a / B.npair;
+                            int ti = 0, rem = pr;
+                            while (rem >= B.NT - ti) {
+                                rem -= B.NT - ti;
+                                ++ti;
+                            }
+                            const int m0 = min(st0 + sp * msplit, msteps) - st0, m1 = min(st0 + (sp + 1) * msplit, msteps) - st0;
+                            v4d acc = schur_chain(W.U, ldu, ti, ti + rem, m0, m1, lane);
+                            STAMP(4);
+                            if (sp > 0) {
+                                double* dst = split_stage + ((size_t)pr * (npar - 1) + (sp - 1)) * 256;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = acc[j];
+                            }
+                            if (npar > 1) __syncthreads();  // (uniform: npair x npar <= 8, every wave makes exactly one trip)
+                            if (sp == 0) {
+                                v4d r = ai == 0 ? run0 : run1;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) r[j] = ch == 0 ? acc[j] : r[j] + acc[j];
+                                for (int s2 = 1; s2 < npar; ++s2) {
+                                    const double* src = split_stage + ((size_t)pr * (npar - 1) + (s2 - 1)) * 256;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) r[j] += src[lane * 4 + j];
+                                }
+                                if (ai == 0) run0 = r;
+                                else if (ai == 1) run1 = r;
+                                if (last) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const int rr = (lane >> 4) + 4 * j, c = lane & 15;
+                                        const int pk = a == wave ? pk4[j] : pkt_g[pr * 256 + rr * 16 + c];
+                                        if (pk >= 0) {
+                                            if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], same_l2);
+                                            else W.Rl[pk] = r[j];
+                                        }
+                                    }
                                 }
                             }
                         }
-                    }
-                    // waves without a chain still meet the barrier of the split combination
-                    if (B.nsplit > 1 && wave >= nchain) __syncthreads();
-                } else {  // validation path: the same chains, one packed entry per thread
-                    for (int pk = tid; pk < nlow; pk += BA_THREADS) {
-                        int i, j;
-                        packed_ij(pk, n, i, j);
-                        double tot = 0;
-                        for (int sp = 0; sp < B.nsplit; ++sp) {
-                            double acc = 0;
-                            const int c0 = min(4 * sp * msplit, ncol), c1 = min(4 * (sp + 1) * msplit, ncol);
-                            for (int col = c0; col < c1; ++col)
-                                acc = __builtin_fma(W.U[u_index(col, j, ldu)], W.U[u_index(col, i, ldu)], acc);
-                            tot = sp == 0 ? acc : tot + acc;
+                        // waves without a chain still meet the barrier of the split combination
+                        if (npar > 1 && wave >= nchain) __syncthreads();
+                    } else {  // validation path: the same chains, one packed entry per thread and pass
+                        for (int pk = tid; pk < nlow; pk += BA_THREADS) {
+                            int i, j;
+                            packed_ij(pk, n, i, j);
+                            double tot = W.Rl[pk];
+                            for (int sp = 0; sp < npar; ++sp) {
+                                double acc = 0;
+                                const int k0 = min(4 * (st0 + sp * msplit), ncol), k1 = min(4 * (st0 + (sp + 1) * msplit), ncol);
+                                for (int colg = k0; colg < k1; ++colg)
+                                    acc = __builtin_fma(W.U[u_index(colg - c0, j, ldu)], W.U[u_index(colg - c0, i, ldu)], acc);
+                                tot = (ch == 0 && sp == 0) ? acc : tot + acc;
+                            }
+                            W.Rl[pk] = tot;
+                            if (last && G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, tot, same_l2);
                         }
-                        if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, tot, same_l2);
-                        else W.Rl[pk] = tot;
                     }
+                    if (!last) __syncthreads();  // (the chunk and the split tiles are consumed)
                 }
                 STAMP(5);
                 PH_END(4);
                 if (G > 1) {
-                    __syncthreads();  // the split tiles in the solver area are dead: it now stages the slice reduction
+                    __syncthreads();
                     STAMP(6);
                     // stage 1: this workgroup reduces its SLICE of the packed entries over all G partials, in workgroup
                     // order, and republishes the slice
@@ -1324,29 +1406,36 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 }
             }
             if (!B.fix_points) {
-                // r = C^T (b_l - W^T dx_p) = cl - U^T dx: one thread per (landmark, k), fma chain over the rows
-                for (int q = tid; q < 3 * Lg; q += BA_THREADS) {
-                    double r = W.cl[q];
-                    if (do_schur) {
-                        const double* up = W.U + (size_t)q * ldu;
-                        for (int row = 0; row < n; row += 6) {  // (n = 6 x free poses)
-                            double u6[6], x6[6];
+                // r = C^T (b_l - W^T dx_p) = C^T b_l - sum over the landmark's observations (ascending edge order) of
+                // Y^T (A~ dx_pose): every edge thread leaves its three terms in the (now free) U area
+                if (do_schur) {
+                    BA_FOR_EDGES
+                    if (e_sl < 0) continue;
+                    const double* sx = sSol + 6 * e_sl;
+                    double s0 = 0, s1 = 0;
 #pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                u6[c] = up[row + c];
-                                x6[c] = sSol[row + c];
-                            }
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) r = __builtin_fma(-u6[c], x6[c], r);
-                        }
+                    for (int c = 0; c < 6; ++c) {
+                        s0 = __builtin_fma(r.a0[c], sx[c], s0);
+                        s1 = __builtin_fma(r.a1[c], sx[c], s1);
                     }
-                    W.rr[q] = r;
+                    double Y[6];
+                    edge_Y(r, W.Cc + BA_XS * e_l, Y);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) W.U[3 * el + k] = Y[k] * s0 + Y[3 + k] * s1;
+                    BA_END_EDGES
                 }
                 STAMP(14);
                 __syncthreads();
                 STAMP(15);
                 for (int l = tid; l < Lg; l += BA_THREADS) {
-                    const double* r = W.rr + 3 * l;
+                    double r[3] = {W.cl[3 * l], W.cl[3 * l + 1], W.cl[3 * l + 2]};
+                    if (do_schur)
+                        for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
+                            const int el = W.ptl[k];
+                            if (sSlot[W.epose[el]] < 0) continue;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) r[c] = r[c] - W.U[3 * el + c];
+                        }
                     const double* cc = W.Cc + BA_XS * l;
                     double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
                     if (!ok2) d[0] = d[1] = d[2] = 0;

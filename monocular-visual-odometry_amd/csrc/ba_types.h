@@ -22,8 +22,12 @@ typedef unsigned long long ba_u64;
 #define BA_WAVES 8
 #define BA_MAX_POSES 20
 #define BA_MSTRIDE 15               // doubles per edge in M: two rows [A~ (6) | e~] at +0 and +7, one pad (odd pitch)
-#define BA_XS 7                     // doubles per edge in X~ (6 used) and per landmark in H_ll / C (6 used): odd pitches,
-//                                  so that one-lane-per-edge / per-landmark accesses spread over the LDS banks
+#define BA_XS 7                     // doubles per landmark in H_ll / C (6 used): odd pitch, so that one-lane-per-landmark
+//                                  accesses spread over the LDS banks
+#define BA_SXS 9                    // doubles per edge in the staged [X~ (6) | e~ (2)] rows of the landmark-block phase (odd)
+#define BA_EDGE_SLOTS 2             // edges per thread: the first one keeps its Jacobian rows in registers, the second one (ranges
+//                                  with more than 512 edges) in LDS; a range holds <= 1024 edges
+#define BA_E2S 19                   // doubles per edge in that LDS area: a0 (6) | a1 (6) | x (6), odd pitch
 #define BA_LDS_BUDGET (157 * 1024)  // dynamic part; the static part (descriptor, flags: < 1.5 KB) comes on top (160 KB per CU)
 #define BA_MAX_WGS 256
 #define BA_MAX_BATCH 16             // windows per launch (8 x 32 or 16 x 16 workgroups = one workgroup per CU)
@@ -47,11 +51,15 @@ struct BaTraceRow {
 };
 
 struct BaDev {
-    int F, L, E, G, nfree, n, NT, npair, fix_points, max_it, maxEg, maxLg, has_dups;
+    int F, L, E, G, nfree, n, NT, npair, fix_points, max_it, maxEg, maxLg;
+    int max_dup;  // largest rank of an observation among those of its (landmark, pose): 0 = no duplicate observations
     int nlow;    // packed entries of the reduced system: lower triangle (i >= j, i < n) then the rhs row (n, j)
     int npk;     // nlow rounded up to 16: row pitch of the partial exchange
     int slice;   // packed entries every workgroup reduces in stage 1
-    int nsplit;  // consecutive column ranges of a Schur chain (more waves busy; results added in range order)
+    int nsplit;  // consecutive column pieces of a Schur chain (results added in piece order) = nseq x npar
+    int npar;    // pieces that run side by side on different waves (one chunk of the U area holds npar pieces)
+    int nseq;    // chunks of the U area that are built and consumed one after the other
+    int uarea;   // doubles of the multi-purpose U / staging area of a workgroup
     int ldu;     // rows of the U buffer = 16 NT
     int nhp;     // pose-block exchange entries per workgroup = BA_HP nfree + 1 (last: max |diag H_ll|)
     double f, cx, cy, delta;
@@ -69,7 +77,7 @@ struct BaDev {
     const int* pt_edge_start; // L + 1 -> pt_edge_list
     const int* pt_edge_list;  // E absolute edge indices, grouped by landmark
     const short* eof;         // L x nfree: LOCAL index of the first edge (landmark, pose slot), -1 if none
-    const short* dup_next;    // E: next LOCAL edge with the same (landmark, pose), -1 if none
+    const short* dup_rank;    // E: rank of the edge among the observations of its (landmark, pose), ascending edge order
     const int* pose_slot;     // F
     const int* slot_pose;     // nfree
     const short* pk_of_tile;  // npair x 256: packed index of tile entry (pair, r, c), -1 if not needed
@@ -96,11 +104,11 @@ struct BaBatch {  // kernel argument: the windows of one launch
 };
 
 // ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner
-__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int nsplit) {
+__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int npar) {
     // the solver area also stages the split-chain tiles and the slice reduction (never live together)
     // register solvers: the system is embedded into 32 / 64 rows (ba_kernels.hip: solve_wave)
     size_t a = n + 1 <= 32 ? 32 * 33 : (n + 1 <= 64 ? 64 * 65 : (size_t)(n + 1) * (size_t)(n + 2));
-    const size_t sp = (size_t)npair * (size_t)(nsplit > 1 ? nsplit - 1 : 0) * 256;
+    const size_t sp = (size_t)npair * (size_t)(npar > 1 ? npar - 1 : 0) * 256;
     const size_t sl = (size_t)((nlow + G - 1) / (G > 0 ? G : 1)) * (size_t)G;
     if (sp > a) a = sp;
     if (sl > a) a = sl;
@@ -108,22 +116,30 @@ __host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int 
 }
 // per-pose state: q t (8) + backup (8), R (9), t (3), H_pp (36), b_p (6), dx (6), solution (6)
 __host__ __device__ inline size_t ba_pose_doubles(int F) { return (size_t)(F > 0 ? F : 1) * 82; }
-__host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int nsplit, int ldu, int nfree,
-                                               int maxEg, int maxLg, int fix_points) {
-    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, nsplit) + (size_t)nlow + 2 * (size_t)nhp + 17 +
-               (size_t)maxEg * (BA_MSTRIDE + 2) + (size_t)maxLg * 3;
-    d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
-    size_t hrows = 4096 / (size_t)(nhp > 0 ? nhp : 1);  // pose-block exchange staging: <= 4096 values at a time
+// The multi-purpose area must hold: one chunk of U (ucols columns at the odd pitch ldu + 1), the staged [X~ | e~] rows of
+// all edges, the back-substitution terms (3 per edge), the rows [A~ | e~] of the largest pose of any range (the pose-block
+// chains stage whole poses), and the pose-block exchange staging.
+__host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int maxEg, int maxEpose, int nhp, int G, int fix_points) {
+    size_t hrows = 4096 / (size_t)(nhp > 0 ? nhp : 1);  // pose-block exchange staging: about 4096 values at a time
     if (hrows < 1) hrows = 1;
     if (hrows > (size_t)G) hrows = (size_t)G;
-    const size_t stage = (size_t)nhp * hrows;
+    size_t a = (size_t)nhp * hrows;
+    const size_t m = (size_t)BA_MSTRIDE * (size_t)(maxEpose > 0 ? maxEpose : 1);
+    if (m > a) a = m;
     if (!fix_points) {
-        d += (size_t)maxEg * BA_XS + (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3 + 3);
-        const size_t u = ((size_t)3 * maxLg + 3) * (ldu + 1);  // (odd column pitch)  // the pose-block staging lives inside the U buffer (rebuilt per trial)
-        d += u > stage ? u : stage;
-    } else {
-        d += stage;
+        const size_t u = (size_t)ucols * (size_t)(ldu + 1), sx = (size_t)BA_SXS * maxEg;
+        if (u > a) a = u;
+        if (sx > a) a = sx;
     }
+    return a;
+}
+__host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int npar, int nfree, int maxEg,
+                                               int maxLg, int fix_points, size_t uarea) {
+    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar) + (size_t)nlow + 2 * (size_t)nhp + 17 + (size_t)maxEg * 2 +
+               (size_t)maxLg * 3;
+    d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
+    if (!fix_points) d += (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3);
+    d += uarea + (size_t)(maxEg > BA_THREADS ? maxEg - BA_THREADS : 0) * BA_E2S;
     size_t shorts = (size_t)maxEg * 4 + (size_t)maxLg + 1 + (size_t)maxLg * (nfree > 0 ? nfree : 1);
     return d * 8 + ((shorts * 2 + 15) & ~(size_t)15) + 64;
 }

@@ -17,7 +17,8 @@
 //   * scalar sums (chi2, predicted decrease): per-"thread" partials (index mod 512), a 64-lane xor butterfly, 8 waves in
 //     order, ranges in order;
 //   * whitened formulation (Omega = Lc^T Lc folded into the Jacobians), (H_ll + lambda I)^-1 = C C^T, reduced system by
-//     right-looking LDL^T with r = 1 / d, l = c r, fma updates; back-substitution through U = W C;
+//     right-looking LDL^T with r = 1 / d, l = c r, fma updates; landmark back-substitution per observation
+//     (C^T b_l - sum_e Y_e^T (A~_e dx), edges in ascending order);
 //   * sin / cos by the fixed polynomial below instead of libm.
 // PARITY UNPINNED like the rest of the oracle (oracle.h).
 #include <algorithm>
@@ -591,12 +592,28 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                     for (int t = 0; t < 6 * F && t < kThreads; ++t)
                         if (B.pose_slot[t / 6] >= 0) part[t] += dx[t] * (lambda * dx[t] + B.bp[t]);
                 if (!B.fix_points) {
-                    const double* Ug = do_schur ? &U[u_off[g]] : nullptr;
-                    for (int q = 0; q < 3 * r.Lg; ++q) {
-                        double rq = cl[3 * (size_t)r.pt_lo + q];
+                    // r = C^T (b_l - W^T dx_p) = C^T b_l - sum over the landmark's observations, in ascending edge order, of
+                    // Y^T (A~ dx_pose) with Y = X~ C: the 2-vector A~ dx as two fma chains over the six pose coordinates
+                    for (int ll = 0; ll < r.Lg; ++ll) {
+                        const int l = r.pt_lo + ll;
+                        const double* cc = &Cc[6 * (size_t)l];
+                        double rq[3] = {cl[3 * (size_t)l], cl[3 * (size_t)l + 1], cl[3 * (size_t)l + 2]};
                         if (do_schur)
-                            for (int row = 0; row < n; ++row) rq = std::fma(-Ug[(size_t)q * nrow + row], sol[row], rq);
-                        rr[3 * (size_t)r.pt_lo + q] = rq;
+                            for (int e : B.pt_edges[l]) {
+                                const int sl = B.pose_slot[B.e_pose[e]];
+                                if (sl < 0) continue;
+                                const double* A = &B.M[14 * (size_t)e];
+                                const double* Xr = &B.X[6 * (size_t)e];
+                                double s0 = 0, s1 = 0;
+                                for (int c = 0; c < 6; ++c) {
+                                    s0 = std::fma(A[c], sol[6 * sl + c], s0);
+                                    s1 = std::fma(A[7 + c], sol[6 * sl + c], s1);
+                                }
+                                const double Y[6] = {Xr[0] * cc[0] + Xr[1] * cc[1] + Xr[2] * cc[3], Xr[1] * cc[2] + Xr[2] * cc[4], Xr[2] * cc[5],
+                                                     Xr[3] * cc[0] + Xr[4] * cc[1] + Xr[5] * cc[3], Xr[4] * cc[2] + Xr[5] * cc[4], Xr[5] * cc[5]};
+                                for (int k = 0; k < 3; ++k) rq[k] = rq[k] - (Y[k] * s0 + Y[3 + k] * s1);
+                            }
+                        for (int k = 0; k < 3; ++k) rr[3 * (size_t)l + k] = rq[k];
                     }
                     for (int ll = 0; ll < r.Lg; ++ll) {
                         const int l = r.pt_lo + ll;
