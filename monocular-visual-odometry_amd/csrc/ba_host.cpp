@@ -31,6 +31,7 @@ int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
 int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
 int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
+int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
 namespace {
 
@@ -204,7 +205,8 @@ void BaService::run() {
         b.use_mfma = jobs[0]->use_mfma;
         b.same_l2_ok = g_ba_same_l2;
         (void)hipEventRecord(e0, stream);
-        hipError_t le = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, ba_solver_class(jobs[0]->ws->plan.n));
+        const int cls = ba_solver_class(jobs[0]->ws->plan.n);
+        hipError_t le = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, cls == 32 && g_ba_block_solver ? -32 : cls);
         (void)hipEventRecord(e1, stream);
         lap(l_launch);
         hipError_t se = hipStreamSynchronize(stream);

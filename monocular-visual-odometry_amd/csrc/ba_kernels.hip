@@ -365,54 +365,6 @@ extern __shared__ __attribute__((aligned(16))) double ba_dyn_lds[];
 #else  // tests/sim: this source compiled for the host against tests/sim/hip_emu (a test aid; the library has no CPU path)
 #define ba_dyn_lds (static_cast<double*>(emu_dyn_lds()))
 #endif
-template <int NR>
-__device__ __forceinline__ int solve_wave(int sl_off, int cb_off, int n, int lane) {
-    constexpr int R = NR - 1;      // lane / row of the rhs
-    constexpr int P = NR + 1;      // row pitch
-    double* SL = ba_dyn_lds + sl_off;
-    double* colbuf = ba_dyn_lds + cb_off;
-    double* xout = colbuf + 128;
-    int ok = 1;
-    if (lane < NR) {
-        // the assemble step wrote the embedded system: rows < n = S (lower triangle, zeros above), identity rows up
-        // to R - 1, row R = rhs
-        double a[NR];
-#pragma unroll
-        for (int k = 0; k < R; ++k) a[k] = SL[lane * P + k];
-        colbuf[lane] = a[0];
-        double d = readlane_d(a[0], 0);
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const int cur = j & 1, nxt = cur ^ 1;
-            ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (j >= n);
-            const double r = ba_rcp_pivot(d);
-            const double l = a[j] * r;
-            if (j + 1 < R) {
-                a[j + 1] = __builtin_fma(-l, colbuf[cur * 64 + j + 1], a[j + 1]);
-                colbuf[nxt * 64 + lane] = a[j + 1];
-                d = readlane_d(a[j + 1], j + 1);
-            }
-#pragma unroll
-            for (int k = j + 2; k < R; ++k) a[k] = __builtin_fma(-l, colbuf[cur * 64 + k], a[k]);
-            SL[j * P + lane] = l;  // column j of L (entries of the lanes <= j are never read)
-        }
-        // back-substitution: lane j owns x_j.  (Row j of L^T was written by the other lanes: an intra-wave hand-off through
-        // LDS -- in order for a wave anyway; the barrier is no instruction, it states the dependence.)
-        __builtin_amdgcn_wave_barrier();
-        double cl[NR];
-#pragma unroll
-        for (int i = 1; i < R; ++i) cl[i] = SL[(lane < R ? lane : 0) * P + i];
-        double x = SL[(lane < R ? lane : 0) * P + R];
-#pragma unroll
-        for (int i = R - 1; i >= 1; --i) {
-            const double xi = readlane_d(x, i);
-            const double t = __builtin_fma(-cl[i], xi, x);
-            x = lane < i ? t : x;
-        }
-        if (lane < n) xout[lane] = x;
-    }
-    return __builtin_amdgcn_readfirstlane(ok);
-}
 // The 32-row flavour uses both halves of the wave: lane = (row i = lane & 31, half h = lane >> 5) keeps the columns
 // k = 2 m + h of its row (16 registers instead of 32), so that the prefetched column of the next step fits the register
 // file next to the one in use, and a step costs half the fused multiply-adds per lane.  Same arithmetic per entry.
@@ -482,7 +434,105 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
     if (lane < n) xout[lane] = x;
     return __builtin_amdgcn_readfirstlane(ok);
 }
-__device__ __forceinline__ int solve_wave_64(int sl_off, int cb_off, int n, int lane) { return solve_wave<64>(sl_off, cb_off, n, lane); }
+
+// The same factorisation as a BLOCK algorithm run by the whole workgroup, matrix in LDS (SL, NR rows at pitch NR + 1,
+// embedded as above: identity rows behind n, the rhs as row NR - 1).  Per block of 4 columns j0 .. j0 + 3:
+//   panel   (wave 0, lane = row): the four pivots one after the other -- pivot and the three sub-diagonal entries of the
+//           diagonal block by v_readlane, r = 1 / d, l = c r, the remaining panel columns updated in registers; the rows
+//           [-l] and [c] of the panel go to LDS in MFMA operand order, the l into the matrix;
+//   update  (all waves, one 16 x 16 tile each): S_tile += (-L_panel) C_panel^T by ONE v_mfma_f64_16x16x4_f64 -- the four
+//           columns of the panel are the four k slots, added as fused multiply-adds in column order, which is exactly
+//           the canonical a_ik = fma(-l_ij, c_kj, a_ik), j ascending; only entries below the panel columns and inside
+//           the lower triangle are written back.
+// Same bits as the scalar right-looking LDL^T (every entry receives the same fma's in the same order); 63 pivots cost 16
+// panel + update rounds instead of 63 single-wave steps with the whole matrix in one wave's registers (the 64-row
+// register solver used every VGPR of the kernel and spilled).  `pan`: 8 NR doubles of scratch.  Returns 0 when a pivot
+// is not usable; leaves x in xout[0 .. n).
+template <int NR>
+__device__ __forceinline__ int solve_block(int sl_off, int pan_off, int xout_off, int n, int tid) {
+    constexpr int R = NR - 1, P = NR + 1, NB = NR / 4, NTL = NR / 16;
+    double* SL = ba_dyn_lds + sl_off;
+    double* LP = ba_dyn_lds + pan_off;  // NR x 4: -l_i,j0+k
+    double* CP = LP + NR * 4;           // NR x 4:  c_i,j0+k
+    double* xout = ba_dyn_lds + xout_off;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int ok = 1;
+    for (int b = 0; b < NB; ++b) {
+        const int j0 = 4 * b;
+        if (wave == 0) {
+            const int i = lane < NR ? lane : R;
+            double p[4], l[4], c[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[k] = SL[i * P + j0 + k];  // (column R of the last block: never a pivot)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = j0 + jj;
+                double d = readlane_d(p[jj], j < NR ? j : 0);
+                if (j >= R) d = 1.0;
+                ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (j >= n);
+                const double r = ba_rcp_pivot(d);
+                c[jj] = p[jj];
+                l[jj] = p[jj] * r;
+#pragma unroll
+                for (int kk = jj + 1; kk < 4; ++kk) {
+                    const double ckj = readlane_d(p[jj], j0 + kk < NR ? j0 + kk : 0);  // S[j0 + kk][j] before the scaling
+                    p[kk] = __builtin_fma(-l[jj], ckj, p[kk]);
+                }
+            }
+            if (lane < NR) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    LP[i * 4 + k] = -l[k];
+                    CP[i * 4 + k] = c[k];
+                    if (i > j0 + k && j0 + k < R) SL[i * P + j0 + k] = l[k];
+                }
+            }
+        }
+        __syncthreads();
+        // trailing update: tiles (ti >= tj) that reach below / right of the panel
+        {
+            const int t0 = (j0 + 4) / 16;  // first tile row / column with an entry behind the panel
+            const int q = lane >> 4, cidx = lane & 15;
+            int t = 0;
+            for (int tj = t0; tj < NTL; ++tj)
+                for (int ti = tj; ti < NTL; ++ti, ++t) {
+                    if ((t & (BA_WAVES - 1)) != wave) continue;
+                    v4d acc;
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) acc[rr] = SL[(16 * ti + 4 * rr + q) * P + 16 * tj + cidx];
+                    const double a = LP[(16 * ti + cidx) * 4 + q], bb = CP[(16 * tj + cidx) * 4 + q];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int row = 16 * ti + 4 * rr + q, col = 16 * tj + cidx;
+                        if (row > j0 + 3 && col > j0 + 3 && col <= row && col < R) SL[row * P + col] = acc[rr];
+                    }
+                }
+        }
+        __syncthreads();
+    }
+    // back-substitution x = L^-T z by wave 0: lane j owns x_j (z = the rhs row of L); row i of L is read in LDS order
+    if (wave == 0) {
+        const int j = lane < R ? lane : 0;
+        double x = SL[R * P + j];
+        for (int i0 = R - 1; i0 >= 1; i0 -= 8) {
+            double li[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) li[u] = i0 - u >= 1 ? SL[(i0 - u) * P + j] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 - u;
+                if (i < 1) break;
+                const double xi = readlane_d(x, i);
+                const double t = __builtin_fma(-li[u], xi, x);
+                x = lane < i ? t : x;
+            }
+        }
+        if (lane < n) xout[lane] = x;
+    }
+    return __builtin_amdgcn_readfirstlane(ok);
+}
 // the same arithmetic for more than 63 unknowns (> 10 free poses): one wave, matrix in LDS (row pitch n + 2)
 __device__ __attribute__((noinline)) int solve_lds(int sl_off, int cb_off, int n, int lane) {
     double* S = ba_dyn_lds + sl_off;
@@ -541,6 +591,7 @@ __device__ __forceinline__ void packed_ij(int idx, int n, int& i, int& j) {
 struct WgLds {
     double* SL;     // reduced system / transposed L; split-chain tiles and the slice reduction are staged here as well
     double* colbuf; // 2 x 64 column broadcast + 64 scratch
+    double* pan;    // BA_PANEL_DOUBLES: panel rows of the block solver
     double* Rl;     // nlow + nhp (+16) packed entries of the summed Schur system (+ pose blocks)
     double* hpl;    // nhp own pose-block partials (waiting for the next Schur exchange, or the only ones when G = 1)
     double* uv;     // maxEg x 2 (u and v in separate arrays)
@@ -682,8 +733,9 @@ __device__ __forceinline__ void edge_Y(const EdgeRegs& r, const double* cc, doub
     Y[5] = r.x[5] * c5;
 }
 
-// PROF: per-phase cycle counters; NR: reduced-solve flavour -- 32 / 64: register solver for n + 1 <= NR rows, 0: LDS
-// solver (any n).  Separate instantiations: the solvers differ widely in register use.
+// PROF: per-phase cycle counters; NR: reduced-solve flavour -- 32: one-wave register solver for n + 1 <= 32 rows; 64 / -32:
+// workgroup-wide block solver for n + 1 <= 64 / 32 rows; 0: LDS solver (any n).  Separate instantiations: the solvers
+// differ widely in register use.
 template <bool PROF, int NR>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     // window = blockIdx % stride; the stride is a multiple of 8 whenever several windows share a launch: with the
@@ -732,9 +784,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     {
         double* d = dyn + ba_pose_doubles(B.F) + 2 * (size_t)G + 8;
         W.SL = d;
-        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar) - 3 * 64;
+        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar) - 3 * 64 - BA_PANEL_DOUBLES;
         W.colbuf = d;
         d += 3 * 64;
+        W.pan = d;
+        d += BA_PANEL_DOUBLES;
         W.Rl = d;
         d += nlow + B.nhp + 16;
         W.hpl = d;
@@ -1325,7 +1379,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n] and solves it
             if (NR != 0) {
                 // register solvers: the system embedded into NR rows (identity rows behind n, the rhs as row NR - 1)
-                constexpr int NRR = NR ? NR : 32, RR = NRR - 1, PP = NRR + 1;
+                constexpr int NRR = NR ? (NR < 0 ? -NR : NR) : 32, RR = NRR - 1, PP = NRR + 1;
                 for (int q = tid; q < NRR * RR; q += BA_THREADS) {
                     const int i = q / RR, k = q - i * RR;
                     double v;
@@ -1365,22 +1419,26 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             __syncthreads();
             STAMP(12);
             PH_END(6);
-            if (wave == 0 && n > 0) {
-                int ok;
+            {
                 const int sl_off = (int)(W.SL - dyn), cb_off = (int)(W.colbuf - dyn);
-                if (NR == 32) {
-                    ok = solve_wave_32(sl_off, cb_off, n, lane);
-                    if (lane < n) sSol[lane] = W.colbuf[128 + lane];
-                } else if (NR == 64) {
-                    ok = solve_wave_64(sl_off, cb_off, n, lane);
-                    if (lane < n) sSol[lane] = W.colbuf[128 + lane];
-                } else {
-                    ok = solve_lds(sl_off, cb_off, n, lane);
-                    for (int j = lane; j < n; j += 64) sSol[j] = W.colbuf[j];
+                if (n > 0 && (NR == 64 || NR == -32)) {
+                    // workgroup-wide block factorisation (all waves take part: barriers inside)
+                    const int ok = solve_block<(NR == 64 ? 64 : 32)>(sl_off, (int)(W.pan - dyn), cb_off + 128, n, tid);
+                    if (tid == 0) sFlag[0] = ok;
+                    if (tid < n) sSol[tid] = W.colbuf[128 + tid];
+                } else if (wave == 0 && n > 0) {
+                    int ok;
+                    if (NR == 32) {
+                        ok = solve_wave_32(sl_off, cb_off, n, lane);
+                        if (lane < n) sSol[lane] = W.colbuf[128 + lane];
+                    } else {
+                        ok = solve_lds(sl_off, cb_off, n, lane);
+                        for (int j = lane; j < n; j += 64) sSol[j] = W.colbuf[j];
+                    }
+                    if (lane == 0) sFlag[0] = ok;
+                } else if (n == 0 && tid == 0) {
+                    sFlag[0] = 1;
                 }
-                if (lane == 0) sFlag[0] = ok;
-            } else if (n == 0 && tid == 0) {
-                sFlag[0] = 1;
             }
             __syncthreads();
             const int ok2 = sFlag[0];
@@ -1580,13 +1638,13 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
 // ------------------------------------------------------------------------------------------------ launch
 typedef void (*ba_kernel_fn)(BaBatch);
 static ba_kernel_fn ba_kernel_for(int profile, int nr) {
-    if (profile) return nr == 32 ? k_ba_lm<true, 32> : (nr == 64 ? k_ba_lm<true, 64> : k_ba_lm<true, 0>);
-    return nr == 32 ? k_ba_lm<false, 32> : (nr == 64 ? k_ba_lm<false, 64> : k_ba_lm<false, 0>);
+    if (profile) return nr == 32 ? k_ba_lm<true, 32> : (nr == -32 ? k_ba_lm<true, -32> : (nr == 64 ? k_ba_lm<true, 64> : k_ba_lm<true, 0>));
+    return nr == 32 ? k_ba_lm<false, 32> : (nr == -32 ? k_ba_lm<false, -32> : (nr == 64 ? k_ba_lm<false, 64> : k_ba_lm<false, 0>));
 }
 int ba_kernel_set_lds_limit() {
     int bad = 0;
     for (int profile = 0; profile < 2; ++profile)
-        for (int nr : {32, 64, 0})
+        for (int nr : {32, -32, 64, 0})
             bad |= hipFuncSetAttribute((const void*)ba_kernel_for(profile, nr), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        BA_LDS_BUDGET) != hipSuccess;
     return bad ? -1 : 0;

@@ -27,6 +27,7 @@ typedef unsigned long long ba_u64;
 #define BA_SXS 9                    // doubles per edge in the staged [X~ (6) | e~ (2)] rows of the landmark-block phase (odd)
 #define BA_EDGE_SLOTS 2             // edges per thread: the first one keeps its Jacobian rows in registers, the second one (ranges
 //                                  with more than 512 edges) in LDS; a range holds <= 1024 edges
+#define BA_PANEL_DOUBLES 512         // block LDL^T: rows [-l] and [c] of a 4-column panel, 64 rows each
 #define BA_E2S 19                   // doubles per edge in that LDS area: a0 (6) | a1 (6) | x (6), odd pitch
 #define BA_LDS_BUDGET (157 * 1024)  // dynamic part; the static part (descriptor, flags: < 1.5 KB) comes on top (160 KB per CU)
 #define BA_MAX_WGS 256
@@ -112,7 +113,7 @@ __host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int 
     const size_t sl = (size_t)((nlow + G - 1) / (G > 0 ? G : 1)) * (size_t)G;
     if (sp > a) a = sp;
     if (sl > a) a = sl;
-    return a + 3 * 64;  // + two column-broadcast buffers + scratch
+    return a + 3 * 64 + BA_PANEL_DOUBLES;  // + two column-broadcast buffers + scratch + the panel of the block solver
 }
 // per-pose state: q t (8) + backup (8), R (9), t (3), H_pp (36), b_p (6), dx (6), solution (6)
 __host__ __device__ inline size_t ba_pose_doubles(int F) { return (size_t)(F > 0 ? F : 1) * 82; }
