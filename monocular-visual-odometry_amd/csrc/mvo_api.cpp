@@ -56,6 +56,8 @@ void mvo_prof_collect(mvo_ctx* c) {
     c->prof_pending.clear();
 }
 
+int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
+
 extern "C" {
 
 int mvo_create(mvo_ctx** out, int device) {
@@ -448,7 +450,6 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 }
 
 // ---------------------------------------------------------------------------------------------- debug hooks
-int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
 int mvo_debug_set(const char* key, int value) {
     if (key && !std::strncmp(key, "ba_", 3)) return ba_debug_set(key, value);
     if (key && !std::strcmp(key, "pyr_force_chain")) {
