@@ -320,6 +320,10 @@ class Context:
         return [(k["poses"].reshape(-1, 4, 4), k["points"], {f: getattr(sts[i], f) for f, _ in BaStats._fields_})
                 for i, k in enumerate(keeps)]
 
+    def ba_set_mode(self, mode):
+        """mvo_ba_set_mode: "latency" (default, ~300 observations per workgroup) or "throughput" (~600)."""
+        self._chk(self.lib.mvo_ba_set_mode(self.h, {"latency": 0, "throughput": 1}[mode]))
+
     def ba_trace_enable(self, on=True):
         self._chk(self.lib.mvo_debug_ba_trace_enable(self.h, int(on)))
 

@@ -31,6 +31,7 @@ int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
 int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
 int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
+int g_ba_cu_share = 0;   // CUs a solver grid may take (0 = 3/4 of the device)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
 namespace {
@@ -114,12 +115,21 @@ struct BaJob {
     float ms = 0;   // duration of the launch this window was part of
     int batch = 0;  // windows in that launch
 };
+// One launch in flight: its windows and the events around it (the completion thread turns it into results).
+struct BaFlight {
+    BaJob* jobs[BA_MAX_BATCH];
+    int nj = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t launch_err = hipSuccess;
+};
 struct BaService {
     int device = 0;
     std::mutex m;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work, cv_done, cv_flight;
     std::deque<BaJob*> q;
-    std::thread th;
+    std::deque<BaFlight*> flights;  // issued, not yet completed (at most BA_MAX_FLIGHTS)
+    std::vector<BaFlight*> flight_pool;
+    std::thread th, th_done;
     bool started = false;
     // who submitted recently (workspace -> time of its last job): with several clients active a launch waits a moment for
     // a full batch, a lone client is never held back
@@ -127,28 +137,29 @@ struct BaService {
     // statistics (mvo_ba_launch_stats)
     long long launches = 0, windows = 0;
     double ms = 0;
-    double t_idle = 0, t_batch = 0, t_launch = 0, t_sync = 0, t_post = 0;  // wall-clock of the loop's stages, ms
+    double t_idle = 0, t_batch = 0, t_launch = 0, t_sync = 0, t_post = 0;  // wall-clock of the loops' stages, ms
     void run();
+    void complete();
 };
-// heap-allocated and never destroyed: the detached launch threads wait on these condition variables until the
+#define BA_MAX_FLIGHTS 2
+// heap-allocated and never destroyed: the detached service threads wait on these condition variables until the
 // process ends (destroying a condition variable with a waiter would block exit)
 BaService* g_service[16] = {nullptr};
 std::mutex* g_service_start = new std::mutex();
 
+// Launch thread: batches staged windows into grids and ISSUES them -- the next grid is queued behind the running one on
+// the same stream (it starts when its predecessor has left the CUs; the workgroups of a window need each other
+// resident, two grids must never be half-resident side by side).  A grid never takes more than `ba_cu_share` CUs (3/4 of
+// the device by default): the solver's workgroups own their CUs completely (all LDS, all VGPRs), so the rest is what the
+// callers' extraction / matching kernels run on WHILE a solve is in progress -- with the whole device taken they only ran
+// in the gaps between launches.  The completion thread waits for the launches in order and publishes their results.
 void BaService::run() {
     (void)hipSetDevice(device);
     hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
     (void)ba_kernel_set_lds_limit();
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) cus = 256;
-    // (Queuing a second launch behind the running one was tried twice, the second time only for FULL batches with 24
-    // clients: back-to-back solver launches own every CU -- 2 waves x 256 VGPRs per SIMD, ~150 KB LDS -- and the extraction
-    // kernels of the other clients only run in the gaps between them; closing the gaps starved the clients and lowered the
-    // frame rate from ~2800 to ~2600.)
     // stage clocks of one loop iteration: kept in locals and folded into the shared statistics under the lock
     auto tp = std::chrono::steady_clock::now();
     auto lap = [&tp](double& acc) {
@@ -156,42 +167,54 @@ void BaService::run() {
         acc += std::chrono::duration<double, std::milli>(now - tp).count();
         tp = now;
     };
-    double l_idle = 0, l_batch = 0, l_launch = 0, l_sync = 0, l_post = 0;
+    double l_idle = 0, l_batch = 0, l_launch = 0;
     for (;;) {
-        BaJob* jobs[BA_MAX_BATCH];
-        int nj = 0;
+        BaFlight* fl = nullptr;
         {
             std::unique_lock<std::mutex> lk(m);
             cv_work.wait(lk, [&] { return !q.empty(); });
             lap(l_idle);
+            int share = g_ba_cu_share > 0 ? g_ba_cu_share : (cus >= 64 ? cus - cus / 4 : cus);
+            share = std::max(1, std::min(share, cus));
             {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
                 const auto now = std::chrono::steady_clock::now();
                 for (auto it = seen.begin(); it != seen.end();)
                     it = (now - it->second > std::chrono::milliseconds(10)) ? seen.erase(it) : std::next(it);
-                const size_t fit = (size_t)std::max(1, cus / std::max(1, q.front()->ws->plan.G));  // windows per grid
+                const size_t fit = (size_t)std::max(1, share / std::max(1, q.front()->ws->plan.G));  // windows per grid
                 const size_t want = std::min<size_t>(std::min<size_t>(BA_MAX_BATCH, fit), seen.size());
                 if (q.size() < want)
                     cv_work.wait_for(lk, std::chrono::microseconds(250), [&] { return q.size() >= want; });
             }
-            // one workgroup per CU (the LDS slice is > 80 KB): a launch may not hold more workgroups than the device has
-            // CUs, or its hand-offs would wait for workgroups that cannot become resident
+            cv_flight.wait(lk, [&] { return flights.size() < BA_MAX_FLIGHTS; });
+            if (flight_pool.empty()) {
+                fl = new BaFlight();
+                (void)hipEventCreate(&fl->e0);
+                (void)hipEventCreate(&fl->e1);
+            } else {
+                fl = flight_pool.back();
+                flight_pool.pop_back();
+            }
+            fl->nj = 0;
+            // one workgroup per CU (the LDS slice is > 80 KB): a launch may not hold more workgroups than its share of
+            // the CUs (a window larger than the share runs alone, on as many CUs as it needs)
             int sum_wgs = 0;
-            while (nj < BA_MAX_BATCH && !q.empty()) {
+            while (fl->nj < BA_MAX_BATCH && !q.empty()) {
                 const int G = q.front()->ws->plan.G;
-                if (nj && sum_wgs + G > cus) break;
-                if (nj && ba_solver_class(q.front()->ws->plan.n) != ba_solver_class(jobs[0]->ws->plan.n)) break;
+                if (fl->nj && sum_wgs + G > share) break;
+                if (fl->nj && ba_solver_class(q.front()->ws->plan.n) != ba_solver_class(fl->jobs[0]->ws->plan.n)) break;
                 sum_wgs += G;
-                jobs[nj++] = q.front();
+                fl->jobs[fl->nj++] = q.front();
                 q.pop_front();
             }
         }
         lap(l_batch);
+        const int nj = fl->nj;
         BaBatch b{};
         b.nwin = nj;
         int maxG = 1;
         size_t lds = 16;
         for (int i = 0; i < nj; ++i) {
-            BaWorkspace* ws = jobs[i]->ws;
+            BaWorkspace* ws = fl->jobs[i]->ws;
             (void)hipStreamWaitEvent(stream, ws->ready, 0);  // the window's upload (queued on its ctx stream)
             b.win[i] = (const BaDev*)(ws->dev + ws->plan.o_desc);
             b.tag_base[i] = ws->seq << 12;
@@ -202,34 +225,62 @@ void BaService::run() {
         // every window's workgroups on ONE XCD (a window of > 32 workgroups does not fit an XCD's 32 CUs anyway)
         b.stride = cus >= 256 && maxG <= 16 ? 16 : (cus >= 256 && maxG <= 32 ? 8 : nj);
         if (b.stride < nj) b.stride = nj;
-        b.use_mfma = jobs[0]->use_mfma;
+        b.use_mfma = fl->jobs[0]->use_mfma;
         b.same_l2_ok = g_ba_same_l2;
-        (void)hipEventRecord(e0, stream);
-        const int cls = ba_solver_class(jobs[0]->ws->plan.n);
-        hipError_t le = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, cls == 32 && g_ba_block_solver ? -32 : cls);
-        (void)hipEventRecord(e1, stream);
+        (void)hipEventRecord(fl->e0, stream);
+        const int cls = ba_solver_class(fl->jobs[0]->ws->plan.n);
+        fl->launch_err = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, cls == 32 && g_ba_block_solver ? -32 : cls);
+        (void)hipEventRecord(fl->e1, stream);
         lap(l_launch);
-        hipError_t se = hipStreamSynchronize(stream);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            flights.push_back(fl);
+            t_idle += l_idle, t_batch += l_batch, t_launch += l_launch;
+            l_idle = l_batch = l_launch = 0;
+        }
+        cv_flight.notify_all();
+    }
+}
+void BaService::complete() {
+    (void)hipSetDevice(device);
+    auto tp = std::chrono::steady_clock::now();
+    auto lap = [&tp](double& acc) {
+        const auto now = std::chrono::steady_clock::now();
+        acc += std::chrono::duration<double, std::milli>(now - tp).count();
+        tp = now;
+    };
+    for (;;) {
+        BaFlight* fl;
+        double l_wait = 0, l_sync = 0, l_post = 0;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_flight.wait(lk, [&] { return !flights.empty(); });
+            fl = flights.front();
+        }
+        lap(l_wait);
+        hipError_t se = hipEventSynchronize(fl->e1);
         lap(l_sync);
         float t = 0;
-        if (le == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&t, e0, e1);
+        if (fl->launch_err == hipSuccess && se == hipSuccess) (void)hipEventElapsedTime(&t, fl->e0, fl->e1);
         else (void)hipGetLastError();
         {
             std::lock_guard<std::mutex> lk(m);
             ++launches;
-            windows += nj;
+            windows += fl->nj;
             ms += t;
-            t_idle += l_idle, t_batch += l_batch, t_launch += l_launch, t_sync += l_sync, t_post += l_post;
-            l_idle = l_batch = l_launch = l_sync = l_post = 0;
-            for (int i = 0; i < nj; ++i) {
-                jobs[i]->err = le != hipSuccess ? le : se;
-                jobs[i]->ms = t;
-                jobs[i]->batch = nj;
-                jobs[i]->done = true;
+            for (int i = 0; i < fl->nj; ++i) {
+                fl->jobs[i]->err = fl->launch_err != hipSuccess ? fl->launch_err : se;
+                fl->jobs[i]->ms = t;
+                fl->jobs[i]->batch = fl->nj;
+                fl->jobs[i]->done = true;
             }
+            flights.pop_front();
+            flight_pool.push_back(fl);
+            lap(l_post);
+            t_sync += l_sync, t_post += l_post;
         }
         cv_done.notify_all();
-        lap(l_post);
+        cv_flight.notify_all();
     }
 }
 BaService& service_for(int device) {
@@ -241,6 +292,8 @@ BaService& service_for(int device) {
         s.started = true;
         s.th = std::thread([&s] { s.run(); });
         s.th.detach();  // lives as long as the process; blocks on its queue when idle
+        s.th_done = std::thread([&s] { s.complete(); });
+        s.th_done.detach();
     }
     return s;
 }
@@ -314,11 +367,12 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.runnable = !(F == 0 && (L == 0 || p->fix_points)) && (nfree > 0 || !p->fix_points);
     // ---- choose G and the landmark ranges (balanced by edge count).  A range's per-edge Jacobian rows live in the
     // registers of its 512 threads (BA_EDGE_SLOTS each), its landmark state and one chunk of the Schur operands in LDS.
-    // Latency mode (default): ~300 edges per workgroup, i.e. 32 workgroups = one XCD for the 5-keyframe window of the
-    // benchmark; throughput mode: ~600 edges per workgroup, half the CUs per window at ~15 % more time per solve.
-    const int edges_per_wg = ctx->ba_throughput_mode ? 320 : 160;
+    // Latency mode (default): up to 32 workgroups (= one XCD) for the 5-keyframe window of the benchmark, ~300 edges each;
+    // throughput mode: up to 16 (~600 edges each), half the CUs per window at some 15 % more time per solve.  Larger
+    // windows get more workgroups either way: a range holds at most 1024 edges and must fit the LDS.
+    const int g_cap = ctx->ba_throughput_mode ? 16 : 32;
     int G = 1;
-    while (G < 32 && E > edges_per_wg * G) G *= 2;
+    while (G < g_cap && E > 160 * G) G *= 2;
     if (g_ba_wgs > 0) G = g_ba_wgs;
     if (const char* env = std::getenv("MVO_BA_WGS")) G = std::max(1, std::atoi(env));
     G = std::max(1, std::min(G, BA_MAX_WGS));

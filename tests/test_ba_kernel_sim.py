@@ -94,3 +94,65 @@ def test_batched_windows_equal_their_single_solves(mvo, simctx):
     batch = simctx.ba_solve_batch([_args(pb) for pb in pbs], fix_points=False, max_iterations=8)
     for (P, X, st), (Pb, Xb, stb) in zip(singles, batch):
         assert np.array_equal(P, Pb) and np.array_equal(X, Xb) and st["trials"] == stb["trials"]
+
+
+def test_throughput_mode_cuts_the_window_into_fewer_workgroups(mvo, O, simctx):
+    """mvo_ba_set_mode(THROUGHPUT): the benchmarked window on 16 workgroups -- more than 512 edges per range (the second
+    edge of a thread keeps its rows in LDS), the Schur operands in two chunks -- still bit for bit the oracle."""
+    simctx.ba_set_mode("throughput")
+    st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
+    assert plan["wgs"] == 16 and plan["nsplit"] == 2 and st["iterations"] == 50
+    _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
+
+
+@pytest.mark.parametrize("block", [0, 1])
+def test_six_to_ten_pose_windows_use_the_block_solver(mvo, O, simctx, simlib, block):
+    """n + 1 in 33..64 (6..10 free poses): workgroup-wide block LDL^T (panel on one wave, MFMA tile updates on all); with
+    the knob also for the 5-pose class.  BASELINE configs[3] (BA10: 10 poses / 4000 landmarks / ~36k edges) fits 64
+    workgroups."""
+    simlib.mvo_debug_set(b"ba_block_solver", block)
+    try:
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(7, 900, 31), fix_points=False, max_iterations=8)
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 800, 5), fix_points=False, max_iterations=8)
+        if block == 0:
+            pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)
+            st, plan = _bitwise(mvo, O, simctx, pb, fix_points=False, max_iterations=3)
+            assert plan["wgs"] <= 64
+    finally:
+        simlib.mvo_debug_set(b"ba_block_solver", 0)
+
+
+def test_concurrent_clients_share_the_launch_service(mvo, simlib):
+    """Several host threads with a ctx each submit windows at the same time: the launch thread packs them into grids within
+    its CU share, queues the next grid behind the running one, the completion thread publishes -- every window must come
+    out exactly as when it is solved alone."""
+    import threading
+
+    class Ctx(mvo.Context):
+        def __init__(self):
+            self.lib = simlib
+            h = C.c_void_p()
+            assert simlib.mvo_create(C.byref(h), 0) == 0
+            self.h, self.device, self.params = h, 0, {}
+
+    pbs = [mvo.synth.ba_problem(4, 300 + 40 * k, 50 + k) for k in range(6)]
+    ref = Ctx()
+    singles = [ref.bundle_adjustment(*_args(pb), fix_points=False, max_iterations=6) for pb in pbs]
+    ref.close()
+    simlib.mvo_debug_set(b"ba_cu_share", 16)  # (small share: forces several launches in flight)
+    out = [None] * len(pbs)
+
+    def work(k):
+        c = Ctx()
+        for _ in range(2):
+            out[k] = c.bundle_adjustment(*_args(pbs[k]), fix_points=False, max_iterations=6)
+        c.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(pbs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    simlib.mvo_debug_set(b"ba_cu_share", 0)
+    for (P, X, st), (Pb, Xb, stb) in zip(singles, out):
+        assert np.array_equal(P, Pb) and np.array_equal(X, Xb) and st["trials"] == stb["trials"]
