@@ -53,6 +53,9 @@ def parse(argv=None):
     ap.add_argument("--ba-mode", default="rebuild", choices=["rebuild", "resident", "none"],
                     help="rebuild (the metric): a new window is marshalled, uploaded and solved every frame; resident: one "
                          "pre-uploaded window re-solved every frame (kernel-side upper bound, round-1 behaviour)")
+    ap.add_argument("--ba-cut", default="auto", choices=["auto", "latency", "throughput"],
+                    help="mvo_ba_set_mode of the shards: latency = 32 workgroups per BA5 window (shortest solve), throughput = 16 "
+                         "(half the CUs per window); auto = throughput when more than 8 shards share the GPU")
     ap.add_argument("--windows", type=int, default=16, help="distinct BA windows per shard (rotated)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="1 (default): every shard overlaps extraction+matching of frame i+1 with the BA of frame i (second "
@@ -84,7 +87,8 @@ class FrameLoopCfg(C.Structure):  # host/driver/frame_loop.cpp: struct frame_loo
                 ("K4", C.c_double * 4), ("track", C.c_int32), ("keyframe_every", C.c_int32), ("map", C.c_void_p),
                 ("n_map", C.c_int32), ("T_w_c", C.c_void_p), ("pts3d", C.c_void_p), ("pts2d", C.c_void_p),
                 ("n_pairs", C.c_int32), ("kf_ref", C.c_void_p), ("kf_cur", C.c_void_p), ("kf_n", C.c_int32),
-                ("kf_T_curr_to_prev", C.c_void_p), ("kf_T_w_cur", C.c_void_p), ("kf_T_w_ref", C.c_void_p)]
+                ("kf_T_curr_to_prev", C.c_void_p), ("kf_T_w_cur", C.c_void_p), ("kf_T_w_ref", C.c_void_p),
+                ("ba_throughput", C.c_int32)]
 
 
 class FrameLoopState(C.Structure):
@@ -125,8 +129,9 @@ def window_pool(mvo, args, shard_id, n):
 class Shard:
     """One sequence: its frames resident in HBM, its own ctx/stream(s), its pool of BA windows, its native loop."""
 
-    def __init__(self, mvo, torch, device, shard_id, args, ba_mode, pipeline, frames=None, pool=None):
+    def __init__(self, mvo, torch, device, shard_id, args, ba_mode, pipeline, frames=None, pool=None, ba_cut=None):
         self.mvo = mvo
+        self.ba_cut = ba_cut or (args.ba_cut if args.ba_cut != "auto" else ("throughput" if args.streams > 8 else "latency"))
         self.id = shard_id
         self.args = args
         self.ctx = mvo.Context(device, max_keypoints=args.max_kp)
@@ -159,6 +164,7 @@ class Shard:
         c.ba_mode = {"none": 0, "rebuild": 1, "resident": 2}[ba_mode]
         c.pipeline = 1 if pipeline else 0
         c.fix_points = 1 if a.ba == "pose_only" else 0
+        c.ba_throughput = 1 if self.ba_cut == "throughput" else 0
         c.track = 1 if self.track is not None else 0
         c.keyframe_every = a.keyframe_every
         for i, k in enumerate(("fx", "fy", "cx", "cy")):

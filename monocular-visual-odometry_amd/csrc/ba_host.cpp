@@ -155,6 +155,8 @@ std::mutex* g_service_start = new std::mutex();
 // in the gaps between launches.  The completion thread waits for the launches in order and publishes their results.
 void BaService::run() {
     (void)hipSetDevice(device);
+    if (const char* e = std::getenv("MVO_BA_CU_SHARE")) g_ba_cu_share = std::atoi(e);        // development knobs, read once
+    if (const char* e = std::getenv("MVO_BA_BLOCK_SOLVER")) g_ba_block_solver = std::atoi(e);
     hipStream_t stream = nullptr;
     (void)hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     (void)ba_kernel_set_lds_limit();

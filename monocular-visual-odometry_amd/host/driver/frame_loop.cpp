@@ -45,6 +45,7 @@ struct frame_loop_cfg {
     const float *kf_ref, *kf_cur; // keyframe matches
     int32_t kf_n;
     const double *kf_T_curr_to_prev, *kf_T_w_cur, *kf_T_w_ref;  // 16 each
+    int32_t ba_throughput;        // 1: mvo_ba_set_mode(ctx_ba, MVO_BA_MODE_THROUGHPUT) (many sequences per GPU)
 };
 
 struct frame_loop_state {  // progress counters, read back by the caller
@@ -139,6 +140,7 @@ void* frame_loop_create(const frame_loop_cfg* cfg) {
     Loop* L = new Loop();
     L->c = *cfg;
     if (!L->c.ctx_ba) L->c.ctx_ba = L->c.ctx;
+    (void)mvo_ba_set_mode(L->c.ctx_ba, cfg->ba_throughput ? MVO_BA_MODE_THROUGHPUT : MVO_BA_MODE_LATENCY);
     L->kps.resize((size_t)cfg->max_kp + 16);
     L->matches.resize((size_t)cfg->max_kp + 16);
     if (cfg->track) {

@@ -5,7 +5,11 @@ import numpy as np, __graft_entry__ as g
 mvo = g.load_package(); ctx = mvo.Context(0)
 kinds = (("full", dict(fix_points=False)), ("pose_only", dict(fix_points=True)))
 wgs_list = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0]
+blk_list = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for kind, kw in kinds:
+ for blk in blk_list:
+  mvo.debug_set("ba_block_solver", blk)
+  print("== block solver", blk)
   for wgs in wgs_list:
     mvo.debug_set("ba_wgs", wgs)
     pb = mvo.synth.ba_problem(5, 2000, 7)
@@ -32,6 +36,7 @@ for kind, kw in kinds:
     mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
 # one-shot path (window rebuilt per call) and batches
+mvo.debug_set("ba_block_solver", 0)
 pb = mvo.synth.ba_problem(5, 2000, 7)
 a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
 mvo.debug_set("ba_wgs", 0)
@@ -39,3 +44,12 @@ for _ in range(3): ctx.bundle_adjustment(*a, fix_points=False)
 t0=time.perf_counter(); N=20
 for _ in range(N): ctx.bundle_adjustment(*a, fix_points=False)
 print("mvo_bundle_adjustment (plan + upload + solve + fetch) ms/call %.3f" % ((time.perf_counter()-t0)/N*1e3))
+# BASELINE configs[3]: BA10 window (10 poses / 4000 landmarks / ~36k edges)
+pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)
+a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+h = ctx.ba_prepare(*a, fix_points=False)
+for _ in range(2): ctx.ba_solve_resident(h); ctx.ba_fetch(h)
+t0=time.perf_counter(); N=5
+for _ in range(N): ctx.ba_solve_resident(h); P,X,st = ctx.ba_fetch(h)
+print("BA10 resident solve ms %.3f trials %d wgs %d" % ((time.perf_counter()-t0)/N*1e3, st["trials"], ctx.debug_ba_phases()["wgs"]))
+ctx.ba_release(h)
