@@ -24,14 +24,15 @@
 #include "mvo_internal.h"
 
 int ba_kernel_set_lds_limit();
-hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr);
+hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr, int slots);
 int ba_solver_class(int n);
 
 int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
 int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
 int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
-int g_ba_cu_share = 0;   // CUs a solver grid may take (0 = 3/4 of the device)
+int g_ba_cu_share = 0;   // CUs a solver grid may take (0 = all)
+int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
 namespace {
@@ -149,10 +150,10 @@ std::mutex* g_service_start = new std::mutex();
 
 // Launch thread: batches staged windows into grids and ISSUES them -- the next grid is queued behind the running one on
 // the same stream (it starts when its predecessor has left the CUs; the workgroups of a window need each other
-// resident, two grids must never be half-resident side by side).  A grid never takes more than `ba_cu_share` CUs (3/4 of
-// the device by default): the solver's workgroups own their CUs completely (all LDS, all VGPRs), so the rest is what the
-// callers' extraction / matching kernels run on WHILE a solve is in progress -- with the whole device taken they only ran
-// in the gaps between launches.  The completion thread waits for the launches in order and publishes their results.
+// resident, two grids must never be half-resident side by side).  The planner leaves a few CUs of every XCD to the
+// callers' extraction / matching kernels (ba_stage), so those run WHILE a solve is in progress; with whole XCDs taken
+// they only ran in the gaps between launches.  The completion thread waits for the launches in order and publishes
+// their results.
 void BaService::run() {
     (void)hipSetDevice(device);
     if (const char* e = std::getenv("MVO_BA_CU_SHARE")) g_ba_cu_share = std::atoi(e);        // development knobs, read once
@@ -176,7 +177,7 @@ void BaService::run() {
             std::unique_lock<std::mutex> lk(m);
             cv_work.wait(lk, [&] { return !q.empty(); });
             lap(l_idle);
-            int share = g_ba_cu_share > 0 ? g_ba_cu_share : (cus >= 64 ? cus - cus / 4 : cus);
+            int share = g_ba_cu_share > 0 ? g_ba_cu_share : cus;
             share = std::max(1, std::min(share, cus));
             {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
                 const auto now = std::chrono::steady_clock::now();
@@ -184,8 +185,12 @@ void BaService::run() {
                     it = (now - it->second > std::chrono::milliseconds(10)) ? seen.erase(it) : std::next(it);
                 const size_t fit = (size_t)std::max(1, share / std::max(1, q.front()->ws->plan.G));  // windows per grid
                 const size_t want = std::min<size_t>(std::min<size_t>(BA_MAX_BATCH, fit), seen.size());
-                if (q.size() < want)
-                    cv_work.wait_for(lk, std::chrono::microseconds(250), [&] { return q.size() >= want; });
+                // While a grid is still running there is no hurry: the next one is only worth queueing when it is full
+                // (a partial grid behind a running one would hold back the windows that arrive a moment later for a whole
+                // solve).  Once the device has no solver grid left, a partial batch waits a fraction of a solve at most.
+                auto full = [&] { return q.size() >= want; };
+                if (!full() && !flights.empty()) cv_work.wait(lk, [&] { return full() || flights.empty(); });
+                if (!full()) cv_work.wait_for(lk, std::chrono::microseconds(250), full);
             }
             cv_flight.wait(lk, [&] { return flights.size() < BA_MAX_FLIGHTS; });
             if (flight_pool.empty()) {
@@ -213,10 +218,11 @@ void BaService::run() {
         const int nj = fl->nj;
         BaBatch b{};
         b.nwin = nj;
-        int maxG = 1;
+        int maxG = 1, slots = 1;
         size_t lds = 16;
         for (int i = 0; i < nj; ++i) {
             BaWorkspace* ws = fl->jobs[i]->ws;
+            if (ws->plan.maxEg > BA_THREADS) slots = 2;
             (void)hipStreamWaitEvent(stream, ws->ready, 0);  // the window's upload (queued on its ctx stream)
             b.win[i] = (const BaDev*)(ws->dev + ws->plan.o_desc);
             b.tag_base[i] = ws->seq << 12;
@@ -231,7 +237,7 @@ void BaService::run() {
         b.same_l2_ok = g_ba_same_l2;
         (void)hipEventRecord(fl->e0, stream);
         const int cls = ba_solver_class(fl->jobs[0]->ws->plan.n);
-        fl->launch_err = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, cls == 32 && g_ba_block_solver ? -32 : cls);
+        fl->launch_err = ba_kernel_launch(b, maxG, lds, stream, g_ba_profile, cls == 32 && g_ba_block_solver ? -32 : cls, slots);
         (void)hipEventRecord(fl->e1, stream);
         lap(l_launch);
         {
@@ -283,6 +289,7 @@ void BaService::complete() {
         }
         cv_done.notify_all();
         cv_flight.notify_all();
+        cv_work.notify_all();  // (the launch thread may be waiting for "no grid left")
     }
 }
 BaService& service_for(int device) {
@@ -369,12 +376,18 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.runnable = !(F == 0 && (L == 0 || p->fix_points)) && (nfree > 0 || !p->fix_points);
     // ---- choose G and the landmark ranges (balanced by edge count).  A range's per-edge Jacobian rows live in the
     // registers of its 512 threads (BA_EDGE_SLOTS each), its landmark state and one chunk of the Schur operands in LDS.
-    // Latency mode (default): up to 32 workgroups (= one XCD) for the 5-keyframe window of the benchmark, ~300 edges each;
-    // throughput mode: up to 16 (~600 edges each), half the CUs per window at some 15 % more time per solve.  Larger
-    // windows get more workgroups either way: a range holds at most 1024 edges and must fit the LDS.
-    const int g_cap = ctx->ba_throughput_mode ? 16 : 32;
+    // The dispatcher places block b of a grid on XCD b % 8, whatever else runs there: a kernel of the caller's (extraction,
+    // matching) cannot finish before it got CUs on EVERY XCD.  A solver workgroup owns its CU, so a window never takes a
+    // whole XCD: `ba_xcd_reserve` CUs (default 4 of 32) stay free on each.  Latency mode (default): one window per XCD,
+    // up to 28 workgroups for the 5-keyframe window of the benchmark (~330 edges each); throughput mode: two windows per
+    // XCD, up to 14 (~670 edges each), half the CUs per window at some 25 % more time per solve.  Larger windows get more
+    // workgroups: a range holds at most 1024 edges and must fit the LDS.
+    static const int env_reserve = std::getenv("MVO_BA_XCD_RESERVE") ? std::atoi(std::getenv("MVO_BA_XCD_RESERVE")) : -1;
+    const int reserve = env_reserve >= 0 ? env_reserve : g_ba_xcd_reserve;
+    const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
+    const int g_cap = ctx->ba_throughput_mode ? per_xcd / 2 : per_xcd;
     int G = 1;
-    while (G < g_cap && E > 160 * G) G *= 2;
+    while (G < g_cap && E > 160 * G) G = std::min(2 * G, g_cap);
     if (g_ba_wgs > 0) G = g_ba_wgs;
     if (const char* env = std::getenv("MVO_BA_WGS")) G = std::max(1, std::atoi(env));
     G = std::max(1, std::min(G, BA_MAX_WGS));
@@ -437,7 +450,12 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         if (fits && maxEg <= BA_EDGE_SLOTS * BA_THREADS && maxLg < 32000) break;
         if (G >= BA_MAX_WGS)
             return mvo_set_err(ctx, MVO_ERR_CAPACITY, "BA window too large for the LDS-resident solver", hipSuccess);
-        G = std::min(2 * G, BA_MAX_WGS);
+        {   // next larger candidate: multiples of the per-XCD allowance and powers of two
+            int next = BA_MAX_WGS;
+            for (int c : {2, 4, 8, 16, 32, 64, 128, 256, per_xcd / 2, per_xcd, 2 * per_xcd, 4 * per_xcd, 8 * per_xcd})
+                if (c > G && c < next) next = c;
+            G = next;
+        }
     }
     P.nsplit = nsplit;
     P.npar = npar;

@@ -736,7 +736,8 @@ __device__ __forceinline__ void edge_Y(const EdgeRegs& r, const double* cc, doub
 // PROF: per-phase cycle counters; NR: reduced-solve flavour -- 32: one-wave register solver for n + 1 <= 32 rows; 64 / -32:
 // workgroup-wide block solver for n + 1 <= 64 / 32 rows; 0: LDS solver (any n).  Separate instantiations: the solvers
 // differ widely in register use.
-template <bool PROF, int NR>
+// SLOTS: edges per thread (1: every range of the launch has <= 512 edges; the code of the second edge is left out).
+template <bool PROF, int NR, int SLOTS>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     // window = blockIdx % stride; the stride is a multiple of 8 whenever several windows share a launch: with the
     // dispatcher's round-robin placement (block b on XCD b % 8) the workgroups of a window then share one XCD (one L2)
@@ -908,93 +909,79 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     EdgeRegs er;
 #pragma unroll
     for (int c = 0; c < 6; ++c) er.a0[c] = er.a1[c] = er.x[c] = 0;
-    const bool have0 = tid < Eg, have1 = tid + BA_THREADS < Eg;
+    const bool have0 = tid < Eg, have1 = SLOTS > 1 && tid + BA_THREADS < Eg;
     const int e0_p = have0 ? W.epose[tid] : 0, e0_l = have0 ? W.ept[tid] : 0, e0_sl = have0 ? sSlot[e0_p] : -1;
     const int e1_p = have1 ? W.epose[tid + BA_THREADS] : 0, e1_l = have1 ? W.ept[tid + BA_THREADS] : 0,
               e1_sl = have1 ? sSlot[e1_p] : -1;
-    const int nslot = Eg > BA_THREADS ? 2 : 1;  // (uniform)
-// BA_FOR_EDGES ... BA_END_EDGES: the loop over this thread's (at most two) edges with `el` = local edge index, `r` = its
-// rows, `e_l` / `e_sl` = its landmark / pose slot.  One copy of the body, not unrolled: the kernel is short of registers,
-// not of time here.  (Spelled as a macro, element by element: behind a lambda capture the compiler parks the register-
-// resident rows in scratch memory.)
-#define BA_FOR_EDGES                                                         \
-    _Pragma("unroll 1") for (int s_ = 0; s_ < nslot; ++s_) {                 \
-        if (s_ == 0 ? !have0 : !have1) continue;                             \
-        EdgeRegs r;                                                          \
-        {                                                                    \
-            const double* q_ = W.E2 + BA_E2S * tid;                          \
-            _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {               \
-                r.a0[c_] = s_ ? q_[c_] : er.a0[c_];                          \
-                r.a1[c_] = s_ ? q_[6 + c_] : er.a1[c_];                      \
-                r.x[c_] = s_ ? q_[12 + c_] : er.x[c_];                       \
-            }                                                                \
+    constexpr int nslot = SLOTS;
+// BA_EDGES(BODY): BODY(el, rows, landmark, slot, e~ pair) for this thread's (at most two) edges -- the first one straight from
+// its registers, the second one (only in ranges with more than 512 edges) from the E2 area.  BODY is a statement macro;
+// `break` leaves it.  (Spelled with macros, element by element: behind a lambda capture the compiler parks the
+// register-resident rows in scratch memory.)
+#define BA_EDGES(BODY)                                                       \
+    if (have0) do { BODY(tid, er, e0_l, e0_sl, ee0) } while (0);             \
+    if (nslot > 1 && have1) do {                                             \
+        EdgeRegs r1_;                                                        \
+        const double* q_ = W.E2 + BA_E2S * tid;                              \
+        _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {                   \
+            r1_.a0[c_] = q_[c_];                                             \
+            r1_.a1[c_] = q_[6 + c_];                                         \
+            r1_.x[c_] = q_[12 + c_];                                         \
         }                                                                    \
-        const int el = tid + s_ * BA_THREADS, e_l = s_ ? e1_l : e0_l, e_sl = s_ ? e1_sl : e0_sl;
-#define BA_END_EDGES }
+        BODY(tid + BA_THREADS, r1_, e1_l, e1_sl, ee1)                        \
+    } while (0);
 
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus), kept in registers;
         // X~ and e~ also go to the staging area for the landmark blocks
         PH_BEGIN();
         double ee0[2] = {0, 0}, ee1[2] = {0, 0};  // e~ of the two edges (needed again when the chain rows are staged)
-#pragma unroll 1
-        for (int s = 0; s < nslot; ++s) {
-            if (s == 0 ? !have0 : !have1) continue;
-            const int el = tid + s * BA_THREADS, p = s ? e1_p : e0_p, sl = s ? e1_sl : e0_sl;
-            EdgeRegs r;
-            double ee[2];
-            {
-                double Xc[3], ew[2], r0, r1;
-                const double chi = edge_error(B, W, el, sR, sT, Xc, ew);
-                huber(chi, B.delta, r0, r1);
-                const double sw = sqrt(r1);
-                const double x = Xc[0], y = Xc[1], z = Xc[2], z2 = z * z, f = B.f;
-                if (sl >= 0) {
-                    const double J0[6] = {x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f};
-                    const double J1[6] = {(1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f};
+// rows of edge `el` (pose p, slot sl) into r, its whitened error into ee; X~ and e~ also into the staging area
+#define BA_LINEARIZE(el, r, p, sl, ee)                                                                              \
+    {                                                                                                               \
+        double Xc[3], ew[2], rho0_, rho1_;                                                                          \
+        const double chi = edge_error(B, W, el, sR, sT, Xc, ew);                                                    \
+        huber(chi, B.delta, rho0_, rho1_);                                                                          \
+        const double sw = sqrt(rho1_);                                                                              \
+        const double x = Xc[0], y = Xc[1], z = Xc[2], z2 = z * z, f = B.f;                                          \
+        if (sl >= 0) {                                                                                              \
+            const double J0[6] = {x * y / z2 * f, -(1 + (x * x / z2)) * f, y / z * f, -1. / z * f, 0, x / z2 * f};   \
+            const double J1[6] = {(1 + y * y / z2) * f, -x * y / z2 * f, -x / z * f, 0, -1. / z * f, y / z2 * f};    \
+            _Pragma("unroll") for (int c = 0; c < 6; ++c) {                                                         \
+                r.a0[c] = sw * (B.lc00 * J0[c] + B.lc01 * J1[c]);                                                   \
+                r.a1[c] = sw * (B.lc11 * J1[c]);                                                                    \
+            }                                                                                                       \
+        } else {                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 6; ++c) r.a0[c] = r.a1[c] = 0;                                    \
+        }                                                                                                           \
+        ee[0] = sw * ew[0];                                                                                         \
+        ee[1] = sw * ew[1];                                                                                         \
+        _Pragma("unroll") for (int c = 0; c < 6; ++c) r.x[c] = 0;                                                   \
+        if (!B.fix_points) {                                                                                        \
+            const double* R = sR + 9 * (p);                                                                         \
+            const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};                                    \
+            double* Xs = stage + BA_SXS * (el);                                                                     \
+            _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                         \
+                double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);                         \
+                double j1 = -1. / z * (t1[0] * R[c] + t1[1] * R[3 + c] + t1[2] * R[6 + c]);                         \
+                r.x[c] = sw * (B.lc00 * j0 + B.lc01 * j1);                                                          \
+                r.x[3 + c] = sw * (B.lc11 * j1);                                                                    \
+            }                                                                                                       \
+            _Pragma("unroll") for (int c = 0; c < 6; ++c) Xs[c] = r.x[c];                                           \
+            Xs[6] = ee[0];                                                                                          \
+            Xs[7] = ee[1];                                                                                          \
+        }                                                                                                           \
+    }
+        if (have0) BA_LINEARIZE(tid, er, e0_p, e0_sl, ee0)
+        if (nslot > 1 && have1) {
+            EdgeRegs r1;
+            BA_LINEARIZE(tid + BA_THREADS, r1, e1_p, e1_sl, ee1)
+            double* q = W.E2 + BA_E2S * tid;
 #pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        r.a0[c] = sw * (B.lc00 * J0[c] + B.lc01 * J1[c]);
-                        r.a1[c] = sw * (B.lc11 * J1[c]);
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) r.a0[c] = r.a1[c] = 0;
-                }
-                ee[0] = sw * ew[0];
-                ee[1] = sw * ew[1];
-#pragma unroll
-                for (int c = 0; c < 6; ++c) r.x[c] = 0;
-                if (!B.fix_points) {
-                    const double* R = sR + 9 * p;
-                    const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};
-                    double* Xs = stage + BA_SXS * el;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);
-                        double j1 = -1. / z * (t1[0] * R[c] + t1[1] * R[3 + c] + t1[2] * R[6 + c]);
-                        r.x[c] = sw * (B.lc00 * j0 + B.lc01 * j1);
-                        r.x[3 + c] = sw * (B.lc11 * j1);
-                    }
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) Xs[c] = r.x[c];
-                    Xs[6] = ee[0];
-                    Xs[7] = ee[1];
-                }
-            }
-            if (s == 0) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) er.a0[c] = r.a0[c], er.a1[c] = r.a1[c], er.x[c] = r.x[c];
-                ee0[0] = ee[0], ee0[1] = ee[1];
-            } else {
-                ee1[0] = ee[0], ee1[1] = ee[1];
-                double* q = W.E2 + BA_E2S * tid;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    q[c] = r.a0[c];
-                    q[6 + c] = r.a1[c];
-                    q[12 + c] = r.x[c];
-                }
+            for (int c = 0; c < 6; ++c) {
+                q[c] = r1.a0[c];
+                q[6 + c] = r1.a1[c];
+                q[12 + c] = r1.x[c];
             }
         }
         __syncthreads();
@@ -1043,57 +1030,80 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 while (p1 < B.F && sPoseStart[p1 + 1] - sPoseStart[p0] <= mcap) ++p1;
                 const int eg0 = sPoseStart[p0], eg1 = sPoseStart[p1];
                 if (eg1 - eg0 > mcap) error = 1;  // (the planner sizes the area for the largest pose of any range)
+#define BA_BODY_STAGE_M(el, r, l_, sl_, ee)                                   \
+    if ((el) < eg0 || (el) >= eg1) break;                                    \
+    double* Mr = stage + BA_MSTRIDE * ((el)-eg0);                            \
+    _Pragma("unroll") for (int c = 0; c < 6; ++c) {                          \
+        Mr[c] = r.a0[c];                                                     \
+        Mr[7 + c] = r.a1[c];                                                 \
+    }                                                                        \
+    Mr[6] = ee[0];                                                           \
+    Mr[13] = ee[1];
                 if (!error) {
-                    BA_FOR_EDGES
-                    (void)e_l, (void)e_sl;
-                    if (el < eg0 || el >= eg1) continue;
-                    double* Mr = stage + BA_MSTRIDE * (el - eg0);
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        Mr[c] = r.a0[c];
-                        Mr[7 + c] = r.a1[c];
-                    }
-                    Mr[6] = s_ ? ee1[0] : ee0[0];
-                    Mr[13] = s_ ? ee1[1] : ee0[1];
-                    BA_END_EDGES
+                    BA_EDGES(BA_BODY_STAGE_M)
                 }
                 __syncthreads();
-                for (int p = p0 + wave; p < p1 && !error; p += BA_WAVES) {
-                    const int sl = sSlot[p];
-                    if (sl < 0) continue;
-                    const int s = sPoseStart[p] - eg0, e = sPoseStart[p + 1] - eg0;
-                    if (batch.use_mfma) {
-                        const int rows = 2 * (e - s), nfull = rows / 4;
-                        const bool cv = col < 7;
-                        // row 2 s + 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
-                        const double* pm = stage + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? col : 0);
+                if (batch.use_mfma && !error) {
+                    // two free poses share a chain: columns 0..6 of the 16-wide operand are the rows [A~ | e~] of the first,
+                    // columns 8..14 those of the second (zero rows once the shorter one has ended: exact no-ops), so the
+                    // diagonal 7 x 7 blocks of the product are the two pose blocks, each its own fma chain over its rows
+                    int nfp = 0;
+                    for (int p = p0; p < p1; ++p) nfp += sSlot[p] >= 0;
+                    for (int pair = wave; 2 * pair < nfp; pair += BA_WAVES) {
+                        int pa = -1, pb = -1, idx = 0;
+                        for (int p = p0; p < p1; ++p) {
+                            if (sSlot[p] < 0) continue;
+                            if (idx == 2 * pair) pa = p;
+                            if (idx == 2 * pair + 1) pb = p;
+                            ++idx;
+                        }
+                        const bool second = col >= 8;
+                        const int pp = second ? pb : pa;
+                        const int cc7 = col & 7;
+                        const bool cv = cc7 < 7 && pp >= 0;
+                        const int sA = sPoseStart[pa] - eg0, rowsA = 2 * (sPoseStart[pa + 1] - sPoseStart[pa]);
+                        const int sB = pb >= 0 ? sPoseStart[pb] - eg0 : 0, rowsB = pb >= 0 ? 2 * (sPoseStart[pb + 1] - sPoseStart[pb]) : 0;
+                        const int s = second ? sB : sA, rows = second ? rowsB : rowsA;
+                        const int rmax = max(rowsA, rowsB);
+                        // row 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
+                        const double* pm = stage + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? cc7 : 0);
+                        const int kq = lane >> 4;
                         v4d acc = {0, 0, 0, 0};
                         int st = 0;
-                        for (; st + 4 <= nfull; st += 4) {
-                            const double v0 = pm[0], v1 = pm[2 * BA_MSTRIDE], v2 = pm[4 * BA_MSTRIDE], v3 = pm[6 * BA_MSTRIDE];
-                            const double w0 = cv ? v0 : 0.0, w1 = cv ? v1 : 0.0, w2 = cv ? v2 : 0.0, w3 = cv ? v3 : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, w2, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
+                        for (; 4 * (st + 4) <= rmax; st += 4) {
+                            const double v0 = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
+                            const double v1 = (cv && 4 * st + 4 + kq < rows) ? pm[2 * BA_MSTRIDE] : 0.0;
+                            const double v2 = (cv && 4 * st + 8 + kq < rows) ? pm[4 * BA_MSTRIDE] : 0.0;
+                            const double v3 = (cv && 4 * st + 12 + kq < rows) ? pm[6 * BA_MSTRIDE] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc, 0, 0, 0);
                             pm += 8 * BA_MSTRIDE;
                         }
-                        for (; 4 * st < rows; ++st) {  // remaining steps, the last one possibly with fewer than 4 rows
-                            const bool ok = cv && 4 * st + (lane >> 4) < rows;
-                            const double v = ok ? pm[0] : 0.0;
+                        for (; 4 * st < rmax; ++st) {  // remaining steps, the last one possibly with fewer than 4 rows
+                            const double v = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
                             pm += 2 * BA_MSTRIDE;
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const int rg = (lane >> 4) + 4 * j;  // acc[j] = entry (rg, col)
-                            if (rg < 7 && col <= rg) {
-                                const int pk = rg * (rg + 1) / 2 + col;
+                            const bool mine = second ? (rg >= 8 && rg < 15 && pb >= 0) : rg < 7;
+                            const int r7 = rg & 7;
+                            if (mine && cc7 <= r7 && cc7 < 7) {
+                                const int sl = sSlot[pp], pk = r7 * (r7 + 1) / 2 + cc7;
                                 if (hp_local) W.hpl[BA_HP * sl + pk] = acc[j];
                                 else gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
                             }
                         }
-                    } else if (lane < BA_HP) {  // validation path: the same fma chains on the vector ALU
+                    }
+                } else if (!error) {
+                    for (int p = p0 + wave; p < p1; p += BA_WAVES) {
+                        const int sl = sSlot[p];
+                        if (sl < 0 || lane >= BA_HP) continue;
+                        const int s = sPoseStart[p] - eg0, e = sPoseStart[p + 1] - eg0;
+                        // validation path: the same fma chains on the vector ALU
                         int i = 0;
                         while ((i + 1) * (i + 2) / 2 <= lane) ++i;
                         const int j = lane - i * (i + 1) / 2;
@@ -1227,25 +1237,28 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                             }
                         }
                     }
-                    for (int rank = 0; rank <= B.max_dup; ++rank) {
-                        BA_FOR_EDGES
-                        const int l = e_l, sl = e_sl;
-                        if (sl < 0 || 3 * l + 2 < c0 || 3 * l >= c1 || W.dup[el] != rank) continue;
-                        double Y[6];
-                        edge_Y(r, W.Cc + BA_XS * l, Y);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const int colg = 3 * l + k;
-                            if (colg < c0 || colg >= c1) continue;
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                double* u = W.U + u_index(colg - c0, 6 * sl + c, ldu);
-                                const double v = r.a0[c] * Y[k] + r.a1[c] * Y[3 + k];
-                                *u = (rank == 0 ? 0.0 : *u) + v;
-                            }
+#define BA_BODY_UFILL(el, r, l_, sl_, ee)                                                          \
+    const int l = l_, sl = sl_;                                                                   \
+    if (sl < 0 || 3 * l + 2 < c0 || 3 * l >= c1 || (has_dups && W.dup[el] != rank)) break;         \
+    double Y[6];                                                                                  \
+    edge_Y(r, W.Cc + BA_XS * l, Y);                                                               \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                               \
+        const int colg = 3 * l + k;                                                               \
+        if (!whole && (colg < c0 || colg >= c1)) continue;                                        \
+        double* u = W.U + u_index(colg - c0, 6 * sl, ldu);                                        \
+        _Pragma("unroll") for (int c = 0; c < 6; ++c) {                                           \
+            const double v = r.a0[c] * Y[k] + r.a1[c] * Y[3 + k];                                 \
+            if (has_dups && rank > 0) u[c] = u[c] + v;                                            \
+            else u[c] = 0.0 + v;                                                                  \
+        }                                                                                         \
+    }
+                    {
+                        const bool has_dups = B.max_dup > 0;
+                        const bool whole = c0 == 0 && c1 >= ncol;  // (every landmark column lies inside the chunk)
+                        for (int rank = 0; rank <= B.max_dup; ++rank) {
+                            BA_EDGES(BA_BODY_UFILL)
+                            __syncthreads();
                         }
-                        BA_END_EDGES
-                        __syncthreads();
                     }
                     STAMP(3);
                     // ---- chains of this chunk; after the last chunk the sums are published (or kept when the window has
@@ -1454,7 +1467,31 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             // ============= T4/T5: back-substitute the own landmarks, computeScale, push + apply the update
             double scale = 0;
             if (g == 0 && tid < 6 * B.F && sSlot[tid / 6] >= 0) scale += sDx[tid] * (lambda * sDx[tid] + sBp[tid]);
-            if (tid >= BA_THREADS - 64 && tid - (BA_THREADS - 64) < B.F) {  // push + oplus of the poses: last wave
+            if (!B.fix_points && do_schur) {
+                // r = C^T (b_l - W^T dx_p) = C^T b_l - sum over the landmark's observations (ascending edge order) of
+                // Y^T (A~ dx_pose): every edge thread leaves its three terms in the (now free) U area (zeros for an
+                // observation from a fixed pose)
+#define BA_BODY_BACKSUB(el, r, l_, sl_, ee)                                     \
+    double t3[3] = {0.0, 0.0, 0.0};                                            \
+    if (sl_ >= 0) {                                                            \
+        const double* sx = sSol + 6 * sl_;                                     \
+        double s0 = 0, s1 = 0;                                                 \
+        _Pragma("unroll") for (int c = 0; c < 6; ++c) {                        \
+            s0 = __builtin_fma(r.a0[c], sx[c], s0);                            \
+            s1 = __builtin_fma(r.a1[c], sx[c], s1);                            \
+        }                                                                      \
+        double Y[6];                                                           \
+        edge_Y(r, W.Cc + BA_XS * l_, Y);                                       \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) t3[k] = Y[k] * s0 + Y[3 + k] * s1; \
+    }                                                                          \
+    _Pragma("unroll") for (int k = 0; k < 3; ++k) W.U[3 * (el) + k] = t3[k];
+                BA_EDGES(BA_BODY_BACKSUB)
+            }
+            STAMP(14);
+            __syncthreads();
+            STAMP(15);
+            // the poses (last wave: push + oplus, a long serial chain) and the landmarks (first waves) update side by side
+            if (tid >= BA_THREADS - 64 && tid - (BA_THREADS - 64) < B.F) {
                 const int p = tid - (BA_THREADS - 64);
                 for (int i = 0; i < 8; ++i) sPbak[8 * p + i] = sP[8 * p + i];
                 if (sSlot[p] >= 0) {
@@ -1464,36 +1501,27 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                 }
             }
             if (!B.fix_points) {
-                // r = C^T (b_l - W^T dx_p) = C^T b_l - sum over the landmark's observations (ascending edge order) of
-                // Y^T (A~ dx_pose): every edge thread leaves its three terms in the (now free) U area
-                if (do_schur) {
-                    BA_FOR_EDGES
-                    if (e_sl < 0) continue;
-                    const double* sx = sSol + 6 * e_sl;
-                    double s0 = 0, s1 = 0;
-#pragma unroll
-                    for (int c = 0; c < 6; ++c) {
-                        s0 = __builtin_fma(r.a0[c], sx[c], s0);
-                        s1 = __builtin_fma(r.a1[c], sx[c], s1);
-                    }
-                    double Y[6];
-                    edge_Y(r, W.Cc + BA_XS * e_l, Y);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) W.U[3 * el + k] = Y[k] * s0 + Y[3 + k] * s1;
-                    BA_END_EDGES
-                }
-                STAMP(14);
-                __syncthreads();
-                STAMP(15);
                 for (int l = tid; l < Lg; l += BA_THREADS) {
                     double r[3] = {W.cl[3 * l], W.cl[3 * l + 1], W.cl[3 * l + 2]};
-                    if (do_schur)
-                        for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
-                            const int el = W.ptl[k];
-                            if (sSlot[W.epose[el]] < 0) continue;
+                    if (do_schur) {
+                        const int k1 = W.pts0[l + 1];
+                        for (int k = W.pts0[l]; k < k1; k += 4) {  // (indices, then terms, fetched four edges at a time)
+                            int e4[4];
+                            double t4[4][3];
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) r[c] = r[c] - W.U[3 * el + c];
+                            for (int u = 0; u < 4; ++u) e4[u] = k + u < k1 ? W.ptl[k + u] : -1;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) t4[u][c] = e4[u] >= 0 ? W.U[3 * e4[u] + c] : 0.0;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (e4[u] >= 0) {
+#pragma unroll
+                                    for (int c = 0; c < 3; ++c) r[c] = r[c] - t4[u][c];
+                                }
                         }
+                    }
                     const double* cc = W.Cc + BA_XS * l;
                     double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
                     if (!ok2) d[0] = d[1] = d[2] = 0;
@@ -1637,21 +1665,26 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
 
 // ------------------------------------------------------------------------------------------------ launch
 typedef void (*ba_kernel_fn)(BaBatch);
-static ba_kernel_fn ba_kernel_for(int profile, int nr) {
-    if (profile) return nr == 32 ? k_ba_lm<true, 32> : (nr == -32 ? k_ba_lm<true, -32> : (nr == 64 ? k_ba_lm<true, 64> : k_ba_lm<true, 0>));
-    return nr == 32 ? k_ba_lm<false, 32> : (nr == -32 ? k_ba_lm<false, -32> : (nr == 64 ? k_ba_lm<false, 64> : k_ba_lm<false, 0>));
+template <bool PROF, int SLOTS>
+static ba_kernel_fn ba_kernel_pick(int nr) {
+    return nr == 32 ? k_ba_lm<PROF, 32, SLOTS> : (nr == -32 ? k_ba_lm<PROF, -32, SLOTS> : (nr == 64 ? k_ba_lm<PROF, 64, SLOTS> : k_ba_lm<PROF, 0, SLOTS>));
+}
+static ba_kernel_fn ba_kernel_for(int profile, int nr, int slots) {
+    if (profile) return slots > 1 ? ba_kernel_pick<true, 2>(nr) : ba_kernel_pick<true, 1>(nr);
+    return slots > 1 ? ba_kernel_pick<false, 2>(nr) : ba_kernel_pick<false, 1>(nr);
 }
 int ba_kernel_set_lds_limit() {
     int bad = 0;
     for (int profile = 0; profile < 2; ++profile)
         for (int nr : {32, -32, 64, 0})
-            bad |= hipFuncSetAttribute((const void*)ba_kernel_for(profile, nr), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       BA_LDS_BUDGET) != hipSuccess;
+            for (int slots = 1; slots <= 2; ++slots)
+                bad |= hipFuncSetAttribute((const void*)ba_kernel_for(profile, nr, slots), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           BA_LDS_BUDGET) != hipSuccess;
     return bad ? -1 : 0;
 }
 // solver class of a window with n unknowns (windows of one launch share it)
 int ba_solver_class(int n) { return n + 1 <= 32 ? 32 : (n + 1 <= 64 ? 64 : 0); }
-hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr) {
-    hipLaunchKernelGGL(ba_kernel_for(profile, nr), dim3(batch.stride * max_wgs), dim3(BA_THREADS), lds_bytes, stream, batch);
+hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr, int slots) {
+    hipLaunchKernelGGL(ba_kernel_for(profile, nr, slots), dim3(batch.stride * max_wgs), dim3(BA_THREADS), lds_bytes, stream, batch);
     return hipGetLastError();
 }

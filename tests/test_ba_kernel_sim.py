@@ -47,7 +47,7 @@ def test_kernel_source_reproduces_the_blocked_oracle_on_the_benchmarked_window(m
     """BA5 as bench.py solves it: 5 poses / 2000 landmarks / ~9.4k edges, no fixed vertex, 32 workgroups x 512 threads,
     all 50 iterations, every trial's lambda / chi2 / rho / decision, final poses and landmarks: zero difference."""
     st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
-    assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 32
+    assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 28  # (one XCD minus the 4 CUs left to other kernels)
 
 
 @pytest.mark.parametrize("mfma", [1, 0])
@@ -97,11 +97,11 @@ def test_batched_windows_equal_their_single_solves(mvo, simctx):
 
 
 def test_throughput_mode_cuts_the_window_into_fewer_workgroups(mvo, O, simctx):
-    """mvo_ba_set_mode(THROUGHPUT): the benchmarked window on 16 workgroups -- more than 512 edges per range (the second
+    """mvo_ba_set_mode(THROUGHPUT): the benchmarked window on 14 workgroups (two windows per XCD) -- more than 512 edges per range (the second
     edge of a thread keeps its rows in LDS), the Schur operands in two chunks -- still bit for bit the oracle."""
     simctx.ba_set_mode("throughput")
     st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
-    assert plan["wgs"] == 16 and plan["nsplit"] == 2 and st["iterations"] == 50
+    assert plan["wgs"] == 14 and plan["nsplit"] >= 2 and st["iterations"] == 50
     _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
 
 

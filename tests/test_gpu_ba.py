@@ -251,7 +251,7 @@ def test_bitwise_the_benchmarked_window_all_50_iterations(mvo, O, ctx):
     """The exact window bench.py solves (BA5: 5 poses / 2000 landmarks / ~9.4k edges, seed 7, NO fixed vertex, 50
     iterations): north-star '1e-4 on poses and landmarks' is met with zero difference."""
     st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
-    assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 32
+    assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 28  # (one XCD minus the 4 CUs left to other kernels)
 
 
 def test_bitwise_config4_ba10_window(mvo, O, ctx):
