@@ -150,13 +150,17 @@ __device__ bool gather_tagged(const u64* src, int count, int per, size_t stride,
     return fine;
 }
 
-__device__ void quat_normalize(double* q) {
-    if (q[0] < 0)
-        for (int i = 0; i < 4; ++i) q[i] = -q[i];
+// (every loop of the pose helpers is unrolled: static indices keep the small arrays in registers -- indexed dynamically
+// they live in scratch memory, and the pose update is a serial chain on the critical path of an LM trial)
+__device__ __forceinline__ void quat_normalize(double* q) {
+    const bool neg = q[0] < 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = neg ? -q[i] : q[i];
     double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+#pragma unroll
     for (int i = 0; i < 4; ++i) q[i] /= n;
 }
-__device__ void quat_from_R(const double* R, double* q) {  // Eigen::Quaterniond(Matrix3d)
+__device__ __forceinline__ void quat_from_R(const double* R, double* q) {  // Eigen::Quaterniond(Matrix3d)
     double tr = R[0] + R[4] + R[8];
     if (tr > 0) {
         double t = sqrt(tr + 1.0);
@@ -193,7 +197,7 @@ __device__ void quat_from_R(const double* R, double* q) {  // Eigen::Quaterniond
         }
     }
 }
-__device__ void quat_to_R(const double* q, double* R) {  // Eigen toRotationMatrix
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {  // Eigen toRotationMatrix
     const double w = q[0], x = q[1], y = q[2], z = q[3];
     const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
     const double twx = tx * w, twy = ty * w, twz = tz * w;
@@ -209,7 +213,7 @@ __device__ void quat_to_R(const double* q, double* R) {  // Eigen toRotationMatr
     R[7] = tyz + twx;
     R[8] = 1 - (txx + tyy);
 }
-__device__ void inv3(const double* A, double* I) {
+__device__ __forceinline__ void inv3(const double* A, double* I) {
     double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
     double id = 1.0 / (A[0] * c0 + A[1] * c1 + A[2] * c2);
     I[0] = c0 * id;
@@ -223,9 +227,10 @@ __device__ void inv3(const double* A, double* I) {
     I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
 }
 // [R t; 0 1]^-1 of a row-major 4x4 -> Ri (9), ti (3)
-__device__ void invert_Rt(const double* T, double* Ri, double* ti) {
+__device__ __forceinline__ void invert_Rt(const double* T, double* Ri, double* ti) {
     double R[9] = {T[0], T[1], T[2], T[4], T[5], T[6], T[8], T[9], T[10]};
     inv3(R, Ri);
+#pragma unroll
     for (int i = 0; i < 3; ++i) ti[i] = -(Ri[3 * i] * T[3] + Ri[3 * i + 1] * T[7] + Ri[3 * i + 2] * T[11]);
 }
 
@@ -255,15 +260,18 @@ __device__ __forceinline__ void ba_sincos(double x, double* s, double* c) {
 }
 
 // VertexSE3Expmap::oplusImpl: T <- SE3Quat::exp(u) * T   (pose = q[4] t[3])
-__device__ void pose_oplus(double* P, const double* u) {
+__device__ __forceinline__ void pose_oplus(double* P, const double* u) {
     const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
     double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
     double O[9] = {0, -om[2], om[1], om[2], 0, -om[0], -om[1], om[0], 0};
     double O2[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) O2[3 * i + j] = O[3 * i] * O[j] + O[3 * i + 1] * O[3 + j] + O[3 * i + 2] * O[6 + j];
     double R[9], V[9];
     if (theta < 0.00001) {
+#pragma unroll
         for (int i = 0; i < 9; ++i) {
             R[i] = (i % 4 == 0 ? 1.0 : 0.0) + O[i] + O2[i];
             V[i] = R[i];
@@ -272,6 +280,7 @@ __device__ void pose_oplus(double* P, const double* u) {
         double st, ct;
         ba_sincos(theta, &st, &ct);
         double a = st / theta, b = (1 - ct) / (theta * theta), c = (theta - st) / (theta * theta * theta);
+#pragma unroll
         for (int i = 0; i < 9; ++i) {
             double I = (i % 4 == 0 ? 1.0 : 0.0);
             R[i] = I + a * O[i] + b * O2[i];
@@ -281,18 +290,22 @@ __device__ void pose_oplus(double* P, const double* u) {
     double dq[4], dt[3], dR[9], nt[3];
     quat_from_R(R, dq);
     quat_normalize(dq);
+#pragma unroll
     for (int i = 0; i < 3; ++i) dt[i] = V[3 * i] * up[0] + V[3 * i + 1] * up[1] + V[3 * i + 2] * up[2];
     quat_to_R(dq, dR);
-    const double* q = P;
-    const double* t = P + 4;
+    const double q[4] = {P[0], P[1], P[2], P[3]};
+    const double t[3] = {P[4], P[5], P[6]};
+#pragma unroll
     for (int i = 0; i < 3; ++i) nt[i] = dt[i] + dR[3 * i] * t[0] + dR[3 * i + 1] * t[1] + dR[3 * i + 2] * t[2];
     double nq[4] = {dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2] - dq[3] * q[3],
                     dq[0] * q[1] + dq[1] * q[0] + dq[2] * q[3] - dq[3] * q[2],
                     dq[0] * q[2] - dq[1] * q[3] + dq[2] * q[0] + dq[3] * q[1],
                     dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1] + dq[3] * q[0]};
+    quat_normalize(nq);
+#pragma unroll
     for (int i = 0; i < 4; ++i) P[i] = nq[i];
+#pragma unroll
     for (int i = 0; i < 3; ++i) P[4 + i] = nt[i];
-    quat_normalize(P);
 }
 
 __device__ __forceinline__ void huber(double e, double delta, double& rho0, double& rho1) {
@@ -1070,6 +1083,16 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                         const int kq = lane >> 4;
                         v4d acc = {0, 0, 0, 0};
                         int st = 0;
+                        const int rmin = pb >= 0 ? min(rowsA, rowsB) : rowsA;
+                        for (; 4 * (st + 4) <= rmin; st += 4) {  // (both poses still have rows: no row predicate)
+                            const double v0 = pm[0], v1 = pm[2 * BA_MSTRIDE], v2 = pm[4 * BA_MSTRIDE], v3 = pm[6 * BA_MSTRIDE];
+                            const double w0 = cv ? v0 : 0.0, w1 = cv ? v1 : 0.0, w2 = cv ? v2 : 0.0, w3 = cv ? v3 : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, w2, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
+                            pm += 8 * BA_MSTRIDE;
+                        }
                         for (; 4 * (st + 4) <= rmax; st += 4) {
                             const double v0 = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
                             const double v1 = (cv && 4 * st + 4 + kq < rows) ? pm[2 * BA_MSTRIDE] : 0.0;
@@ -1493,6 +1516,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             // the poses (last wave: push + oplus, a long serial chain) and the landmarks (first waves) update side by side
             if (tid >= BA_THREADS - 64 && tid - (BA_THREADS - 64) < B.F) {
                 const int p = tid - (BA_THREADS - 64);
+#pragma unroll
                 for (int i = 0; i < 8; ++i) sPbak[8 * p + i] = sP[8 * p + i];
                 if (sSlot[p] >= 0) {
                     pose_oplus(sP + 8 * p, sDx + 6 * p);
