@@ -70,8 +70,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-sequence and resident-window runs")
     ap.add_argument("--cpu-frames", type=int, default=150)
-    ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="also time the oracle with this many host threads, one sequence shard each (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=-1,
+                    help="also time the oracle with this many host threads, one sequence shard each (-1 = all cores, 0 = skip)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--max-kp", type=int, default=2000)
@@ -88,7 +88,7 @@ class FrameLoopCfg(C.Structure):  # host/driver/frame_loop.cpp: struct frame_loo
                 ("n_map", C.c_int32), ("T_w_c", C.c_void_p), ("pts3d", C.c_void_p), ("pts2d", C.c_void_p),
                 ("n_pairs", C.c_int32), ("kf_ref", C.c_void_p), ("kf_cur", C.c_void_p), ("kf_n", C.c_int32),
                 ("kf_T_curr_to_prev", C.c_void_p), ("kf_T_w_cur", C.c_void_p), ("kf_T_w_ref", C.c_void_p),
-                ("ba_throughput", C.c_int32)]
+                ("ba_throughput", C.c_int32), ("h_frames", C.POINTER(C.c_void_p)), ("chain", C.c_int32)]
 
 
 class FrameLoopState(C.Structure):
@@ -129,8 +129,12 @@ def window_pool(mvo, args, shard_id, n):
 class Shard:
     """One sequence: its frames resident in HBM, its own ctx/stream(s), its pool of BA windows, its native loop."""
 
-    def __init__(self, mvo, torch, device, shard_id, args, ba_mode, pipeline, frames=None, pool=None, ba_cut=None):
+    def __init__(self, mvo, torch, device, shard_id, args, ba_mode, pipeline, frames=None, pool=None, ba_cut=None,
+                 host_frames=False, chain=False, fix_points=None):
         self.mvo = mvo
+        self.torch = torch
+        self.from_host, self.chain = host_frames, chain
+        self.fix_points = (args.ba == "pose_only") if fix_points is None else fix_points
         self.ba_cut = ba_cut or (args.ba_cut if args.ba_cut != "auto" else ("throughput" if args.streams > 8 else "latency"))
         self.id = shard_id
         self.args = args
@@ -163,7 +167,12 @@ class Shard:
         c.n_frames, c.width, c.height, c.stride, c.channels, c.max_kp = len(self.dev_frames), a.width, a.height, a.width * 3, 3, a.max_kp
         c.ba_mode = {"none": 0, "rebuild": 1, "resident": 2}[ba_mode]
         c.pipeline = 1 if pipeline else 0
-        c.fix_points = 1 if a.ba == "pose_only" else 0
+        c.fix_points = 1 if self.fix_points else 0
+        c.chain = 1 if self.chain else 0
+        if self.from_host:   # the same frames in pinned host memory: handed over as host images (H2D inside the loop)
+            self._pinned = [self.torch.from_numpy(f).pin_memory() for f in self.host_frames]
+            self._hf = (C.c_void_p * len(self._pinned))(*[t.data_ptr() for t in self._pinned])
+            c.h_frames = C.cast(self._hf, C.POINTER(C.c_void_p))
         c.ba_throughput = 1 if self.ba_cut == "throughput" else 0
         c.track = 1 if self.track is not None else 0
         c.keyframe_every = a.keyframe_every
@@ -476,10 +485,35 @@ def main(argv=None, env=None):
             for r_ in res:
                 r_.close()
 
+            def variant(**kw):
+                """The headline configuration (same shards, frames and window pools) with one thing changed."""
+                vs = [env.make_shard(s.id, args, "rebuild", pipeline, frames=(s.host_frames, s.dev_frames), pool=s.pool, **kw)
+                      for s in shards]
+                run_steps(vs, max(5, args.warmup))
+                nv = max(20, args.steps // 2)
+                dt_ = timed_run(vs, nv, env.sync)
+                inl = vs[0].state().n_inliers
+                for v_ in vs:
+                    v_.close()
+                return len(vs) * nv / dt_, inl
+
+            secondary["h2d_inclusive_fps"], _ = variant(host_frames=True)
+            secondary["h2d_inclusive_note"] = ("every frame handed over as a HOST image (pinned, %d B) like run_vo.cpp:114 -> "
+                                               "mvo_calc_keypoints uploads it inside the loop" % (args.width * args.height * 3))
+            if args.ba == "full":
+                secondary["pose_only_ba_fps"], _ = variant(fix_points=True)
+                secondary["pose_only_ba_note"] = "the shipped default is_ba_fix_map_points: true (config.yaml:123, vo.cpp:395-421)"
+            fps_c, inl_c = variant(chain=True)
+            secondary["chained_fps"] = fps_c
+            secondary["chained_note"] = ("every frame: solvePnPRansac on the new frame's own 3D-2D pairs (a quarter of them wrong), pose "
+                                         "from it, ONLY its inliers (%d) become the frame's map-point connections (vo.cpp:304-357), "
+                                         "then the window is marshalled and solved (vo.cpp:408-449)" % inl_c)
+
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, shards[0])
         cpu_mt = None
-        if not args.no_cpu_baseline and args.cpu_threads > 1:
-            cpu_mt = cpu_baseline_threads(args, shards[0], args.cpu_threads)
+        nthr = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
+        if not args.no_cpu_baseline and nthr > 1:
+            cpu_mt = cpu_baseline_threads(args, shards[0], nthr)
         st = st_after[0]
         result = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -33,6 +33,7 @@ int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
 int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
 int g_ba_cu_share = 0;   // CUs a solver grid may take (0 = all)
 int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
+int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
 namespace {
@@ -49,7 +50,7 @@ struct Carver {
 // Everything the host computes for one window; offsets are relative to the start of the device block.
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
-        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0;
+        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1;
     size_t uarea = 0;
     size_t lds = 0;
     std::vector<int> wg_pt;
@@ -209,6 +210,7 @@ void BaService::run() {
                 const int G = q.front()->ws->plan.G;
                 if (fl->nj && sum_wgs + G > share) break;
                 if (fl->nj && ba_solver_class(q.front()->ws->plan.n) != ba_solver_class(fl->jobs[0]->ws->plan.n)) break;
+                if (fl->nj && q.front()->ws->plan.slots != fl->jobs[0]->ws->plan.slots) break;  // (one kernel flavour per grid)
                 sum_wgs += G;
                 fl->jobs[fl->nj++] = q.front();
                 q.pop_front();
@@ -218,11 +220,11 @@ void BaService::run() {
         const int nj = fl->nj;
         BaBatch b{};
         b.nwin = nj;
-        int maxG = 1, slots = 1;
+        int maxG = 1, slots = 0;
         size_t lds = 16;
         for (int i = 0; i < nj; ++i) {
             BaWorkspace* ws = fl->jobs[i]->ws;
-            if (ws->plan.maxEg > BA_THREADS) slots = 2;
+            slots = ws->plan.slots;
             (void)hipStreamWaitEvent(stream, ws->ready, 0);  // the window's upload (queued on its ctx stream)
             b.win[i] = (const BaDev*)(ws->dev + ws->plan.o_desc);
             b.tag_base[i] = ws->seq << 12;
@@ -435,17 +437,24 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         // column pieces of the Schur chains: with one chunk, as many pieces side by side as there are idle waves; otherwise
         // one piece per chunk, as few chunks as the LDS budget allows (a wave keeps the running sums of <= 2 tile pairs)
         const int msteps = (3 * maxLg + 3) / 4;
+        // where the Jacobian rows of the edges live: all in LDS when the range has the room (fewest registers: the
+        // kernel flavour without register-resident rows), else the first 512 of a range in the registers of its threads
         bool fits = false;
         const int max_seq = (do_schur && npair <= 16) ? 8 : 1;
-        for (int q = 1; q <= max_seq && !fits; ++q) {
-            nseq = q;
-            npar = (do_schur && q == 1) ? std::max(1, BA_WAVES / npair) : 1;
-            if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
-            nsplit = nseq * npar;
-            const int msplit = (msteps + nsplit - 1) / nsplit;
-            uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, maxEg, maxEpose, nhp, G, p->fix_points);
-            P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea);
-            fits = P.lds <= BA_LDS_BUDGET;
+        for (int all_lds = (g_ba_edge_rows == 1 ? 0 : 1); all_lds >= (g_ba_edge_rows == 0 ? 1 : 0) && !fits; --all_lds) {
+            P.e2_edges = all_lds ? maxEg : std::max(0, maxEg - BA_THREADS);
+            P.slots = all_lds ? 0 : (maxEg > BA_THREADS ? 2 : 1);
+            for (int q = 1; q <= max_seq && !fits; ++q) {
+                nseq = q;
+                npar = (do_schur && q == 1) ? std::max(1, BA_WAVES / npair) : 1;
+                if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
+                nsplit = nseq * npar;
+                const int msplit = (msteps + nsplit - 1) / nsplit;
+                uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, maxEg, maxEpose, nhp, G, p->fix_points);
+                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges);
+                fits = P.lds <= BA_LDS_BUDGET;
+                if (all_lds && q >= 2) break;  // (rows in LDS only when at most two chunks are needed: more would cost more than registers)
+            }
         }
         if (fits && maxEg <= BA_EDGE_SLOTS * BA_THREADS && maxLg < 32000) break;
         if (G >= BA_MAX_WGS)
@@ -598,6 +607,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.npar = npar;
     B.nseq = nseq;
     B.uarea = (int)uarea;
+    B.e2_edges = P.e2_edges;
+    B.slots = P.slots;
     B.ldu = ldu;
     B.nhp = nhp;
     B.f = p->focal;

@@ -615,7 +615,8 @@ struct WgLds {
     double* Cc;     // maxLg x 6 (pitch BA_XS)   Cholesky factor of (H_ll + lambda I)^-1
     double* cl;     // maxLg x 3   C^T b_l
     double* U;      // `uarea` doubles: see above
-    double* E2;     // (maxEg - 512) x BA_E2S: rows [a0 | a1 | x] of the edges 512 .. Eg - 1
+    double* E2;     // rows [a0 | a1 | x | e~] (pitch BA_E2S) of the edges that do not keep them in registers: all edges
+                    // (SLOTS = 0) or the edges 512 .. Eg - 1
     short* epose;   // maxEg
     short* ept;     // maxEg  local landmark index
     short* dup;     // maxEg  rank of the edge among the observations of its (landmark, pose): 0 for the first
@@ -749,7 +750,9 @@ __device__ __forceinline__ void edge_Y(const EdgeRegs& r, const double* cc, doub
 // PROF: per-phase cycle counters; NR: reduced-solve flavour -- 32: one-wave register solver for n + 1 <= 32 rows; 64 / -32:
 // workgroup-wide block solver for n + 1 <= 64 / 32 rows; 0: LDS solver (any n).  Separate instantiations: the solvers
 // differ widely in register use.
-// SLOTS: edges per thread (1: every range of the launch has <= 512 edges; the code of the second edge is left out).
+// SLOTS: where the rows of an edge live between the linearisation and the trials -- 0: all of them in LDS (ranges that
+// have the room: the latency cut of the 5-keyframe window; fewest registers), 1: in the registers of thread `edge` (<= 512
+// edges per range), 2: edges behind 512 in LDS (ranges of up to 1024 edges).
 template <bool PROF, int NR, int SLOTS>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     // window = blockIdx % stride; the stride is a multiple of 8 whenever several windows share a launch: with the
@@ -827,7 +830,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         stage = d;
         d += B.uarea;
         W.E2 = d;
-        d += (size_t)max(0, B.maxEg - BA_THREADS) * BA_E2S;
+        d += (size_t)B.e2_edges * BA_E2S;
         short* s = reinterpret_cast<short*>(d);
         W.epose = s;
         s += B.maxEg;
@@ -922,33 +925,42 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     EdgeRegs er;
 #pragma unroll
     for (int c = 0; c < 6; ++c) er.a0[c] = er.a1[c] = er.x[c] = 0;
-    const bool have0 = tid < Eg, have1 = SLOTS > 1 && tid + BA_THREADS < Eg;
+    const bool have0 = SLOTS > 0 && tid < Eg, have1 = SLOTS > 1 && tid + BA_THREADS < Eg;
     const int e0_p = have0 ? W.epose[tid] : 0, e0_l = have0 ? W.ept[tid] : 0, e0_sl = have0 ? sSlot[e0_p] : -1;
     const int e1_p = have1 ? W.epose[tid + BA_THREADS] : 0, e1_l = have1 ? W.ept[tid + BA_THREADS] : 0,
               e1_sl = have1 ? sSlot[e1_p] : -1;
     constexpr int nslot = SLOTS;
-// BA_EDGES(BODY): BODY(el, rows, landmark, slot, e~ pair) for this thread's (at most two) edges -- the first one straight from
-// its registers, the second one (only in ranges with more than 512 edges) from the E2 area.  BODY is a statement macro;
-// `break` leaves it.  (Spelled with macros, element by element: behind a lambda capture the compiler parks the
-// register-resident rows in scratch memory.)
-#define BA_EDGES(BODY)                                                       \
-    if (have0) do { BODY(tid, er, e0_l, e0_sl, ee0) } while (0);             \
-    if (nslot > 1 && have1) do {                                             \
+    constexpr int e2_first = SLOTS == 0 ? 0 : BA_THREADS;  // first edge of the E2 area
+// BA_EDGES(BODY): BODY(el, rows, landmark, slot, e~ pair) for this thread's edges -- from its registers (edge `tid`), from the
+// E2 area (SLOTS = 2: edge tid + 512; SLOTS = 0: edges tid, tid + 512, ...).  BODY is a statement macro; `break` leaves
+// it.  (Spelled with macros, element by element: behind a lambda capture the compiler parks the register-resident rows
+// in scratch memory.)
+#define BA_EDGE_FROM_LDS(BODY, el_)                                          \
+    do {                                                                     \
         EdgeRegs r1_;                                                        \
-        const double* q_ = W.E2 + BA_E2S * tid;                              \
+        double ee_[2];                                                       \
+        const double* q_ = W.E2 + BA_E2S * ((el_)-e2_first);                 \
         _Pragma("unroll") for (int c_ = 0; c_ < 6; ++c_) {                   \
             r1_.a0[c_] = q_[c_];                                             \
             r1_.a1[c_] = q_[6 + c_];                                         \
             r1_.x[c_] = q_[12 + c_];                                         \
         }                                                                    \
-        BODY(tid + BA_THREADS, r1_, e1_l, e1_sl, ee1)                        \
+        ee_[0] = q_[18];                                                     \
+        ee_[1] = q_[19];                                                     \
+        const int p1_ = W.epose[el_];                                        \
+        BODY(el_, r1_, W.ept[el_], sSlot[p1_], ee_)                          \
     } while (0);
+#define BA_EDGES(BODY)                                                       \
+    if (nslot > 0 && have0) do { BODY(tid, er, e0_l, e0_sl, ee0) } while (0); \
+    if (nslot > 1 && have1) BA_EDGE_FROM_LDS(BODY, tid + BA_THREADS)         \
+    if (nslot == 0)                                                          \
+        for (int el0_ = tid; el0_ < Eg; el0_ += BA_THREADS) BA_EDGE_FROM_LDS(BODY, el0_)
 
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus), kept in registers;
         // X~ and e~ also go to the staging area for the landmark blocks
         PH_BEGIN();
-        double ee0[2] = {0, 0}, ee1[2] = {0, 0};  // e~ of the two edges (needed again when the chain rows are staged)
+        double ee0[2] = {0, 0};  // e~ of the register edge (needed again when the chain rows are staged)
 // rows of edge `el` (pose p, slot sl) into r, its whitened error into ee; X~ and e~ also into the staging area
 #define BA_LINEARIZE(el, r, p, sl, ee)                                                                              \
     {                                                                                                               \
@@ -985,17 +997,21 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             Xs[7] = ee[1];                                                                                          \
         }                                                                                                           \
     }
-        if (have0) BA_LINEARIZE(tid, er, e0_p, e0_sl, ee0)
-        if (nslot > 1 && have1) {
+        if (nslot > 0 && have0) BA_LINEARIZE(tid, er, e0_p, e0_sl, ee0)
+        for (int el = nslot == 0 ? tid : tid + BA_THREADS; nslot != 1 && el < Eg; el += BA_THREADS) {
             EdgeRegs r1;
-            BA_LINEARIZE(tid + BA_THREADS, r1, e1_p, e1_sl, ee1)
-            double* q = W.E2 + BA_E2S * tid;
+            double ee[2];
+            const int p1 = W.epose[el], sl1 = sSlot[p1];
+            BA_LINEARIZE(el, r1, p1, sl1, ee)
+            double* q = W.E2 + BA_E2S * (el - e2_first);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 q[c] = r1.a0[c];
                 q[6 + c] = r1.a1[c];
                 q[12 + c] = r1.x[c];
             }
+            q[18] = ee[0];
+            q[19] = ee[1];
         }
         __syncthreads();
         PH_END(0);
@@ -1036,16 +1052,46 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
         const bool hp_local = hp_deferred || G == 1;  // results stay in this workgroup's hpl
         if (!hp_deferred) ++tagH;
         {
+            // The rows are staged in `npass` passes: pass q holds, for EVERY pose, the q-th slice of its rows (an even number of
+            // edges, so that a slice is whole MFMA steps), all slices of a pass packed back to back.  Every chain therefore runs
+            // in every pass -- side by side on different waves -- and carries its accumulator from pass to pass: the same fma
+            // chain over the pose's rows in storage order as with one pass.
             const int col = lane & 15;
             const int mcap = (int)(B.uarea / BA_MSTRIDE);
-            for (int p0 = 0; p0 < B.F;) {
-                int p1 = p0 + 1;
-                while (p1 < B.F && sPoseStart[p1 + 1] - sPoseStart[p0] <= mcap) ++p1;
-                const int eg0 = sPoseStart[p0], eg1 = sPoseStart[p1];
-                if (eg1 - eg0 > mcap) error = 1;  // (the planner sizes the area for the largest pose of any range)
+            const int npass = max(1, (Eg + 2 * B.F + mcap - 1) / max(mcap, 1));
+            // pair of free poses this wave chains (two rounds at most: F <= 20 -> <= 10 pairs on 8 waves)
+            int nfp = 0;
+            for (int p = 0; p < B.F; ++p) nfp += sSlot[p] >= 0;
+            v4d accp0 = {0, 0, 0, 0}, accp1 = {0, 0, 0, 0};
+            for (int q = 0; q < npass && !error; ++q) {
+                // slice q of pose p: edges [s_p + q h_p, min(e_p, s_p + (q + 1) h_p)), h_p = ceil(n_p / npass) rounded up to even;
+                // its place in the staging area: the slices of the poses before it
+                auto slice_of = [&](int p, int& lo, int& hi) {
+                    const int s0 = sPoseStart[p], n_p = sPoseStart[p + 1] - s0;
+                    const int h = ((n_p + npass - 1) / npass + 1) & ~1;
+                    lo = min(s0 + q * h, s0 + n_p);
+                    hi = min(s0 + (q + 1) * h, s0 + n_p);
+                };
+                auto slice_off = [&](int p) {
+                    int off = 0;
+                    for (int pp = 0; pp < p; ++pp) {
+                        int lo, hi;
+                        slice_of(pp, lo, hi);
+                        off += hi - lo;
+                    }
+                    return off;
+                };
+                {
+                    int lo, hi;
+                    slice_of(B.F - 1, lo, hi);
+                    if (slice_off(B.F - 1) + hi - lo > mcap) error = 1;  // (cannot happen: npass is sized for it)
+                }
 #define BA_BODY_STAGE_M(el, r, l_, sl_, ee)                                   \
-    if ((el) < eg0 || (el) >= eg1) break;                                    \
-    double* Mr = stage + BA_MSTRIDE * ((el)-eg0);                            \
+    const int p_ = W.epose[el];                                              \
+    int lo_, hi_;                                                            \
+    slice_of(p_, lo_, hi_);                                                  \
+    if ((el) < lo_ || (el) >= hi_) break;                                    \
+    double* Mr = stage + BA_MSTRIDE * (slice_off(p_) + (el)-lo_);            \
     _Pragma("unroll") for (int c = 0; c < 6; ++c) {                          \
         Mr[c] = r.a0[c];                                                     \
         Mr[7 + c] = r.a1[c];                                                 \
@@ -1056,15 +1102,15 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     BA_EDGES(BA_BODY_STAGE_M)
                 }
                 __syncthreads();
+                const bool lastq = q == npass - 1;
                 if (batch.use_mfma && !error) {
                     // two free poses share a chain: columns 0..6 of the 16-wide operand are the rows [A~ | e~] of the first,
                     // columns 8..14 those of the second (zero rows once the shorter one has ended: exact no-ops), so the
                     // diagonal 7 x 7 blocks of the product are the two pose blocks, each its own fma chain over its rows
-                    int nfp = 0;
-                    for (int p = p0; p < p1; ++p) nfp += sSlot[p] >= 0;
-                    for (int pair = wave; 2 * pair < nfp; pair += BA_WAVES) {
+                    int ai = 0;
+                    for (int pair = wave; 2 * pair < nfp; pair += BA_WAVES, ++ai) {
                         int pa = -1, pb = -1, idx = 0;
-                        for (int p = p0; p < p1; ++p) {
+                        for (int p = 0; p < B.F; ++p) {
                             if (sSlot[p] < 0) continue;
                             if (idx == 2 * pair) pa = p;
                             if (idx == 2 * pair + 1) pb = p;
@@ -1074,14 +1120,17 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                         const int pp = second ? pb : pa;
                         const int cc7 = col & 7;
                         const bool cv = cc7 < 7 && pp >= 0;
-                        const int sA = sPoseStart[pa] - eg0, rowsA = 2 * (sPoseStart[pa + 1] - sPoseStart[pa]);
-                        const int sB = pb >= 0 ? sPoseStart[pb] - eg0 : 0, rowsB = pb >= 0 ? 2 * (sPoseStart[pb + 1] - sPoseStart[pb]) : 0;
+                        int loA, hiA, loB = 0, hiB = 0;
+                        slice_of(pa, loA, hiA);
+                        if (pb >= 0) slice_of(pb, loB, hiB);
+                        const int sA = slice_off(pa), rowsA = 2 * (hiA - loA);
+                        const int sB = pb >= 0 ? slice_off(pb) : 0, rowsB = 2 * (hiB - loB);
                         const int s = second ? sB : sA, rows = second ? rowsB : rowsA;
                         const int rmax = max(rowsA, rowsB);
                         // row 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
                         const double* pm = stage + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? cc7 : 0);
                         const int kq = lane >> 4;
-                        v4d acc = {0, 0, 0, 0};
+                        v4d acc = ai == 0 ? accp0 : accp1;
                         int st = 0;
                         const int rmin = pb >= 0 ? min(rowsA, rowsB) : rowsA;
                         for (; 4 * (st + 4) <= rmin; st += 4) {  // (both poses still have rows: no row predicate)
@@ -1093,52 +1142,46 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
                             pm += 8 * BA_MSTRIDE;
                         }
-                        for (; 4 * (st + 4) <= rmax; st += 4) {
-                            const double v0 = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
-                            const double v1 = (cv && 4 * st + 4 + kq < rows) ? pm[2 * BA_MSTRIDE] : 0.0;
-                            const double v2 = (cv && 4 * st + 8 + kq < rows) ? pm[4 * BA_MSTRIDE] : 0.0;
-                            const double v3 = (cv && 4 * st + 12 + kq < rows) ? pm[6 * BA_MSTRIDE] : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc, 0, 0, 0);
-                            pm += 8 * BA_MSTRIDE;
-                        }
-                        for (; 4 * st < rmax; ++st) {  // remaining steps, the last one possibly with fewer than 4 rows
+                        for (; 4 * st < rmax; ++st) {  // remaining steps, possibly with fewer than 4 rows or only one pose left
                             const double v = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
                             pm += 2 * BA_MSTRIDE;
                         }
+                        if (ai == 0) accp0 = acc;
+                        else accp1 = acc;
+                        if (lastq) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int rg = (lane >> 4) + 4 * j;  // acc[j] = entry (rg, col)
-                            const bool mine = second ? (rg >= 8 && rg < 15 && pb >= 0) : rg < 7;
-                            const int r7 = rg & 7;
-                            if (mine && cc7 <= r7 && cc7 < 7) {
-                                const int sl = sSlot[pp], pk = r7 * (r7 + 1) / 2 + cc7;
-                                if (hp_local) W.hpl[BA_HP * sl + pk] = acc[j];
-                                else gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
+                            for (int j = 0; j < 4; ++j) {
+                                const int rg = (lane >> 4) + 4 * j;  // acc[j] = entry (rg, col)
+                                const bool mine = second ? (rg >= 8 && rg < 15 && pb >= 0) : rg < 7;
+                                const int r7 = rg & 7;
+                                if (mine && cc7 <= r7 && cc7 < 7) {
+                                    const int sl = sSlot[pp], pk = r7 * (r7 + 1) / 2 + cc7;
+                                    if (hp_local) W.hpl[BA_HP * sl + pk] = acc[j];
+                                    else gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + pk), tag0 + tagH, acc[j], same_l2);
+                                }
                             }
                         }
                     }
                 } else if (!error) {
-                    for (int p = p0 + wave; p < p1; p += BA_WAVES) {
+                    // validation path: the same fma chains on the vector ALU, running sums in hpl between the passes
+                    for (int p = wave; p < B.F; p += BA_WAVES) {
                         const int sl = sSlot[p];
                         if (sl < 0 || lane >= BA_HP) continue;
-                        const int s = sPoseStart[p] - eg0, e = sPoseStart[p + 1] - eg0;
-                        // validation path: the same fma chains on the vector ALU
+                        int lo, hi;
+                        slice_of(p, lo, hi);
+                        const int s = slice_off(p), e = s + hi - lo;
                         int i = 0;
                         while ((i + 1) * (i + 2) / 2 <= lane) ++i;
                         const int j = lane - i * (i + 1) / 2;
-                        double acc = 0;
+                        double acc = q == 0 ? 0.0 : W.hpl[BA_HP * sl + lane];
                         for (int r = 2 * s; r < 2 * e; ++r)
                             acc = __builtin_fma(stage[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + i], stage[BA_MSTRIDE * (r >> 1) + 7 * (r & 1) + j], acc);
-                        if (hp_local) W.hpl[BA_HP * sl + lane] = acc;
+                        if (hp_local || !lastq) W.hpl[BA_HP * sl + lane] = acc;
                         else gstore_d(B.xH + 2 * ((size_t)g * B.nhp + BA_HP * sl + lane), tag0 + tagH, acc, same_l2);
                     }
                 }
                 __syncthreads();  // (the staged rows are dead)
-                p0 = p1;
             }
         }
         PH_END(1);
@@ -1694,14 +1737,14 @@ static ba_kernel_fn ba_kernel_pick(int nr) {
     return nr == 32 ? k_ba_lm<PROF, 32, SLOTS> : (nr == -32 ? k_ba_lm<PROF, -32, SLOTS> : (nr == 64 ? k_ba_lm<PROF, 64, SLOTS> : k_ba_lm<PROF, 0, SLOTS>));
 }
 static ba_kernel_fn ba_kernel_for(int profile, int nr, int slots) {
-    if (profile) return slots > 1 ? ba_kernel_pick<true, 2>(nr) : ba_kernel_pick<true, 1>(nr);
-    return slots > 1 ? ba_kernel_pick<false, 2>(nr) : ba_kernel_pick<false, 1>(nr);
+    if (profile) return slots == 0 ? ba_kernel_pick<true, 0>(nr) : (slots > 1 ? ba_kernel_pick<true, 2>(nr) : ba_kernel_pick<true, 1>(nr));
+    return slots == 0 ? ba_kernel_pick<false, 0>(nr) : (slots > 1 ? ba_kernel_pick<false, 2>(nr) : ba_kernel_pick<false, 1>(nr));
 }
 int ba_kernel_set_lds_limit() {
     int bad = 0;
     for (int profile = 0; profile < 2; ++profile)
         for (int nr : {32, -32, 64, 0})
-            for (int slots = 1; slots <= 2; ++slots)
+            for (int slots = 0; slots <= 2; ++slots)
                 bad |= hipFuncSetAttribute((const void*)ba_kernel_for(profile, nr, slots), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            BA_LDS_BUDGET) != hipSuccess;
     return bad ? -1 : 0;

@@ -28,7 +28,7 @@ typedef unsigned long long ba_u64;
 #define BA_EDGE_SLOTS 2             // edges per thread: the first one keeps its Jacobian rows in registers, the second one (ranges
 //                                  with more than 512 edges) in LDS; a range holds <= 1024 edges
 #define BA_PANEL_DOUBLES 512         // block LDL^T: rows [-l] and [c] of a 4-column panel, 64 rows each
-#define BA_E2S 19                   // doubles per edge in that LDS area: a0 (6) | a1 (6) | x (6), odd pitch
+#define BA_E2S 21                   // doubles per edge in that LDS area: a0 (6) | a1 (6) | x (6) | e~ (2), odd pitch
 #define BA_LDS_BUDGET (157 * 1024)  // dynamic part; the static part (descriptor, flags: < 1.5 KB) comes on top (160 KB per CU)
 #define BA_MAX_WGS 256
 #define BA_MAX_BATCH 16             // windows per launch (8 x 32 or 16 x 16 workgroups = one workgroup per CU)
@@ -61,6 +61,8 @@ struct BaDev {
     int npar;    // pieces that run side by side on different waves (one chunk of the U area holds npar pieces)
     int nseq;    // chunks of the U area that are built and consumed one after the other
     int uarea;   // doubles of the multi-purpose U / staging area of a workgroup
+    int e2_edges;  // edges per range whose Jacobian rows live in LDS (all of them, or those behind the first 512)
+    int slots;   // kernel flavour the plan was made for: 0 = all rows in LDS, 1 / 2 = first 512 edges in registers
     int ldu;     // rows of the U buffer = 16 NT
     int nhp;     // pose-block exchange entries per workgroup = BA_HP nfree + 1 (last: max |diag H_ll|)
     double f, cx, cy, delta;
@@ -135,12 +137,12 @@ __host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int maxEg
     return a;
 }
 __host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int npar, int nfree, int maxEg,
-                                               int maxLg, int fix_points, size_t uarea) {
+                                               int maxLg, int fix_points, size_t uarea, int e2_edges) {
     size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar) + (size_t)nlow + 2 * (size_t)nhp + 17 + (size_t)maxEg * 2 +
                (size_t)maxLg * 3;
     d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
     if (!fix_points) d += (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3);
-    d += uarea + (size_t)(maxEg > BA_THREADS ? maxEg - BA_THREADS : 0) * BA_E2S;
+    d += uarea + (size_t)e2_edges * BA_E2S;
     size_t shorts = (size_t)maxEg * 4 + (size_t)maxLg + 1 + (size_t)maxLg * (nfree > 0 ? nfree : 1);
     return d * 8 + ((shorts * 2 + 15) & ~(size_t)15) + 64;
 }

@@ -46,6 +46,10 @@ struct frame_loop_cfg {
     int32_t kf_n;
     const double *kf_T_curr_to_prev, *kf_T_w_cur, *kf_T_w_ref;  // 16 each
     int32_t ba_throughput;        // 1: mvo_ba_set_mode(ctx_ba, MVO_BA_MODE_THROUGHPUT) (many sequences per GPU)
+    const void* const* h_frames;  // optional: the same frames in (pinned) host memory; when set, every frame is handed to
+                                  // mvo_calc_keypoints as a HOST image like run_vo.cpp:114 does (H2D inside the loop)
+    int32_t chain;                // 1: the newest frame of every window takes its pose and its map-point connections from
+                                  // solvePnPRansac on its own 3D-2D pairs (vo.cpp:304-357) before the window is marshalled
 };
 
 struct frame_loop_state {  // progress counters, read back by the caller
@@ -77,6 +81,12 @@ struct Window {
     std::vector<int> point_ids;              // map point id of landmark l
     int F = 0, L = 0, E = 0;
     mvo_ba_handle* resident = nullptr;       // ba_mode 2
+    // chained mode: the 3D-2D pairs of the newest frame as matching would deliver them (a quarter of them wrong), the
+    // keypoint index of every pair
+    std::vector<float> pnp3d, pnp2d;
+    std::vector<int> pnp_kpt;
+    std::vector<int32_t> pnp_inl;
+    std::vector<vo::PtConn> conn0;            // connection of keypoint k of the newest frame when every pair is kept
 };
 
 struct Loop {
@@ -115,9 +125,15 @@ void restore(Window& w) {
 
 int extract_and_match(Loop& L, int frame_no, const void** d_desc, int* n_out, int* n_match) {
     const frame_loop_cfg& c = L.c;
-    const void* img = c.d_frames[frame_no % c.n_frames];
     int n = 0, r;
-    if ((r = mvo_calc_keypoints_dev(c.ctx, img, c.width, c.height, c.stride, c.channels, L.kps.data(), (int)L.kps.size(), &n))) return r;
+    if (c.h_frames) {  // host image in, as the reference's loop hands it over (imread -> createFrame -> calcKeyPoints)
+        if ((r = mvo_calc_keypoints(c.ctx, (const uint8_t*)c.h_frames[frame_no % c.n_frames], c.width, c.height, c.stride, c.channels,
+                                    L.kps.data(), (int)L.kps.size(), &n)))
+            return r;
+    } else if ((r = mvo_calc_keypoints_dev(c.ctx, c.d_frames[frame_no % c.n_frames], c.width, c.height, c.stride, c.channels, L.kps.data(),
+                                           (int)L.kps.size(), &n))) {
+        return r;
+    }
     if ((r = mvo_calc_descriptors_dev(c.ctx, L.kps.data(), &n, nullptr, d_desc))) return r;
     *n_match = 0;
     if (L.prev_desc && n && L.prev_n) {
@@ -188,6 +204,30 @@ int frame_loop_add_window(void* h, int F, int Lm, int E, const double* poses0, c
         conn.pt_ref_idx = -1;
         conn.pt_map_idx = w->point_ids[edge_point[e]];
         f.inliers_to_mappt_connections_[kpt_idx] = conn;
+    }
+    if (L->c.chain) {
+        // the newest frame (pose index 0 = frames_buff[F]): its observations become the pairs PnP sees; every fourth pair gets
+        // a wrong pixel (a mismatch), deterministically
+        vo::Frame& f = *w->frames_buff[(size_t)F];
+        unsigned lcg = 12345u + (unsigned)Lm;
+        for (int e = 0, k = 0; e < E; ++e) {
+            if (edge_pose[e] != 0) continue;
+            const int l = edge_point[e];
+            float u = (float)edge_uv[2 * (size_t)e], v = (float)edge_uv[2 * (size_t)e + 1];
+            if (k % 4 == 3) {
+                lcg = lcg * 1664525u + 1013904223u;
+                u += (float)((int)(lcg >> 16) % 61 - 30);
+                lcg = lcg * 1664525u + 1013904223u;
+                v += (float)((int)(lcg >> 16) % 61 - 30);
+            }
+            w->pnp3d.insert(w->pnp3d.end(), {w->points0[3 * (size_t)l], w->points0[3 * (size_t)l + 1], w->points0[3 * (size_t)l + 2]});
+            w->pnp2d.insert(w->pnp2d.end(), {u, v});
+            w->pnp_kpt.push_back(k);
+            ++k;
+        }
+        w->pnp_inl.resize(w->pnp_kpt.size() + 1);
+        w->conn0.resize(f.keypoints_.size());
+        for (auto& kv : f.inliers_to_mappt_connections_) w->conn0[(size_t)kv.first] = kv.second;
     }
     restore(*w);
     if (L->c.ba_mode == 2 && L->windows.empty()) {  // the resident variant keeps the first window in HBM
@@ -275,6 +315,37 @@ int frame_loop_run(void* h, int steps, double* traj) {
                     auto t0 = Clock::now();
                     restore(w);  // the state this window had when it was "new"
                     st.ns_restore += ns_since(t0);
+                    if (c.chain && !w.pnp_kpt.empty()) {
+                        // VisualOdometry::poseEstimationPnP_ (vo.cpp:304-357): pose of the new frame from solvePnPRansac on its
+                        // own pairs, then ONLY the inliers become map-point connections -- the edges BA gets for this frame
+                        vo::Frame& f = *w.frames_buff.back();
+                        double rvec[3], tvec[3], R[9], Tcw[16] = {0}, Twc[16];
+                        int n_inl = 0, found = 0;
+                        if ((r = mvo_solve_pnp_ransac(c.ctx, w.pnp3d.data(), w.pnp2d.data(), (int)w.pnp_kpt.size(), c.K4[0], c.K4[1], c.K4[2],
+                                                      c.K4[3], 100, 2.0f, 0.999, rvec, tvec, w.pnp_inl.data(), (int)w.pnp_inl.size(), &n_inl,
+                                                      &found))) {
+                            status = r;
+                            break;
+                        }
+                        st.n_inliers = n_inl;
+                        if (found && n_inl >= 3) {
+                            mvo_rodrigues(rvec, R);
+                            for (int i = 0; i < 3; ++i) {
+                                for (int j = 0; j < 3; ++j) Tcw[4 * i + j] = R[3 * i + j];
+                                Tcw[4 * i + 3] = tvec[i];
+                            }
+                            Tcw[15] = 1;
+                            mvo_invert_pose(Tcw, Twc);
+                            for (int k = 0; k < 16; ++k) f.T_w_c_.at<double>(k / 4, k % 4) = Twc[k];
+                            std::unordered_map<int, vo::PtConn> conns;
+                            conns.reserve((size_t)n_inl * 2);
+                            for (int i = 0; i < n_inl; ++i) {
+                                const int kpt = w.pnp_kpt[(size_t)w.pnp_inl[i]];
+                                conns[kpt] = w.conn0[(size_t)kpt];
+                            }
+                            f.inliers_to_mappt_connections_.swap(conns);
+                        }
+                    }
                     // VisualOdometry::callBundleAdjustment_ (vo.cpp:384-478) in two halves
                     t0 = Clock::now();
                     L.pending = vo::buildBundleAdjustmentWindow(w.frames_buff, w.map, w.F);

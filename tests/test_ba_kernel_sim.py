@@ -156,3 +156,15 @@ def test_concurrent_clients_share_the_launch_service(mvo, simlib):
     simlib.mvo_debug_set(b"ba_cu_share", 0)
     for (P, X, st), (Pb, Xb, stb) in zip(singles, out):
         assert np.array_equal(P, Pb) and np.array_equal(X, Xb) and st["trials"] == stb["trials"]
+
+
+def test_register_resident_rows_flavour(mvo, O, simctx, simlib):
+    """The planner keeps the Jacobian rows of a range in LDS when they fit (latency cut of the benchmarked window) and in the
+    registers of the edge-owning threads otherwise; forced to registers the result must be the same bits."""
+    simlib.mvo_debug_set(b"ba_edge_rows", 1)
+    try:
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=12)
+        assert plan["wgs"] == 28
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(4, 700, 21), fix_points=False, pose_fixed=_fix(4, 1), max_iterations=12)
+    finally:
+        simlib.mvo_debug_set(b"ba_edge_rows", -1)

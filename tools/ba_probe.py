@@ -8,8 +8,8 @@ wgs_list = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0
 blk_list = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0]
 for kind, kw in kinds:
  for blk in blk_list:
-  mvo.debug_set("ba_block_solver", blk)
-  print("== block solver", blk)
+  mvo.debug_set("ba_edge_rows", blk - 1 if blk < 2 else 1)
+  print("== edge rows knob (0 = auto, 2 = registers)", blk)
   for wgs in wgs_list:
     mvo.debug_set("ba_wgs", wgs)
     pb = mvo.synth.ba_problem(5, 2000, 7)
@@ -36,7 +36,7 @@ for kind, kw in kinds:
     mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
 # one-shot path (window rebuilt per call) and batches
-mvo.debug_set("ba_block_solver", 0)
+mvo.debug_set("ba_edge_rows", -1)
 pb = mvo.synth.ba_problem(5, 2000, 7)
 a = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
 mvo.debug_set("ba_wgs", 0)
