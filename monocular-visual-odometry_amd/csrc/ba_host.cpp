@@ -453,7 +453,12 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, maxEg, maxEpose, nhp, G, p->fix_points);
                 P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges);
                 fits = P.lds <= BA_LDS_BUDGET;
-                if (all_lds && q >= 2) break;  // (rows in LDS only when at most two chunks are needed: more would cost more than registers)
+                // rows in LDS only while ONE chunk of U and ONE pass of the pose-block rows still fit next to them: with more
+                // chunks / passes the barriers cost more than the registers save (measured: 2.76 vs 2.41 ms on the BA5 window)
+                if (all_lds && g_ba_edge_rows != 0) {
+                    if (uarea < (size_t)BA_MSTRIDE * (maxEg + 2 * F)) fits = false;
+                    break;
+                }
             }
         }
         if (fits && maxEg <= BA_EDGE_SLOTS * BA_THREADS && maxLg < 32000) break;

@@ -784,6 +784,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     double* const sSol = sDx + 6 * B.F;           // 6 F (+ rhs slot)
     double* const sX = dyn + ba_pose_doubles(B.F);  // 2 G
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
+    __shared__ int sSliceLo[BA_MAX_POSES], sSliceHi[BA_MAX_POSES], sSliceOff[BA_MAX_POSES];  // pose-block chains: slices of a pass
     __shared__ int sFlag[4];
     __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
     if (threadIdx.x == 0) sFlag[2] = 0;
@@ -1058,34 +1059,45 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             // chain over the pose's rows in storage order as with one pass.
             const int col = lane & 15;
             const int mcap = (int)(B.uarea / BA_MSTRIDE);
-            const int npass = max(1, (Eg + 2 * B.F + mcap - 1) / max(mcap, 1));
+            int npass = 1;  // smallest number of passes whose slices fit the area together (uniform)
+            for (;; ++npass) {
+                int tot = 0;
+                for (int p = 0; p < B.F; ++p) {
+                    const int n_p = sPoseStart[p + 1] - sPoseStart[p];
+                    tot += min(n_p, ((n_p + npass - 1) / npass + 1) & ~1);
+                }
+                if (tot <= mcap) break;
+                if (npass > Eg) {
+                    error = 1;
+                    break;
+                }
+            }
             // pair of free poses this wave chains (two rounds at most: F <= 20 -> <= 10 pairs on 8 waves)
             int nfp = 0;
             for (int p = 0; p < B.F; ++p) nfp += sSlot[p] >= 0;
             v4d accp0 = {0, 0, 0, 0}, accp1 = {0, 0, 0, 0};
             for (int q = 0; q < npass && !error; ++q) {
                 // slice q of pose p: edges [s_p + q h_p, min(e_p, s_p + (q + 1) h_p)), h_p = ceil(n_p / npass) rounded up to even;
-                // its place in the staging area: the slices of the poses before it
-                auto slice_of = [&](int p, int& lo, int& hi) {
-                    const int s0 = sPoseStart[p], n_p = sPoseStart[p + 1] - s0;
-                    const int h = ((n_p + npass - 1) / npass + 1) & ~1;
-                    lo = min(s0 + q * h, s0 + n_p);
-                    hi = min(s0 + (q + 1) * h, s0 + n_p);
-                };
-                auto slice_off = [&](int p) {
-                    int off = 0;
-                    for (int pp = 0; pp < p; ++pp) {
-                        int lo, hi;
-                        slice_of(pp, lo, hi);
+                // its place in the staging area: behind the slices of the poses before it (tables in LDS, one thread per pose)
+                if (tid < B.F) {
+                    int off = 0, lo = 0, hi = 0;
+                    for (int pp = 0; pp <= tid; ++pp) {
+                        const int s0 = sPoseStart[pp], n_p = sPoseStart[pp + 1] - s0;
+                        const int h = ((n_p + npass - 1) / npass + 1) & ~1;
                         off += hi - lo;
+                        lo = min(s0 + q * h, s0 + n_p);
+                        hi = min(s0 + (q + 1) * h, s0 + n_p);
                     }
-                    return off;
-                };
-                {
-                    int lo, hi;
-                    slice_of(B.F - 1, lo, hi);
-                    if (slice_off(B.F - 1) + hi - lo > mcap) error = 1;  // (cannot happen: npass is sized for it)
+                    sSliceLo[tid] = lo;
+                    sSliceHi[tid] = hi;
+                    sSliceOff[tid] = off;
                 }
+                __syncthreads();
+                auto slice_of = [&](int p, int& lo, int& hi) {
+                    lo = sSliceLo[p];
+                    hi = sSliceHi[p];
+                };
+                auto slice_off = [&](int p) { return sSliceOff[p]; };
 #define BA_BODY_STAGE_M(el, r, l_, sl_, ee)                                   \
     const int p_ = W.epose[el];                                              \
     int lo_, hi_;                                                            \
@@ -1142,7 +1154,18 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
                             pm += 8 * BA_MSTRIDE;
                         }
-                        for (; 4 * st < rmax; ++st) {  // remaining steps, possibly with fewer than 4 rows or only one pose left
+                        for (; 4 * (st + 4) <= rmax; st += 4) {  // (only one of the two poses still has rows)
+                            const double v0 = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
+                            const double v1 = (cv && 4 * st + 4 + kq < rows) ? pm[2 * BA_MSTRIDE] : 0.0;
+                            const double v2 = (cv && 4 * st + 8 + kq < rows) ? pm[4 * BA_MSTRIDE] : 0.0;
+                            const double v3 = (cv && 4 * st + 12 + kq < rows) ? pm[6 * BA_MSTRIDE] : 0.0;
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc, 0, 0, 0);
+                            pm += 8 * BA_MSTRIDE;
+                        }
+                        for (; 4 * st < rmax; ++st) {  // last steps, possibly with fewer than 4 rows
                             const double v = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
                             pm += 2 * BA_MSTRIDE;
