@@ -446,8 +446,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
             P.slots = all_lds ? 0 : (maxEg > BA_THREADS ? 2 : 1);
             for (int q = 1; q <= max_seq && !fits; ++q) {
                 nseq = q;
-                npar = (do_schur && msteps >= 4) ? 2 : 1;  // two pieces per chunk, run by one wave with alternating instructions
-                if (env_nsplit) npar = std::max(1, std::min(npar, env_nsplit));
+                npar = (do_schur && q == 1) ? std::max(1, BA_WAVES / npair) : 1;
+                if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
                 nsplit = nseq * npar;
                 const int msplit = (msteps + nsplit - 1) / nsplit;
                 uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, maxEg, maxEpose, nhp, G, p->fix_points);

@@ -710,85 +710,6 @@ __device__ __forceinline__ v4d schur_chain_t(const double* U, int ti, int tj, in
     }
     return acc;
 }
-// Two consecutive column pieces [a0, a1) and [b0, b1) of one tile pair run by ONE wave with alternating instructions:
-// two independent accumulators, so that the matrix core never waits for the previous result (a lone chain sees ~110
-// cycles per dependent v_mfma_f64_16x16x4_f64, the pipe itself takes 64).  Each piece is still its own fma chain over
-// its columns in order; the caller adds the pieces in piece order.
-template <int LDU>
-__device__ __forceinline__ void schur_chain2_t(const double* U, int ti, int tj, int a0, int a1, int b0, int b1, int lane, v4d& accA,
-                                               v4d& accB) {
-    const int k = lane >> 4, i = lane & 15;
-    constexpr int st = 4 * LDU;
-    const double* pa = U + (size_t)(4 * a0 + k) * LDU + (16 * ti + i);
-    const double* pb = U + (size_t)(4 * a0 + k) * LDU + (16 * tj + i);
-    const double* qa = U + (size_t)(4 * b0 + k) * LDU + (16 * ti + i);
-    const double* qb = U + (size_t)(4 * b0 + k) * LDU + (16 * tj + i);
-    int nA = a1 - a0, nB = b1 - b0;
-    const int n = min(nA, nB);
-    int m = 0;
-#define BA_LOAD22(S)                                                                                         \
-    S##a0 = pa[0], S##b0 = pb[0], S##c0 = qa[0], S##d0 = qb[0], S##a1 = pa[st], S##b1 = pb[st], S##c1 = qa[st], S##d1 = qb[st]; \
-    pa += 2 * st, pb += 2 * st, qa += 2 * st, qb += 2 * st
-#define BA_MFMA22_LOADNEXT(S, T, more)                                           \
-    accA = __builtin_amdgcn_mfma_f64_16x16x4f64(S##a0, S##b0, accA, 0, 0, 0);    \
-    __builtin_amdgcn_sched_barrier(0);                                           \
-    if (more) { BA_LOAD22(T); }                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                           \
-    accB = __builtin_amdgcn_mfma_f64_16x16x4f64(S##c0, S##d0, accB, 0, 0, 0);    \
-    accA = __builtin_amdgcn_mfma_f64_16x16x4f64(S##a1, S##b1, accA, 0, 0, 0);    \
-    accB = __builtin_amdgcn_mfma_f64_16x16x4f64(S##c1, S##d1, accB, 0, 0, 0)
-    if (n >= 2) {
-        double xa0, xb0, xc0, xd0, xa1, xb1, xc1, xd1, ya0 = 0, yb0 = 0, yc0 = 0, yd0 = 0, ya1 = 0, yb1 = 0, yc1 = 0, yd1 = 0;
-        BA_LOAD22(x);
-        m += 2;
-        for (;;) {
-            const bool more1 = m + 2 <= n;
-            BA_MFMA22_LOADNEXT(x, y, more1);
-            if (!more1) break;
-            m += 2;
-            const bool more2 = m + 2 <= n;
-            BA_MFMA22_LOADNEXT(y, x, more2);
-            if (!more2) break;
-            m += 2;
-        }
-    }
-#undef BA_LOAD22
-#undef BA_MFMA22_LOADNEXT
-    for (int r = m; r < nA; ++r) {
-        accA = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], accA, 0, 0, 0);
-        pa += st;
-        pb += st;
-    }
-    for (int r = m; r < nB; ++r) {
-        accB = __builtin_amdgcn_mfma_f64_16x16x4f64(qa[0], qb[0], accB, 0, 0, 0);
-        qa += st;
-        qb += st;
-    }
-}
-__device__ __forceinline__ void schur_chain2(const double* U, int ldu, int ti, int tj, int a0, int a1, int b0, int b1, int lane, v4d& accA,
-                                             v4d& accB) {
-    switch (ldu) {
-        case 17: return schur_chain2_t<17>(U, ti, tj, a0, a1, b0, b1, lane, accA, accB);
-        case 33: return schur_chain2_t<33>(U, ti, tj, a0, a1, b0, b1, lane, accA, accB);
-        case 49: return schur_chain2_t<49>(U, ti, tj, a0, a1, b0, b1, lane, accA, accB);
-        case 65: return schur_chain2_t<65>(U, ti, tj, a0, a1, b0, b1, lane, accA, accB);
-        default: break;
-    }
-    const int k = lane >> 4, i = lane & 15;
-    for (int half = 0; half < 2; ++half) {  // larger windows (> 10 free poses): plain loops
-        const int m0 = half ? b0 : a0, m1 = half ? b1 : a1;
-        v4d acc = half ? accB : accA;
-        const double* pa = U + (size_t)(4 * m0 + k) * ldu + (16 * ti + i);
-        const double* pb = U + (size_t)(4 * m0 + k) * ldu + (16 * tj + i);
-        for (int m = m0; m < m1; ++m) {
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[0], pb[0], acc, 0, 0, 0);
-            pa += 4 * ldu;
-            pb += 4 * ldu;
-        }
-        if (half) accB = acc;
-        else accA = acc;
-    }
-}
 __device__ __forceinline__ v4d schur_chain(const double* U, int ldu, int ti, int tj, int m0, int m1, int lane) {
     switch (ldu) {
         case 17: return schur_chain_t<17>(U, ti, tj, m0, m1, lane);
@@ -996,9 +917,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     // where the entries of this wave's first Schur chain go in the packed order (constant for the whole solve)
     const short* pkt_g = B.pk_of_tile;
     int pk4[4] = {-1, -1, -1, -1};
-    if (do_schur && wave < B.npair) {
+    if (do_schur && wave < B.npair * npar) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pk4[j] = pkt_g[wave * 256 + ((lane >> 4) + 4 * j) * 16 + (lane & 15)];
+        for (int j = 0; j < 4; ++j) pk4[j] = pkt_g[(wave % B.npair) * 256 + ((lane >> 4) + 4 * j) * 16 + (lane & 15)];
     }
     // ---- this thread's edges: edge `tid` (rows in registers) and, in ranges with more than 512 edges, edge tid + 512
     // (rows in the E2 area)
@@ -1369,6 +1290,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             // chunk: one chain per (tile pair, column piece); the pieces of a pair are added in piece order.
             if (do_schur) {
                 ++tagA;
+                double* split_stage = W.SL;  // (free until the assemble step) npair x (npar - 1) x 256
                 // running sums of this wave's first two tile pairs over the chunks (windows with more than 16 tile pairs are
                 // planned with one chunk: a wave then publishes every pair straight from the chain)
                 v4d run0 = {0, 0, 0, 0}, run1 = {0, 0, 0, 0};
@@ -1404,7 +1326,6 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                             }
                         }
                     }
-                    STAMP(2);
 #define BA_BODY_UFILL(el, r, l_, sl_, ee)                                                          \
     const int l = l_, sl = sl_;                                                                   \
     if (sl < 0 || 3 * l + 2 < c0 || 3 * l >= c1 || (has_dups && W.dup[el] != rank)) break;         \
@@ -1434,45 +1355,50 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
                     const int st0 = ch * npar * msplit;  // first MFMA step of the chunk
                     const bool last = ch == nch - 1;
                     if (batch.use_mfma) {
-                        // one wave per tile pair runs the (one or two) pieces of the chunk, two pieces with alternating
-                        // instructions; pieces are added to the pair's running sum in piece order
+                        const int nchain = B.npair * npar;
                         int ai = 0;
-                        for (int pr = wave; pr < B.npair; pr += BA_WAVES, ++ai) {
+                        for (int a = wave; a < nchain; a += BA_WAVES, ++ai) {
+                            const int pr = a % B.npair, sp = a / B.npair;
                             int ti = 0, rem = pr;
                             while (rem >= B.NT - ti) {
                                 rem -= B.NT - ti;
                                 ++ti;
                             }
-                            const int a0 = min(st0, msteps) - st0, a1 = min(st0 + msplit, msteps) - st0;
-                            v4d accA = {0, 0, 0, 0}, accB = {0, 0, 0, 0};
-                            if (npar > 1) {
-                                const int b1 = min(st0 + 2 * msplit, msteps) - st0;
-                                schur_chain2(W.U, ldu, ti, ti + rem, a0, a1, a1, b1, lane, accA, accB);
-                            } else {
-                                accA = schur_chain(W.U, ldu, ti, ti + rem, a0, a1, lane);
-                            }
+                            const int m0 = min(st0 + sp * msplit, msteps) - st0, m1 = min(st0 + (sp + 1) * msplit, msteps) - st0;
+                            v4d acc = schur_chain(W.U, ldu, ti, ti + rem, m0, m1, lane);
                             STAMP(4);
-                            v4d r = ai == 0 ? run0 : run1;
+                            if (sp > 0) {
+                                double* dst = split_stage + ((size_t)pr * (npar - 1) + (sp - 1)) * 256;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) r[j] = ch == 0 ? accA[j] : r[j] + accA[j];
-                            if (npar > 1) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) r[j] += accB[j];
+                                for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = acc[j];
                             }
-                            if (ai == 0) run0 = r;
-                            else if (ai == 1) run1 = r;
-                            if (last) {
+                            if (npar > 1) __syncthreads();  // (uniform: npair x npar <= 8, every wave makes exactly one trip)
+                            if (sp == 0) {
+                                v4d r = ai == 0 ? run0 : run1;
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) {
-                                    const int rr = (lane >> 4) + 4 * j, c = lane & 15;
-                                    const int pk = pr == wave ? pk4[j] : pkt_g[pr * 256 + rr * 16 + c];
-                                    if (pk >= 0) {
-                                        if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], same_l2);
-                                        else W.Rl[pk] = r[j];
+                                for (int j = 0; j < 4; ++j) r[j] = ch == 0 ? acc[j] : r[j] + acc[j];
+                                for (int s2 = 1; s2 < npar; ++s2) {
+                                    const double* src = split_stage + ((size_t)pr * (npar - 1) + (s2 - 1)) * 256;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) r[j] += src[lane * 4 + j];
+                                }
+                                if (ai == 0) run0 = r;
+                                else if (ai == 1) run1 = r;
+                                if (last) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const int rr = (lane >> 4) + 4 * j, c = lane & 15;
+                                        const int pk = a == wave ? pk4[j] : pkt_g[pr * 256 + rr * 16 + c];
+                                        if (pk >= 0) {
+                                            if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], same_l2);
+                                            else W.Rl[pk] = r[j];
+                                        }
                                     }
                                 }
                             }
                         }
+                        // waves without a chain still meet the barrier of the split combination
+                        if (npar > 1 && wave >= nchain) __syncthreads();
                     } else {  // validation path: the same chains, one packed entry per thread and pass
                         for (int pk = tid; pk < nlow; pk += BA_THREADS) {
                             int i, j;

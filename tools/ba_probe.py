@@ -31,7 +31,7 @@ for kind, kw in kinds:
         else:
             tot = ph["total"]
             raw = ctx.ba_trace(h, raw_rows=412)[400:406].ravel()
-            print("   timeline of trial 6 (cycles between stamps 0..23):", [int(raw[i + 1] - raw[i]) for i in range(23)], "| T1 %d fillAB %d fillC %d" % (raw[1]-raw[0], raw[2]-raw[1], raw[3]-raw[2]))
+            print("   timeline of trial 6 (cycles between stamps 0..23):", [int(raw[i + 1] - raw[i]) for i in range(23)])
             print("   instrumented: ms/solve %.3f" % (dt*1e3), "cyc/us %.0f" % (tot/ (dt*1e6)), {k: round(v/max(st["trials"],1)) for k,v in ph.items() if k not in ("wgs", "x15")})
     mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
