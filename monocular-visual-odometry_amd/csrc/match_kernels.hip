@@ -3,16 +3,15 @@
 //               (reference src/geometry/feature_match.cpp:141,203-208) and, as the exact 1-NN, the
 //               cv::FlannBasedMatcher(LshIndexParams(5,10,2))::match call at feature_match.cpp:140,162.
 //   k_radius_l1 geometry::matchByRadiusAndBruteForce (feature_match.cpp:86-124).
-// Work decomposition (wave64): one LANE per query, the query's 256 bits live in 4 x u64 VGPRs; the train
-// descriptor of the current step is wave-uniform, so it is fetched with scalar loads (s_load_dwordx8) and
-// broadcast for free; distance = 8 x (v_xor + v_bcnt_u32).  k_knn2: one wave per (64 queries, train slice) pair,
-// 32 slices -> 1024 waves for 2000 x 2000 in workgroups of four, each scanning its slice in index order; LDS fold of the
-// four, then the last workgroup to arrive for a query group folds the 8 partial (best, second) pairs, keeping the
-// lexicographically smallest
-// (distance, index) pairs, which reproduces cv::batchDistance's tie rule exactly (equal distances keep the lower
-// train index).  k_radius_l1
-// keeps the single-kernel form (16 waves x 64 queries, LDS merge).  Everything is integer: results are bit-exact.
-// The whole working set (<= 2 x 128 KB) is L2-resident: the bound is VALU integer throughput, not HBM.
+//   k_knn2_mfma the same 2-NN as an i8 Gram on the matrix cores (default; see its header below).
+// k_knn2 (vector ALU, kept as the second implementation the tests compare and for train sets of >= 65536 descriptors):
+// one LANE per query, the query's 256 bits in 8 VGPRs; a wave parks its train slice in registers (lane j = descriptor j)
+// and broadcasts descriptor j with v_readlane, distance = 8 x (v_xor + v_bcnt_u32); one wave per (64 queries, train
+// slice) pair, 32 slices -> 1024 waves for 2000 x 2000 in workgroups of four; LDS fold of the four, then the last
+// workgroup to arrive for a query group folds the 8 partial (best, second) pairs, keeping the lexicographically smallest
+// (distance, index) pairs, which reproduces cv::batchDistance's tie rule exactly (equal distances keep the lower train
+// index).  k_radius_l1 keeps the single-kernel form (16 waves x 64 queries, LDS merge).  Everything is integer: results
+// are bit-exact.  The whole working set (<= 2 x 128 KB) is L2-resident: no HBM bound.
 #include "mvo_internal.h"
 
 #include <climits>
@@ -20,6 +19,8 @@
 typedef unsigned long long u64;
 
 #define MK_WAVES 16
+
+int g_match_mfma = 1;  // test hook: 0 = the vector-ALU kernel k_knn2 for every call
 
 struct Top2 {
     int d0, i0, d1, i1;
@@ -123,6 +124,124 @@ __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int n
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_knn2_mfma: the same exact 2-NN on the INTEGER MATRIX CORES.  With every descriptor bit b mapped to the byte
+// s = 1 - 2 b (+1 / -1), the dot product of two descriptors is 256 - 2 hamming: a 2000 x 2000 x 256 Gram in i8 with
+// exact i32 accumulation (v_mfma_i32_16x16x64_i8: four instructions per 16 x 16 tile of pairs) instead of
+// 8 x (v_readlane + v_xor + v_bcnt) per pair on the vector ALU.
+//   grid = (groups of 64 queries) x (train slices); workgroup = 4 waves, wave w owns queries 16 w .. 16 w + 15 of the group.
+//   prologue: the workgroup expands its train slice (<= 256 descriptors) into LDS, 256 bytes per descriptor in bit order
+//             (row pitch 272: the 16 rows of a tile start on different banks); every lane expands the 4 x 16 bits of ITS
+//             query column that the four K = 64 steps need (B operand: lane = (column l & 15, k block l >> 4)).
+//   loop:     per tile of 16 trains: 4 x (ds_read_b128 A operand + MFMA); lane (column l & 15, rows 4 (l >> 4) + r)
+//             turns its four dot products into keys (hamming << 16 | train index) and folds them into its running
+//             (best, second) with v_min / v_max -- the lexicographic (distance, index) order IS cv::batchDistance's tie
+//             rule (strict '<' in index order: equal distances keep the lower train index).
+//   epilogue: the four lanes of a column merge by shuffles, the slice partials meet like in k_knn2 (write-through
+//             partial + arrival counter, the last workgroup of a query group folds and delivers).
+// Exact integers throughout; needs nt < 65536 (16-bit index in the key), else k_knn2 runs.
+typedef int v4i __attribute__((ext_vector_type(4)));
+#define MM_TS 256      // trains per slice (LDS: 256 x 272 B = 68 KB)
+#define MM_PITCH 272
+__device__ __forceinline__ uint32_t mm_spread(uint32_t nib) {  // 4 bits -> 4 bytes of +1 (0x01) / -1 (0xff)
+    const uint32_t x = (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u;
+    return (x * 0xffu) | 0x01010101u;
+}
+__device__ __forceinline__ void mm_fold(uint32_t& b0, uint32_t& b1, uint32_t key) {
+    b1 = min(b1, max(b0, key));
+    b0 = min(b0, key);
+}
+__global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, int nt,
+                                                   int slice, u64* __restrict__ part, int32_t* __restrict__ arrive,
+                                                   int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.y * slice, jn = max(0, min(slice, nt - j0));  // trains j0 .. j0 + jn - 1
+    const int ntile = (jn + 15) / 16;
+    // ---- expand the slice: item = (train row, source dword): 32 bits -> 32 bytes
+    for (int it = tid; it < ntile * 16 * 8; it += 256) {
+        const int r = it >> 3, w = it & 7;
+        const uint32_t bits = r < jn ? t[8 * (size_t)(j0 + r) + w] : 0u;
+        uint4 lo, hi;
+        lo.x = mm_spread(bits & 15u), lo.y = mm_spread((bits >> 4) & 15u), lo.z = mm_spread((bits >> 8) & 15u), lo.w = mm_spread((bits >> 12) & 15u);
+        hi.x = mm_spread((bits >> 16) & 15u), hi.y = mm_spread((bits >> 20) & 15u), hi.z = mm_spread((bits >> 24) & 15u), hi.w = mm_spread(bits >> 28);
+        uint4* dst = reinterpret_cast<uint4*>(mm_lds + (size_t)r * MM_PITCH + 32 * w);
+        dst[0] = lo;
+        dst[1] = hi;
+    }
+    // ---- this lane's query column: bits [64 m + 16 kb, +16) for the four K steps
+    const int col = lane & 15, kb = lane >> 4;
+    const int qi = blockIdx.x * 64 + 16 * wave + col;
+    const int qc = min(qi, nq - 1);
+    v4i bq[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const uint32_t wsrc = q[8 * (size_t)qc + 2 * m + (kb >> 1)];
+        const uint32_t h = (kb & 1) ? (wsrc >> 16) : (wsrc & 0xffffu);
+        bq[m][0] = (int)mm_spread(h & 15u);
+        bq[m][1] = (int)mm_spread((h >> 4) & 15u);
+        bq[m][2] = (int)mm_spread((h >> 8) & 15u);
+        bq[m][3] = (int)mm_spread(h >> 12);
+    }
+    __syncthreads();
+    uint32_t b0 = 0xffffffffu, b1 = 0xffffffffu;
+    for (int tile = 0; tile < ntile; ++tile) {
+        const unsigned char* row = mm_lds + (size_t)(16 * tile + col) * MM_PITCH + 16 * kb;  // (A operand: row l & 15 = train)
+        v4i acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const v4i a = *reinterpret_cast<const v4i*>(row + 64 * m);
+            acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bq[m], acc, 0, 0, 0);
+        }
+        // acc[r] = dot(train 16 tile + 4 kb + r, query col)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int jl = 16 * tile + 4 * kb + r;
+            const uint32_t d = (uint32_t)(256 - acc[r]) >> 1;
+            const uint32_t key = jl < jn ? ((d << 16) | (uint32_t)(j0 + jl)) : 0xffffffffu;
+            mm_fold(b0, b1, key);
+        }
+    }
+    // ---- the four lanes of a column
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const uint32_t o0 = (uint32_t)__shfl_xor((int)b0, o), o1 = (uint32_t)__shfl_xor((int)b1, o);
+        const uint32_t c1 = min(max(b0, o0), min(b1, o1));
+        b0 = min(b0, o0);
+        b1 = c1;
+    }
+    // ---- slice partials -> the last workgroup of the query group folds them (arrival counter per group, self re-arming)
+    u64* mine = part + ((size_t)blockIdx.y * nq + qc);
+    if (kb == 0 && qi < nq) __hip_atomic_store(mine, ((u64)b1 << 32) | b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    if (tid == 0) {
+        const int nsl = gridDim.y;
+        const int last = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nsl - 1;
+        if (last) __hip_atomic_store(arrive + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last || tid >= 64) return;
+    const int qo = blockIdx.x * 64 + tid;
+    if (qo >= nq) return;
+    b0 = b1 = 0xffffffffu;
+    for (int s2 = 0; s2 < (int)gridDim.y; ++s2) {
+        const u64 w = __hip_atomic_load(part + ((size_t)s2 * nq + qo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t o0 = (uint32_t)w, o1 = (uint32_t)(w >> 32);
+        const uint32_t c1 = min(max(b0, o0), min(b1, o1));
+        b0 = min(b0, o0);
+        b1 = c1;
+    }
+    const bool h0 = b0 != 0xffffffffu, h1 = b1 != 0xffffffffu;
+    out_idx[2 * qo] = h0 ? (int)(b0 & 0xffffu) : -1;
+    out_idx[2 * qo + 1] = h1 ? (int)(b1 & 0xffffu) : -1;
+    out_dist[2 * qo] = h0 ? (int)(b0 >> 16) : INT_MAX;
+    out_dist[2 * qo + 1] = h1 ? (int)(b1 >> 16) : INT_MAX;
+}
+
 __global__ __launch_bounds__(1024) void k_radius_l1(const uint32_t* __restrict__ q, const float2* __restrict__ qxy,
                                                     int nq, const uint32_t* __restrict__ t,
                                                     const float2* __restrict__ txy, int nt, float r2,
@@ -177,6 +296,21 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
     u64* d_part = reinterpret_cast<u64*>(d_out + 4 * (size_t)nq);
     int32_t* dst = final_out ? final_out : d_out;
     ProfScope ps(ctx, "k_knn2");
+    if (g_match_mfma && nt > 0 && nt < 65536) {
+        // slices of <= MM_TS trains, at most 64 of them (the partial area holds 64 x nq x 16 B)
+        int nsl = (nt + MM_TS - 1) / MM_TS;
+        if (nsl > 64) nsl = 64;
+        int slice = ((nt + nsl - 1) / nsl + 15) & ~15;
+        if (slice <= MM_TS) {
+            static const int lds_ok = hipFuncSetAttribute((const void*)k_knn2_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, MM_TS * MM_PITCH);
+            (void)lds_ok;
+            nsl = (nt + slice - 1) / slice;
+            hipLaunchKernelGGL(k_knn2_mfma, dim3((nq + 63) / 64, nsl), dim3(256), (size_t)slice * MM_PITCH, ctx->stream, (const uint32_t*)d_q, nq,
+                               (const uint32_t*)d_t, nt, slice, d_part, ctx->d_marrive, dst, dst + 2 * (size_t)nq);
+            MVO_HIP(hipGetLastError());
+            return MVO_OK;
+        }
+    }
     hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, MK_GROUPS), dim3(256), 0, ctx->stream, (const uint4*)d_q, nq,
                        (const uint4*)d_t, nt, d_part, ctx->d_marrive, dst, dst + 2 * (size_t)nq);
     MVO_HIP(hipGetLastError());

@@ -452,6 +452,10 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 // ---------------------------------------------------------------------------------------------- debug hooks
 int mvo_debug_set(const char* key, int value) {
     if (key && !std::strncmp(key, "ba_", 3)) return ba_debug_set(key, value);
+    if (key && !std::strcmp(key, "match_mfma")) {
+        g_match_mfma = value;
+        return MVO_OK;
+    }
     if (key && !std::strcmp(key, "pyr_force_chain")) {
         g_pyr_force_chain = value;
         return MVO_OK;

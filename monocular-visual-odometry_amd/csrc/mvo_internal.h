@@ -218,6 +218,7 @@ int track_launch_em_hypotheses(mvo_ctx* ctx, const double* d_q1, const double* d
 int track_launch_em_mask(mvo_ctx* ctx, const double* d_q1, const double* d_q2, int n, const double* d_E, float thr2,
                          uint8_t* d_mask);
 extern int g_pyr_force_chain;  // test hook (orb_kernels.hip)
+extern int g_match_mfma;       // test hook (match_kernels.hip)
 extern int g_pnp_replay_skew;  // test hook: the device replays the RANSAC loop with a wrong confidence
 // track_host.cpp
 void track_release(mvo_ctx* ctx);

@@ -5,14 +5,45 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("mfma", [1, 0])
 @pytest.mark.parametrize("kind", ["uniform", "perturbed", "ties"])
-@pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (63, 65), (64, 16), (129, 15), (1000, 2500), (5, 1)])
-def test_knn2_bit_exact(mvo, O, ctx, kind, nq, nt):
-    q, t = mvo.synth.match_inputs(kind, nq, nt)
-    idx, dist = ctx.match_knn2(q, t)
+@pytest.mark.parametrize("nq,nt", [(2000, 2000), (1, 1), (63, 65), (64, 16), (129, 15), (1000, 2500), (5, 1), (4000, 4001), (17, 255),
+                                   (33, 257), (300, 5000)])
+def test_knn2_bit_exact(mvo, O, ctx, kind, nq, nt, mfma):
+    """Both implementations -- the i8 Gram on the matrix cores (default) and the vector-ALU kernel -- against the oracle."""
+    mvo.debug_set("match_mfma", mfma)
+    try:
+        q, t = mvo.synth.match_inputs(kind, nq, nt)
+        idx, dist = ctx.match_knn2(q, t)
+    finally:
+        mvo.debug_set("match_mfma", 1)
     io, do = O.match_knn2(q, t)
     assert np.array_equal(idx, io), "%d index rows differ" % (idx != io).any(1).sum()
     assert np.array_equal(dist, do)
+
+
+def test_knn2_mfma_on_structured_descriptors(mvo, O, ctx):
+    """Descriptors whose bits are NOT exchangeable (single bits, bytes, halves set; all zero; all one): a wrong bit -> byte
+    placement or a swapped operand role in the MFMA shows here, on random descriptors it could hide."""
+    rows = [np.zeros(32, np.uint8), np.full(32, 255, np.uint8)]
+    for b in range(0, 256, 7):
+        r = np.zeros(32, np.uint8)
+        r[b // 8] = 1 << (b % 8)
+        rows.append(r)
+    for k in range(32):
+        r = np.zeros(32, np.uint8)
+        r[k] = 255
+        rows.append(r)
+        r2 = np.zeros(32, np.uint8)
+        r2[:k] = 0xA5
+        rows.append(r2)
+    t = np.array(rows, np.uint8)
+    rng = np.random.RandomState(5)
+    q = t[rng.permutation(len(t))[:60]].copy()
+    q[::3, 5] ^= 0x10                                       # near-duplicates: distance 1 to exactly one train row
+    idx, dist = ctx.match_knn2(q, t)
+    io, do = O.match_knn2(q, t)
+    assert np.array_equal(idx, io) and np.array_equal(dist, do)
 
 
 def test_knn2_empty_sets(mvo, O, ctx):
