@@ -57,6 +57,7 @@ void mvo_prof_collect(mvo_ctx* c) {
 }
 
 int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
+static int g_match_host_out = 1;  // measurement knob: 0 = k_knn2 delivers into HBM, a copy follows
 
 extern "C" {
 
@@ -297,7 +298,12 @@ static int knn2_common(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* 
     // the merge kernel writes the nq x (idx[2], dist[2]) block straight into the pinned staging buffer
     int r = mvo_ensure_pinned(ctx, (size_t)nq * 16);
     if (r) return r;
-    if ((r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout, reinterpret_cast<int32_t*>(ctx->h_pin)))) return r;
+    if (g_match_host_out) {
+        if ((r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout, reinterpret_cast<int32_t*>(ctx->h_pin)))) return r;
+    } else {  // measurement knob: the kernel delivers into HBM and a copy follows (kernel time without the PCIe write tail)
+        if ((r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout, nullptr))) return r;
+        MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_mout, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->prof) mvo_prof_collect(ctx);
     std::memcpy(idx, ctx->h_pin, (size_t)nq * 8);
@@ -452,6 +458,10 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 // ---------------------------------------------------------------------------------------------- debug hooks
 int mvo_debug_set(const char* key, int value) {
     if (key && !std::strncmp(key, "ba_", 3)) return ba_debug_set(key, value);
+    if (key && !std::strcmp(key, "match_host_out")) {
+        g_match_host_out = value;
+        return MVO_OK;
+    }
     if (key && !std::strcmp(key, "match_mfma")) {
         g_match_mfma = value;
         return MVO_OK;
