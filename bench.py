@@ -405,20 +405,37 @@ def main(argv=None, env=None):
         per_kernel = {}
         if solves:
             flops = trials * ba_trial_flops(E_avg, args.ba_points, args.ba_poses, fix)
-            avg_ms = launch["ms"] / max(launch["launches"], 1)
-            roof = dict(bound="mfma", achieved=flops / (launch["ms"] * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
-            roof["frac"] = roof["achieved"] / roof["peak"]
-            roof.update(kernel="k_ba_lm", avg_launch_ms=avg_ms, launches=launch["launches"],
-                        windows_per_launch=launch["windows"] / max(launch["launches"], 1),
-                        algorithmic_per_launch=flops / max(launch["launches"], 1),
-                        trials_per_solve=trials / max(solves, 1), launch_thread_ms=launch.get("service_ms"),
-                        timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2))
+            resident = launch.get("resident_windows", 0) > 0.5 * max(launch["windows"], 1)
+            if resident:
+                # resident solver service: ONE grid (k_ba_service) stays on the device for the whole timed region and its slots
+                # pull windows; the kernel's duration is the region, its work the windows solved in it.  Per window: the
+                # device-clock duration of its solve (launch["ms"] sums them, launches == windows).
+                busy_ms = launch.get("elapsed_ms", elapsed * 1e3)
+                roof = dict(bound="mfma", achieved=flops / (busy_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                avg_ms = launch["ms"] / max(launch["windows"], 1)
+                roof.update(kernel="k_ba_service (resident k_ba_lm body)", avg_launch_ms=busy_ms, launches=max(1, launch.get("resident_grid_starts", 1)),
+                            windows_per_launch=launch["windows"], avg_window_ms=avg_ms,
+                            windows_in_flight=launch["ms"] / max(busy_ms, 1e-9),
+                            algorithmic_per_launch=flops, trials_per_solve=trials / max(solves, 1),
+                            launch_thread_ms=launch.get("service_ms"), timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2),
+                            note="the resident grid is launched once and spans the timed region: duration = the region, work = the "
+                                 "windows its 16 slots solved in it; avg_window_ms = mean solve time of a window on the device clock")
+            else:
+                avg_ms = launch["ms"] / max(launch["launches"], 1)
+                roof = dict(bound="mfma", achieved=flops / (launch["ms"] * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                roof.update(kernel="k_ba_lm", avg_launch_ms=avg_ms, launches=launch["launches"],
+                            windows_per_launch=launch["windows"] / max(launch["launches"], 1),
+                            algorithmic_per_launch=flops / max(launch["launches"], 1),
+                            trials_per_solve=trials / max(solves, 1), launch_thread_ms=launch.get("service_ms"),
+                            timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2))
             tr = pmc_traffic("k_ba_lm")
             # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command (tools/collect_evidence.sh); the
             # hand-offs are 8-byte accesses, a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported
             # uncorrected
             roof["traffic"], roof["traffic_source"] = (tr[0], tr[1]) if tr else (None, None)
-            per_kernel["k_ba_lm"] = launch["ms"] / max(args.steps * args.streams, 1)
+            per_kernel["k_ba_lm"] = (launch.get("elapsed_ms", 0.0) if resident else launch["ms"]) / max(args.steps * args.streams, 1)
         else:
             roof = None
         # ---- per-kernel durations of the other kernels: HIP events on the ctx stream of ONE shard running the serial loop
@@ -509,6 +526,12 @@ def main(argv=None, env=None):
                                          "from it, ONLY its inliers (%d) become the frame's map-point connections (vo.cpp:304-357), "
                                          "then the window is marshalled and solved (vo.cpp:408-449)" % inl_c)
 
+        # host wall-clock per frame of the loop's stages in the HEADLINE run (mean over the shards): shows which stage the
+        # shards wait in (extract = extraction + matching call, end = wait for the solve + scatter)
+        nfr = max(1, sum(a.frame_no - b.frame_no for a, b in zip(st_after, st_before)))
+        secondary["headline_host_us_per_frame"] = {
+            k: round(sum(getattr(a, "ns_" + k) - getattr(b, "ns_" + k) for a, b in zip(st_after, st_before)) / nfr / 1e3, 1)
+            for k in ("extract", "restore", "build", "begin", "end")}
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, shards[0])
         cpu_mt = None
         nthr = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads

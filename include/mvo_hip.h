@@ -241,6 +241,10 @@ int mvo_ba_launch_stats(int device, long long* launches, long long* windows, dou
 /* Wall-clock (ms, since the last reset of mvo_ba_launch_stats) the launch thread spent: [0] waiting for work, [1] waiting
  * for a full batch, [2] building + issuing launches, [3] waiting for the kernels, [4] publishing results. */
 int mvo_debug_ba_service_times(int device, double* out5);
+/* Resident solver service (throughput mode): windows it solved and how often the resident grid was put on the device since
+ * the last reset of mvo_ba_launch_stats (those windows count as one launch each there, `ms` = their solve times on the
+ * device clock). */
+int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_starts);
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per
  * kernel name until reset. */
 int mvo_profile_enable(mvo_ctx* ctx, int on);

@@ -26,6 +26,7 @@
 int ba_kernel_set_lds_limit();
 hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr, int slots);
 int ba_solver_class(int n);
+hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream);
 
 int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
@@ -33,6 +34,7 @@ int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
 int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
 int g_ba_cu_share = 0;   // CUs a solver grid may take (0 = all)
 int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
+int g_ba_service = 1;     // 1 = throughput-mode windows of the 5-pose class go to the resident solver service
 int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
@@ -51,6 +53,7 @@ struct Carver {
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
         ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1;
+    bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
     std::vector<int> wg_pt;
@@ -116,6 +119,8 @@ struct BaJob {
     hipError_t err = hipSuccess;
     float ms = 0;   // duration of the launch this window was part of
     int batch = 0;  // windows in that launch
+    int slot = -1;  // resident service: the slot the job was posted to (-1: not posted / launch path)
+    unsigned long long seq = 0;  // and its sequence number there
 };
 // One launch in flight: its windows and the events around it (the completion thread turns it into results).
 struct BaFlight {
@@ -133,6 +138,19 @@ struct BaService {
     std::vector<BaFlight*> flight_pool;
     std::thread th, th_done;
     bool started = false;
+    // resident solver service (k_ba_service): BA_SERVICE_SLOTS slots of `wgs_per_slot` workgroups stay on the device and
+    // pull windows from their mailboxes; the launch thread only assigns slots
+    bool resident = false;               // the grid is on the device
+    BaMail* mail = nullptr;              // pinned host memory
+    ba_u64* d_cmd = nullptr;             // device memory: 8 words per slot + one arrival counter per slot
+    hipStream_t resident_stream = nullptr;
+    unsigned long long slot_seq[BA_SERVICE_SLOTS] = {0};
+    BaJob* slot_job[BA_SERVICE_SLOTS] = {nullptr};
+    int slots_busy = 0, wgs_per_slot = 14;
+    std::condition_variable cv_slot;
+    long long resident_jobs = 0, resident_starts = 0;
+    int start_resident();
+    void stop_resident(std::unique_lock<std::mutex>& lk);
     // who submitted recently (workspace -> time of its last job): with several clients active a launch waits a moment for
     // a full batch, a lone client is never held back
     std::map<const BaWorkspace*, std::chrono::steady_clock::time_point> seen;
@@ -176,8 +194,47 @@ void BaService::run() {
         BaFlight* fl = nullptr;
         {
             std::unique_lock<std::mutex> lk(m);
-            cv_work.wait(lk, [&] { return !q.empty(); });
+            // (with the resident grid on the device the thread wakes up now and then: an idle grid is taken off after 20 ms)
+            while (q.empty()) {
+                if (!resident) {
+                    cv_work.wait(lk, [&] { return !q.empty(); });
+                } else if (!cv_work.wait_for(lk, std::chrono::milliseconds(20), [&] { return !q.empty(); }) && slots_busy == 0) {
+                    stop_resident(lk);
+                }
+            }
             lap(l_idle);
+            if (q.front()->ws->plan.service) {
+                // ---- resident solver service: no launch per window -- the job goes to a free slot of the resident grid
+                cv_flight.wait(lk, [&] { return flights.empty(); });  // (launch-path grids and the resident grid never share the device)
+                if (!resident && start_resident() != 0) {
+                    BaJob* j = q.front();
+                    q.pop_front();
+                    j->err = hipErrorUnknown;
+                    j->done = true;
+                    cv_done.notify_all();
+                    continue;
+                }
+                cv_slot.wait(lk, [&] { return slots_busy < BA_SERVICE_SLOTS; });
+                BaJob* j = q.front();
+                q.pop_front();
+                int sl = 0;
+                while (slot_job[sl]) ++sl;
+                slot_job[sl] = j;
+                ++slots_busy;
+                ++resident_jobs;
+                j->seq = ++slot_seq[sl];
+                BaMail* mb = mail + sl;
+                mb->desc = (ba_u64)(uintptr_t)(j->ws->pin + j->ws->plan.o_desc);
+                mb->flags = (ba_u64)(j->ws->seq << 12) | ((ba_u64)(j->use_mfma ? 1 : 0) << 32) | ((ba_u64)(g_ba_same_l2 ? 1 : 0) << 33);
+                __atomic_store_n(&mb->seq, j->seq, __ATOMIC_RELEASE);  // (fields first, the sequence number last)
+                j->slot = sl;
+                cv_done.notify_all();  // (the waiting client learns its slot)
+                lap(l_launch);
+                t_idle += l_idle, t_launch += l_launch;
+                l_idle = l_launch = 0;
+                continue;
+            }
+            if (resident) stop_resident(lk);  // a launch-path window: the resident grid leaves first
             int share = g_ba_cu_share > 0 ? g_ba_cu_share : cus;
             share = std::max(1, std::min(share, cus));
             {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
@@ -251,6 +308,43 @@ void BaService::run() {
         cv_flight.notify_all();
     }
 }
+int BaService::start_resident() {
+    // (called with the service mutex held; everything here is quick)
+    if (!mail) {
+        if (hipHostMalloc((void**)&mail, sizeof(BaMail) * BA_SERVICE_SLOTS, hipHostMallocDefault) != hipSuccess) return -1;
+        std::memset(mail, 0, sizeof(BaMail) * BA_SERVICE_SLOTS);
+        if (hipMalloc((void**)&d_cmd, sizeof(ba_u64) * 9 * BA_SERVICE_SLOTS) != hipSuccess) return -1;
+        if (hipStreamCreateWithFlags(&resident_stream, hipStreamNonBlocking) != hipSuccess) return -1;
+    }
+    BaServiceArgs a{};
+    a.mail = mail;
+    a.cmd = d_cmd;
+    a.arrived = d_cmd + 8 * BA_SERVICE_SLOTS;
+    a.nslots = BA_SERVICE_SLOTS;
+    a.wgs_per_slot = wgs_per_slot;
+    ba_u64 init[9 * BA_SERVICE_SLOTS] = {0};
+    for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) {
+        a.first_seq[sl] = slot_seq[sl];
+        init[8 * sl] = slot_seq[sl];  // (the republished sequence number starts where the mailbox stands: no job)
+        mail[sl].seq = slot_seq[sl];
+        mail[sl].stop = 0;
+        mail[sl].done_seq = slot_seq[sl];
+    }
+    if (hipMemcpyAsync(d_cmd, init, sizeof(init), hipMemcpyHostToDevice, resident_stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(resident_stream) != hipSuccess) return -1;
+    if (ba_service_launch(a, resident_stream) != hipSuccess) return -1;
+    resident = true;
+    ++resident_starts;
+    return 0;
+}
+void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
+    cv_slot.wait(lk, [&] { return slots_busy == 0; });
+    for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&mail[sl].stop, (ba_u64)1, __ATOMIC_RELEASE);
+    lk.unlock();
+    (void)hipStreamSynchronize(resident_stream);
+    lk.lock();
+    resident = false;
+}
 void BaService::complete() {
     (void)hipSetDevice(device);
     auto tp = std::chrono::steady_clock::now();
@@ -294,13 +388,37 @@ void BaService::complete() {
         cv_work.notify_all();  // (the launch thread may be waiting for "no grid left")
     }
 }
+// at process exit a resident grid must not outlive the host: post `stop` to every slot and wait for the grid (running
+// solves finish first; their results simply are not collected any more)
+void ba_service_shutdown() {
+    for (int d = 0; d < 16; ++d) {
+        BaService* sp = g_service[d];
+        if (!sp) continue;
+        std::unique_lock<std::mutex> lk(sp->m);
+        if (!sp->resident) continue;
+        for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&sp->mail[sl].stop, (ba_u64)1, __ATOMIC_RELEASE);
+        lk.unlock();
+        (void)hipSetDevice(sp->device);
+        (void)hipStreamSynchronize(sp->resident_stream);
+        lk.lock();
+        sp->resident = false;
+    }
+}
 BaService& service_for(int device) {
     std::lock_guard<std::mutex> lk(*g_service_start);
-    if (!g_service[device & 15]) g_service[device & 15] = new BaService();
+    if (!g_service[device & 15]) {
+        g_service[device & 15] = new BaService();
+        static bool hooked = false;
+        if (!hooked) {
+            hooked = true;
+            std::atexit(ba_service_shutdown);
+        }
+    }
     BaService& s = *g_service[device & 15];
     if (!s.started) {
         s.device = device;
         s.started = true;
+        if (const char* e = std::getenv("MVO_BA_SERVICE")) g_ba_service = std::atoi(e);
         s.th = std::thread([&s] { s.run(); });
         s.th.detach();  // lives as long as the process; blocks on its queue when idle
         s.th_done = std::thread([&s] { s.complete(); });
@@ -320,6 +438,40 @@ void service_submit(BaService& s, BaJob* jobs, int n) {
     s.cv_work.notify_one();
 }
 void service_wait(BaService& s, BaJob* jobs, int n) {
+    for (int i = 0; i < n; ++i) {
+        BaJob& j = jobs[i];
+        if (!j.ws || !j.ws->plan.service) continue;
+        {   // resident service: wait for the slot, then poll its completion word (pinned host memory the device writes)
+            std::unique_lock<std::mutex> lk(s.m);
+            s.cv_done.wait(lk, [&] { return j.slot >= 0 || j.done; });
+            if (j.done) continue;
+        }
+        const ba_u64* done_seq = &s.mail[j.slot].done_seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; ++spin) {
+            if (__atomic_load_n(done_seq, __ATOMIC_ACQUIRE) >= j.seq) break;
+            if ((spin & 1023) == 1023) {
+                std::this_thread::yield();
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    j.err = hipErrorUnknown;  // (the grid left or hangs: reported, never waited for forever)
+                    break;
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(s.m);
+            s.slot_job[j.slot] = nullptr;
+            --s.slots_busy;
+            const BaStatsDev* sd = (const BaStatsDev*)(j.ws->pin + j.ws->plan.m_stats);
+            j.ms = (float)(sd->solve_ticks * 1e-5);  // 100 MHz ticks -> ms
+            j.batch = 1;
+            j.done = true;
+            ++s.launches;  // (statistics: every window of the resident grid counts as its own launch of `ms`)
+            ++s.windows;
+            s.ms += j.ms;
+        }
+        s.cv_slot.notify_all();
+    }
     std::unique_lock<std::mutex> lk(s.m);
     s.cv_done.wait(lk, [&] {
         for (int i = 0; i < n; ++i)
@@ -388,6 +540,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     const int reserve = env_reserve >= 0 ? env_reserve : g_ba_xcd_reserve;
     const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
     const int g_cap = ctx->ba_throughput_mode ? per_xcd / 2 : per_xcd;
+    service_for(ctx->device).wgs_per_slot = per_xcd / 2;
     int G = 1;
     while (G < g_cap && E > 160 * G) G = std::min(2 * G, g_cap);
     if (g_ba_wgs > 0) G = g_ba_wgs;
@@ -623,23 +776,28 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.lc00 = lc00;
     B.lc01 = lc01;
     B.lc11 = lc11;
-    B.poses_in = (const double*)(D + P.o_pin);
+    // Windows for the resident solver service are read by the device straight from this pinned image (the grid is already
+    // running: a host-to-device copy into memory it may have cached would not be seen); every other window is uploaded.
+    P.service = g_ba_service && ctx->ba_throughput_mode && !g_ba_profile && !g_ba_block_solver && P.runnable &&
+                ba_solver_class(n) == 32 && P.slots != 0 && G <= service_for(ctx->device).wgs_per_slot;
+    char* I = P.service ? ws.pin : D;  // where the kernel finds the inputs
+    B.poses_in = (const double*)(I + P.o_pin);
     B.poses_out = (double*)(D + P.o_pout);
-    B.pts_in = (const double*)(D + P.o_ptsin);
+    B.pts_in = (const double*)(I + P.o_ptsin);
     B.pts_out = (double*)(D + P.o_pts);
-    B.wg_pt_start = (const int*)(D + P.o_wpt);
-    B.wg_edge_start = (const int*)(D + P.o_wed);
-    B.wg_pose_start = (const int*)(D + P.o_wps);
-    B.e_pose = (const int*)(D + P.o_ep);
-    B.e_point = (const int*)(D + P.o_el);
-    B.e_uv = (const double*)(D + P.o_uv);
-    B.pt_edge_start = (const int*)(D + P.o_ptstart);
-    B.pt_edge_list = (const int*)(D + P.o_ptl);
-    B.eof = (const short*)(D + P.o_eof);
-    B.dup_rank = (const short*)(D + P.o_dup);
-    B.pose_slot = (const int*)(D + P.o_slot);
-    B.slot_pose = (const int*)(D + P.o_sp);
-    B.pk_of_tile = (const short*)(D + P.o_pkt);
+    B.wg_pt_start = (const int*)(I + P.o_wpt);
+    B.wg_edge_start = (const int*)(I + P.o_wed);
+    B.wg_pose_start = (const int*)(I + P.o_wps);
+    B.e_pose = (const int*)(I + P.o_ep);
+    B.e_point = (const int*)(I + P.o_el);
+    B.e_uv = (const double*)(I + P.o_uv);
+    B.pt_edge_start = (const int*)(I + P.o_ptstart);
+    B.pt_edge_list = (const int*)(I + P.o_ptl);
+    B.eof = (const short*)(I + P.o_eof);
+    B.dup_rank = (const short*)(I + P.o_dup);
+    B.pose_slot = (const int*)(I + P.o_slot);
+    B.slot_pose = (const int*)(I + P.o_sp);
+    B.pk_of_tile = (const short*)(I + P.o_pkt);
     B.xP = (ba_u64*)(D + P.o_xp);
     B.xR = (ba_u64*)(D + P.o_xr);
     B.xH = (ba_u64*)(D + P.o_xh);
@@ -655,6 +813,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
 }
 
 int ba_upload(mvo_ctx* ctx, BaWorkspace& ws) {
+    if (ws.plan.service) return MVO_OK;  // (the resident grid reads the pinned image itself)
     MVO_HIP(hipMemcpyAsync(ws.dev, ws.pin, ws.plan.upload_end, hipMemcpyHostToDevice, ctx->stream));
     MVO_HIP(hipEventRecord(ws.ready, ctx->stream));
     return MVO_OK;
@@ -881,6 +1040,20 @@ void ba_service_times(int device, double* out5) {
     std::lock_guard<std::mutex> lk(sp->m);
     out5[0] = sp->t_idle, out5[1] = sp->t_batch, out5[2] = sp->t_launch, out5[3] = sp->t_sync, out5[4] = sp->t_post;
 }
+void ba_resident_stats(int device, long long* windows, long long* grid_starts) {
+    if (windows) *windows = 0;
+    if (grid_starts) *grid_starts = 0;
+    if (device < 0 || device >= 16) return;
+    BaService* sp;
+    {
+        std::lock_guard<std::mutex> lk(*g_service_start);
+        sp = g_service[device & 15];
+    }
+    if (!sp) return;
+    std::lock_guard<std::mutex> lk(sp->m);
+    if (windows) *windows = sp->resident_jobs;
+    if (grid_starts) *grid_starts = sp->resident_starts;
+}
 void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
     if (launches) *launches = 0;
     if (windows) *windows = 0;
@@ -901,5 +1074,6 @@ void ba_launch_stats(int device, long long* launches, long long* windows, double
         s.launches = s.windows = 0;
         s.ms = 0;
         s.t_idle = s.t_batch = s.t_launch = s.t_sync = s.t_post = 0;
+        s.resident_jobs = s.resident_starts = 0;
     }
 }

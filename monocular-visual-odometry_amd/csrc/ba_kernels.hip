@@ -320,6 +320,13 @@ __device__ __forceinline__ void huber(double e, double delta, double& rho0, doub
     }
 }
 
+__device__ __forceinline__ void asm_waitcnt_vm0() {
+#ifndef MVO_KERNEL_SIM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+#endif
+}
 // the XCD this workgroup runs on (placement is used for speed only, never for results)
 __device__ __forceinline__ unsigned ba_xcc_id() {
 #ifndef MVO_KERNEL_SIM
@@ -753,24 +760,26 @@ __device__ __forceinline__ void edge_Y(const EdgeRegs& r, const double* cc, doub
 // SLOTS: where the rows of an edge live between the linearisation and the trials -- 0: all of them in LDS (ranges that
 // have the room: the latency cut of the 5-keyframe window; fewest registers), 1: in the registers of thread `edge` (<= 512
 // edges per range), 2: edges behind 512 in LDS (ranges of up to 1024 edges).
+// One window, one workgroup of it: `desc` = the window's descriptor (device memory, or pinned host memory for the resident
+// solver service), g = this workgroup's range.  Called once per launch by k_ba_lm and once per job by k_ba_service.
+struct BaRun {
+    unsigned tag0;
+    int use_mfma, same_l2_ok;
+};
 template <bool PROF, int NR, int SLOTS>
-__global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
-    // window = blockIdx % stride; the stride is a multiple of 8 whenever several windows share a launch: with the
-    // dispatcher's round-robin placement (block b on XCD b % 8) the workgroups of a window then share one XCD (one L2)
-    const int win = blockIdx.x % batch.stride;
-    const int g = blockIdx.x / batch.stride;
-    if (win >= batch.nwin) return;
+__device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, const int g) {
     // the descriptor is staged in LDS: read through the global pointer the compiler has to assume that every store of
     // the kernel may have changed it and re-loads fields from memory all over the LM loop
     __shared__ BaDev sB;
     {
-        const unsigned* src = reinterpret_cast<const unsigned*>(batch.win[win]);
+        const unsigned* src = reinterpret_cast<const unsigned*>(desc);
         unsigned* dst = reinterpret_cast<unsigned*>(&sB);
         for (unsigned i = threadIdx.x; i < sizeof(BaDev) / 4; i += BA_THREADS) dst[i] = src[i];
     }
     __syncthreads();
     const BaDev& B = sB;
     if (g >= B.G) return;
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
     double* dyn = ba_dyn_lds;
     __shared__ double sScr[BA_WAVES];
     // per-pose state and the per-workgroup exchange values live at the front of the dynamic segment (sized by F and G)
@@ -793,7 +802,7 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
     const int n = B.n, G = B.G, nfree = B.nfree, urows = B.ldu, ldu = B.ldu + 1, nlow = B.nlow, npk = B.npk;
     const int pt_lo = B.wg_pt_start[g], Lg = B.wg_pt_start[g + 1] - pt_lo;
     const int e_lo = B.wg_edge_start[g], Eg = B.wg_edge_start[g + 1] - e_lo;
-    const unsigned tag0 = batch.tag_base[win];
+    const unsigned tag0 = batch.tag0;
     unsigned tagA = 0, tagB = 0, tagH = 0;
 
     // ---- carve the dynamic LDS (the same sizes as ba_lds_bytes)
@@ -1746,10 +1755,95 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
             for (int i = 0; i < BA_NPHASE; ++i) st.phase[i] = ph[PROF ? i : 0];
         }
         st.phase[15] = same_l2 ? 1 : 0;
+        st.solve_ticks = (long long)(__builtin_amdgcn_s_memrealtime() - t_begin);
         if (PROF && B.trace)
             for (int i = 0; i < 32; ++i) reinterpret_cast<double*>(B.trace + 400)[i] = (double)sStamp[PROF ? i : 0];
         *B.stats = st;
         if (B.h_stats) *B.h_stats = st;
+    }
+}
+
+// The launch form: window = blockIdx % stride; the stride is a multiple of 8 whenever several windows share a launch: with the
+// dispatcher's round-robin placement (block b on XCD b % 8) the workgroups of a window then share one XCD (one L2).
+template <bool PROF, int NR, int SLOTS>
+__global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
+    const int win = blockIdx.x % batch.stride;
+    const int g = blockIdx.x / batch.stride;
+    if (win >= batch.nwin) return;
+    BaRun run = {batch.tag_base[win], batch.use_mfma, batch.same_l2_ok};
+    ba_window<PROF, NR, SLOTS>(batch.win[win], run, g);
+}
+
+// The resident form (solver service): the grid is launched ONCE and stays; slot = blockIdx % nslots (two slots per XCD
+// with 16 slots), workgroup g = blockIdx / nslots of its slot.  Workgroup 0 of a slot polls the slot's mailbox in pinned
+// host memory; a new sequence number is a job: it republishes the job to the other workgroups of the slot through a word
+// pair in device memory (same XCD: they poll its L2), everybody solves the window -- inputs are read straight from the
+// pinned upload image, results go to the pinned mirrors as always --, the workgroups count themselves off, workgroup 0 writes
+// the job's sequence number into the window's pinned status word and the slot waits for the next job.  A slot leaves when
+// the host posts `stop` or nothing has arrived for BA_SERVICE_IDLE_TICKS of the 100 MHz clock (safety net: the grid must
+// never outlive its host).
+template <int NR, int SLOTS>
+__global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
+    const int slot = blockIdx.x % a.nslots;
+    const int g = blockIdx.x / a.nslots;
+    __shared__ unsigned long long sJob[4];  // seq, desc, (tag0 | use_mfma << 32), stop
+    volatile BaMail* mail = a.mail + slot;
+    u64* cmd = a.cmd + 8 * (size_t)slot;    // device memory: {seq, desc, flags, stop} republished by workgroup 0
+    u64* arrived = a.arrived + slot;        // device memory: workgroups that finished the current job (monotonic)
+    unsigned long long last = a.first_seq[slot];
+    unsigned long long idle0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (threadIdx.x == 0) {
+            unsigned long long seq, stop = 0, desc = 0, flags = 0;
+            for (;;) {
+                if (g == 0) {
+                    seq = __hip_atomic_load(&mail->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    stop = __hip_atomic_load(&mail->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (!stop && seq == last && __builtin_amdgcn_s_memrealtime() - idle0 > BA_SERVICE_IDLE_TICKS) stop = 1;
+                    if (seq != last || stop) {
+                        desc = __hip_atomic_load(&mail->desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        flags = __hip_atomic_load(&mail->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        __hip_atomic_store(cmd + 1, desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(cmd + 2, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(cmd + 3, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm_waitcnt_vm0();
+                        __hip_atomic_store(cmd, stop ? ~0ull : seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                } else {
+                    seq = __hip_atomic_load(cmd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seq != last) {
+                        desc = __hip_atomic_load(cmd + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        flags = __hip_atomic_load(cmd + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        stop = __hip_atomic_load(cmd + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            sJob[0] = seq, sJob[1] = desc, sJob[2] = flags, sJob[3] = stop;
+        }
+        __syncthreads();
+        const unsigned long long seq = sJob[0], desc = sJob[1], flags = sJob[2], stop = sJob[3];
+        __syncthreads();
+        if (stop) return;
+        last = seq;
+        BaRun run = {(unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1)};
+        const BaDev* D = reinterpret_cast<const BaDev*>(desc);
+        ba_window<false, NR, SLOTS>(D, run, g);
+        // ---- completion: every workgroup of the slot counts itself off once its results are on their way to the host (every
+        // wave drains its own stores first); workgroup 0 waits for all of them and then posts the job's sequence number
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(arrived, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == 0) {
+                const unsigned long long want = (unsigned long long)a.wgs_per_slot * (seq - a.first_seq[slot]);
+                while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+                __hip_atomic_store(&mail->done_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        idle0 = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1771,6 +1865,11 @@ int ba_kernel_set_lds_limit() {
                 bad |= hipFuncSetAttribute((const void*)ba_kernel_for(profile, nr, slots), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            BA_LDS_BUDGET) != hipSuccess;
     return bad ? -1 : 0;
+}
+hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
+    hipLaunchKernelGGL((k_ba_service<32, 2>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
+    return hipGetLastError();
 }
 // solver class of a window with n unknowns (windows of one launch share it)
 int ba_solver_class(int n) { return n + 1 <= 32 ? 32 : (n + 1 <= 64 ? 64 : 0); }

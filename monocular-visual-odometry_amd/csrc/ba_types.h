@@ -40,6 +40,7 @@ struct BaStatsDev {
     int iterations, trials, terminated, error;
     double chi2_initial, chi2_final, lambda_final;
     long long phase[BA_NPHASE];  // shader-clock cycles per phase as seen by thread 0 of workgroup 0
+    long long solve_ticks;       // duration of the solve on the 100 MHz clock (workgroup 0, load to write-back)
 };
 // phase ids: 0 LIN, 1 pose-block chains, 2 landmark blocks + pose-block exchange, 3 T1 + U, 4 Schur chains,
 // 5 publish + slice reduction + gather, 6 assemble, 7 reduced solve, 8 back-substitution + update, 9 chi2,
@@ -104,6 +105,27 @@ struct BaBatch {  // kernel argument: the windows of one launch
     int stride;      // blockIdx -> (window = b % stride, workgroup = b / stride); 8 when every window has <= 32 workgroups
     int use_mfma;    // 0: validation path (the same fma chains on the vector ALU)
     int same_l2_ok;  // 0: always publish write-through (test hook); 1: plain stores when a window sits on one XCD
+};
+
+// ---- resident solver service (k_ba_service): one mailbox per slot in pinned host memory, written by the host's scheduler
+// (fields first, `seq` last) and polled by workgroup 0 of the slot; `done_seq` is written by the device when the job's
+// results are in the window's pinned mirrors.
+#define BA_SERVICE_SLOTS 16
+#define BA_SERVICE_IDLE_TICKS 300000000ull  // 3 s of the 100 MHz clock without a job: the slot leaves by itself
+struct BaMail {
+    ba_u64 seq;       // job number of this slot (monotonic)
+    ba_u64 desc;      // the window's descriptor (pinned host address, device-readable)
+    ba_u64 flags;     // tag base | use_mfma << 32 | same_l2_ok << 33
+    ba_u64 stop;      // 1: leave
+    ba_u64 done_seq;  // device -> host
+    ba_u64 pad[3];
+};
+struct BaServiceArgs {
+    BaMail* mail;          // BA_SERVICE_SLOTS mailboxes (pinned host memory)
+    ba_u64* cmd;           // device memory: 8 words per slot (job republished to the slot's workgroups)
+    ba_u64* arrived;       // device memory: one counter per slot
+    ba_u64 first_seq[BA_SERVICE_SLOTS];  // seq of every slot at launch
+    int nslots, wgs_per_slot;
 };
 
 // ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner

@@ -6,7 +6,7 @@
 
 #include "mvo_internal.h"
 
-extern int g_ba_use_mfma, g_ba_wgs, g_ba_same_l2, g_ba_profile, g_ba_block_solver, g_ba_cu_share, g_ba_xcd_reserve, g_ba_edge_rows;  // ba_host.cpp
+extern int g_ba_use_mfma, g_ba_wgs, g_ba_same_l2, g_ba_profile, g_ba_block_solver, g_ba_cu_share, g_ba_xcd_reserve, g_ba_edge_rows, g_ba_service;  // ba_host.cpp
 // mvo_debug_set("ba_*", v): validation paths and planner overrides the tests compare
 int ba_debug_set(const char* key, int value) {
     if (!std::strcmp(key, "ba_mfma")) g_ba_use_mfma = value;
@@ -17,6 +17,7 @@ int ba_debug_set(const char* key, int value) {
     else if (!std::strcmp(key, "ba_cu_share")) g_ba_cu_share = value;
     else if (!std::strcmp(key, "ba_xcd_reserve")) g_ba_xcd_reserve = value;
     else if (!std::strcmp(key, "ba_edge_rows")) g_ba_edge_rows = value;
+    else if (!std::strcmp(key, "ba_service")) g_ba_service = value;
     else return MVO_ERR_INVALID;
     return MVO_OK;
 }
@@ -95,6 +96,11 @@ void mvo_ba_release(mvo_ctx* ctx, mvo_ba_handle* handle) {
 int mvo_debug_ba_service_times(int device, double* out5) {
     if (!out5) return MVO_ERR_INVALID;
     ba_service_times(device, out5);
+    return MVO_OK;
+}
+
+int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_starts) {
+    ba_resident_stats(device, windows, grid_starts);
     return MVO_OK;
 }
 

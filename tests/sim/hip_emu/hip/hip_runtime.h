@@ -100,6 +100,7 @@ inline unsigned long long __ballot(int pred) {
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) emu_yield()
 #define __builtin_amdgcn_s_memtime() ((unsigned long long)emu_clock())
+#define __builtin_amdgcn_s_memrealtime() ((unsigned long long)emu_clock() / 10ull)  // 100 MHz
 // v_rcp_f64 is an approximation that the callers refine by Newton steps to the correctly rounded quotient; starting the
 // refinement from the correctly rounded value ends on the same bits
 #define __builtin_amdgcn_rcp(d) (1.0 / (d))
@@ -175,6 +176,7 @@ typedef int hipError_t;
 #define hipSuccess 0
 #define hipErrorInvalidValue 1
 #define hipErrorNotReady 600
+#define hipErrorUnknown 999
 struct EmuStream;
 struct EmuEvent;
 typedef EmuStream* hipStream_t;

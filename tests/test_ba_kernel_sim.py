@@ -168,3 +168,51 @@ def test_register_resident_rows_flavour(mvo, O, simctx, simlib):
         _bitwise(mvo, O, simctx, mvo.synth.ba_problem(4, 700, 21), fix_points=False, pose_fixed=_fix(4, 1), max_iterations=12)
     finally:
         simlib.mvo_debug_set(b"ba_edge_rows", -1)
+
+
+def test_resident_solver_service(mvo, O, simlib):
+    """Throughput-mode windows go to the resident grid (k_ba_service): slots that stay on the device and pull windows from
+    pinned mailboxes -- no launch per window, inputs read from the pinned image.  Several client threads, more jobs than
+    slots, a latency-mode window in between (the resident grid leaves, a launch runs, the grid comes back): every result
+    must equal the oracle's bits / the launch path's."""
+    import threading
+
+    class Ctx(mvo.Context):
+        def __init__(self):
+            self.lib = simlib
+            h = C.c_void_p()
+            assert simlib.mvo_create(C.byref(h), 0) == 0
+            self.h, self.device, self.params = h, 0, {}
+
+    a, b = C.c_longlong(), C.c_longlong()
+    ms = C.c_double()
+    simlib.mvo_ba_launch_stats(0, C.byref(a), C.byref(b), C.byref(ms), 1)
+    pbs = [mvo.synth.ba_problem(4, 500 + 60 * k, 70 + k) for k in range(5)]
+    c0 = Ctx()
+    c0.ba_set_mode("throughput")
+    st, plan = _bitwise(mvo, O, c0, pbs[0], fix_points=False, max_iterations=5)      # bit for bit through the service
+    ref = [c0.bundle_adjustment(*_args(pb), fix_points=False, max_iterations=5) for pb in pbs]
+    out = [[None, None] for _ in pbs]
+
+    def work(k):
+        c = Ctx()
+        c.ba_set_mode("throughput")
+        for rep in range(2):
+            out[k][rep] = c.bundle_adjustment(*_args(pbs[k]), fix_points=False, max_iterations=5)
+        c.close()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(pbs))]
+    for t in th:
+        t.start()
+    lat = Ctx()                                                                       # default mode: launch path
+    Pl, Xl, stl = lat.bundle_adjustment(*_args(pbs[1]), fix_points=False, max_iterations=5)
+    lat.close()
+    for t in th:
+        t.join()
+    for k in range(len(pbs)):
+        for rep in range(2):
+            assert np.array_equal(ref[k][0], out[k][rep][0]) and np.array_equal(ref[k][1], out[k][rep][1])
+    assert np.abs(Pl - ref[1][0]).max() < 1e-6                                        # (another cut: same optimum, other bits)
+    simlib.mvo_ba_launch_stats(0, C.byref(a), C.byref(b), C.byref(ms), 0)
+    assert b.value >= 1 + len(pbs) * 3 + 1 and ms.value > 0
+    c0.close()
