@@ -314,7 +314,12 @@ int BaService::start_resident() {
         if (hipHostMalloc((void**)&mail, sizeof(BaMail) * BA_SERVICE_SLOTS, hipHostMallocDefault) != hipSuccess) return -1;
         std::memset(mail, 0, sizeof(BaMail) * BA_SERVICE_SLOTS);
         if (hipMalloc((void**)&d_cmd, sizeof(ba_u64) * 9 * BA_SERVICE_SLOTS) != hipSuccess) return -1;
-        if (hipStreamCreateWithFlags(&resident_stream, hipStreamNonBlocking) != hipSuccess) return -1;
+        // The resident grid never ends: nothing else may sit behind it in a hardware queue.  Streams of one priority share the
+        // runtime's pool of hardware queues (GPU_MAX_HW_QUEUES) round-robin; a stream of its own priority class gets a
+        // queue of its own.
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&resident_stream, hipStreamNonBlocking, greatest) != hipSuccess) return -1;
     }
     BaServiceArgs a{};
     a.mail = mail;
@@ -453,7 +458,7 @@ void service_wait(BaService& s, BaJob* jobs, int n) {
             if ((spin & 1023) == 1023) {
                 std::this_thread::yield();
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    j.err = hipErrorUnknown;  // (the grid left or hangs: reported, never waited for forever)
+                    j.err = hipErrorNotReady;  // (the grid left or hangs: reported, never waited for forever)
                     break;
                 }
             }

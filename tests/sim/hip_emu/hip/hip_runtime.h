@@ -193,6 +193,11 @@ const char* hipGetErrorString(hipError_t);
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int device);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int prio);
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) {
+    *least = 0;
+    *greatest = -1;
+    return hipSuccess;
+}
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamQuery(hipStream_t s);

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/r03k
+O=gpurun_out/r03l
 mkdir -p $O
 cat > /tmp/svc_test.py <<'PY'
 import sys, time, numpy as np
@@ -20,8 +20,8 @@ c2 = mvo.Context(0)
 P, X, s2 = c2.bundle_adjustment(*_args(pb), fix_points=False); print("latency-mode launch in between ok", s2["trials"])
 P, X, s3 = ctx.bundle_adjustment(*_args(pb), fix_points=False); print("service again ok", s3["trials"])
 PY
-timeout 120 python /tmp/svc_test.py > $O/svc_test.log 2>&1; echo "svc rc $?"; tail -6 $O/svc_test.log
-timeout 300 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -3 $O/pytest_gpu.log
+echo skip
+echo skip
 for v in "svc:X=1" "nosvc:MVO_BA_SERVICE=0"; do
   name=${v%%:*}; envs=${v#*:}
   for st in 24 32; do
@@ -29,7 +29,7 @@ for v in "svc:X=1" "nosvc:MVO_BA_SERVICE=0"; do
   python - "$name" "$st" <<'PY'
 import json, sys
 try:
-    d = json.loads(open("gpurun_out/r03k/bench_%s_s%s.json" % (sys.argv[1], sys.argv[2])).read().strip().splitlines()[-1])
+    d = json.loads(open("gpurun_out/r03l/bench_%s_s%s.json" % (sys.argv[1], sys.argv[2])).read().strip().splitlines()[-1])
     r = d["roofline"]
     print(sys.argv[1], sys.argv[2], round(d["value"]), round(r["frac"], 4), r.get("avg_window_ms"), r.get("windows_in_flight"), round(r["avg_launch_ms"], 3), r["windows_per_launch"], d["secondary"].get("headline_host_us_per_frame"))
 except Exception as e:
