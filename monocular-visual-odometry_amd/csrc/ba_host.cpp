@@ -150,6 +150,7 @@ struct BaService {
     std::condition_variable cv_slot;
     long long resident_jobs = 0, resident_starts = 0;
     int start_resident();
+    bool reap_locked();
     void stop_resident(std::unique_lock<std::mutex>& lk);
     // who submitted recently (workspace -> time of its last job): with several clients active a launch waits a moment for
     // a full batch, a lone client is never held back
@@ -194,18 +195,16 @@ void BaService::run() {
         BaFlight* fl = nullptr;
         {
             std::unique_lock<std::mutex> lk(m);
-            // (with the resident grid on the device the thread wakes up now and then: an idle grid is taken off after 20 ms)
-            while (q.empty()) {
-                if (!resident) {
-                    cv_work.wait(lk, [&] { return !q.empty(); });
-                } else if (!cv_work.wait_for(lk, std::chrono::milliseconds(20), [&] { return !q.empty(); }) && slots_busy == 0) {
-                    stop_resident(lk);
-                }
-            }
-            lap(l_idle);
-            if (q.front()->ws->plan.service) {
+            // With the resident grid on the device this thread is its scheduler: it polls the completion words of the busy slots
+            // (pinned host memory the device writes), hands finished windows back and posts queued windows to free slots.  A
+            // slot is held exactly as long as the device works on it, not until the client comes back for the result.
+            bool posted_or_reaped = false;
+            if (resident && reap_locked()) posted_or_reaped = true;
+            while (!q.empty() && q.front()->ws->plan.service) {
                 // ---- resident solver service: no launch per window -- the job goes to a free slot of the resident grid
-                cv_flight.wait(lk, [&] { return flights.empty(); });  // (launch-path grids and the resident grid never share the device)
+                if (!flights.empty()) {  // (launch-path grids and the resident grid never share the device)
+                    cv_flight.wait(lk, [&] { return flights.empty(); });
+                }
                 if (!resident && start_resident() != 0) {
                     BaJob* j = q.front();
                     q.pop_front();
@@ -214,7 +213,7 @@ void BaService::run() {
                     cv_done.notify_all();
                     continue;
                 }
-                cv_slot.wait(lk, [&] { return slots_busy < BA_SERVICE_SLOTS; });
+                if (slots_busy >= BA_SERVICE_SLOTS) break;
                 BaJob* j = q.front();
                 q.pop_front();
                 int sl = 0;
@@ -228,12 +227,23 @@ void BaService::run() {
                 mb->flags = (ba_u64)(j->ws->seq << 12) | ((ba_u64)(j->use_mfma ? 1 : 0) << 32) | ((ba_u64)(g_ba_same_l2 ? 1 : 0) << 33);
                 __atomic_store_n(&mb->seq, j->seq, __ATOMIC_RELEASE);  // (fields first, the sequence number last)
                 j->slot = sl;
-                cv_done.notify_all();  // (the waiting client learns its slot)
-                lap(l_launch);
-                t_idle += l_idle, t_launch += l_launch;
-                l_idle = l_launch = 0;
+                posted_or_reaped = true;
+            }
+            if (resident && (q.empty() || q.front()->ws->plan.service)) {
+                // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 20 ms
+                if (slots_busy > 0) {
+                    lk.unlock();
+                    if (!posted_or_reaped) std::this_thread::yield();
+                    continue;
+                }
+                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(20), [&] { return !q.empty(); })) stop_resident(lk);
                 continue;
             }
+            if (q.empty()) {
+                cv_work.wait(lk, [&] { return !q.empty(); });
+                continue;
+            }
+            lap(l_idle);
             if (resident) stop_resident(lk);  // a launch-path window: the resident grid leaves first
             int share = g_ba_cu_share > 0 ? g_ba_cu_share : cus;
             share = std::max(1, std::min(share, cus));
@@ -308,6 +318,26 @@ void BaService::run() {
         cv_flight.notify_all();
     }
 }
+// finished windows of the resident grid -> their clients (service mutex held); true if any slot was freed
+bool BaService::reap_locked() {
+    bool any = false;
+    for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) {
+        BaJob* j = slot_job[sl];
+        if (!j || __atomic_load_n(&mail[sl].done_seq, __ATOMIC_ACQUIRE) < j->seq) continue;
+        const BaStatsDev* sd = (const BaStatsDev*)(j->ws->pin + j->ws->plan.m_stats);
+        j->ms = (float)(sd->solve_ticks * 1e-5);  // 100 MHz ticks -> ms
+        j->batch = 1;
+        j->done = true;
+        slot_job[sl] = nullptr;
+        --slots_busy;
+        ++launches;  // (statistics: every window of the resident grid counts as its own launch of `ms`)
+        ++windows;
+        ms += j->ms;
+        any = true;
+    }
+    if (any) cv_done.notify_all();
+    return any;
+}
 int BaService::start_resident() {
     // (called with the service mutex held; everything here is quick)
     if (!mail) {
@@ -343,7 +373,15 @@ int BaService::start_resident() {
     return 0;
 }
 void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
-    cv_slot.wait(lk, [&] { return slots_busy == 0; });
+    const auto t0 = std::chrono::steady_clock::now();
+    while (slots_busy > 0) {  // (this thread is the one that reaps)
+        if (!reap_locked()) {
+            lk.unlock();
+            std::this_thread::yield();
+            lk.lock();
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;  // (a slot that never answers: give up waiting)
+        }
+    }
     for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&mail[sl].stop, (ba_u64)1, __ATOMIC_RELEASE);
     lk.unlock();
     (void)hipStreamSynchronize(resident_stream);
@@ -443,40 +481,6 @@ void service_submit(BaService& s, BaJob* jobs, int n) {
     s.cv_work.notify_one();
 }
 void service_wait(BaService& s, BaJob* jobs, int n) {
-    for (int i = 0; i < n; ++i) {
-        BaJob& j = jobs[i];
-        if (!j.ws || !j.ws->plan.service) continue;
-        {   // resident service: wait for the slot, then poll its completion word (pinned host memory the device writes)
-            std::unique_lock<std::mutex> lk(s.m);
-            s.cv_done.wait(lk, [&] { return j.slot >= 0 || j.done; });
-            if (j.done) continue;
-        }
-        const ba_u64* done_seq = &s.mail[j.slot].done_seq;
-        const auto t0 = std::chrono::steady_clock::now();
-        for (unsigned spin = 0;; ++spin) {
-            if (__atomic_load_n(done_seq, __ATOMIC_ACQUIRE) >= j.seq) break;
-            if ((spin & 1023) == 1023) {
-                std::this_thread::yield();
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
-                    j.err = hipErrorNotReady;  // (the grid left or hangs: reported, never waited for forever)
-                    break;
-                }
-            }
-        }
-        {
-            std::lock_guard<std::mutex> lk(s.m);
-            s.slot_job[j.slot] = nullptr;
-            --s.slots_busy;
-            const BaStatsDev* sd = (const BaStatsDev*)(j.ws->pin + j.ws->plan.m_stats);
-            j.ms = (float)(sd->solve_ticks * 1e-5);  // 100 MHz ticks -> ms
-            j.batch = 1;
-            j.done = true;
-            ++s.launches;  // (statistics: every window of the resident grid counts as its own launch of `ms`)
-            ++s.windows;
-            s.ms += j.ms;
-        }
-        s.cv_slot.notify_all();
-    }
     std::unique_lock<std::mutex> lk(s.m);
     s.cv_done.wait(lk, [&] {
         for (int i = 0; i < n; ++i)
