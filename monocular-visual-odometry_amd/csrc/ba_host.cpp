@@ -9,6 +9,7 @@
 //                must never be half-resident at the same time; every BA launch of the process goes through this thread,
 //                which batches up to BA_MAX_BATCH pending windows (of any ctx) into one grid.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -147,6 +148,7 @@ struct BaService {
     unsigned long long slot_seq[BA_SERVICE_SLOTS] = {0};
     BaJob* slot_job[BA_SERVICE_SLOTS] = {nullptr};
     int slots_busy = 0, wgs_per_slot = 14;
+    std::atomic<int> q_pending{0};  // queued jobs (lets the scheduler poll without the mutex)
     std::condition_variable cv_slot;
     long long resident_jobs = 0, resident_starts = 0;
     int start_resident();
@@ -208,6 +210,7 @@ void BaService::run() {
                 if (!resident && start_resident() != 0) {
                     BaJob* j = q.front();
                     q.pop_front();
+                    q_pending.fetch_sub(1, std::memory_order_relaxed);
                     j->err = hipErrorUnknown;
                     j->done = true;
                     cv_done.notify_all();
@@ -216,6 +219,7 @@ void BaService::run() {
                 if (slots_busy >= BA_SERVICE_SLOTS) break;
                 BaJob* j = q.front();
                 q.pop_front();
+                q_pending.fetch_sub(1, std::memory_order_relaxed);
                 int sl = 0;
                 while (slot_job[sl]) ++sl;
                 slot_job[sl] = j;
@@ -232,8 +236,16 @@ void BaService::run() {
             if (resident && (q.empty() || q.front()->ws->plan.service)) {
                 // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 20 ms
                 if (slots_busy > 0) {
+                    // poll WITHOUT the mutex (this thread is the only writer of the slot table): the clients need the mutex
+                    // to submit and to wake up -- a scheduler that spins on it starves them
                     lk.unlock();
-                    if (!posted_or_reaped) std::this_thread::yield();
+                    for (;;) {
+                        bool work = q_pending.load(std::memory_order_acquire) > 0 && slots_busy < BA_SERVICE_SLOTS;
+                        for (int sl = 0; sl < BA_SERVICE_SLOTS && !work; ++sl)
+                            work = slot_job[sl] && __atomic_load_n(&mail[sl].done_seq, __ATOMIC_ACQUIRE) >= slot_job[sl]->seq;
+                        if (work) break;
+                        for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
+                    }
                     continue;
                 }
                 if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(20), [&] { return !q.empty(); })) stop_resident(lk);
@@ -281,6 +293,7 @@ void BaService::run() {
                 sum_wgs += G;
                 fl->jobs[fl->nj++] = q.front();
                 q.pop_front();
+                q_pending.fetch_sub(1, std::memory_order_relaxed);
             }
         }
         lap(l_batch);
@@ -477,6 +490,7 @@ void service_submit(BaService& s, BaJob* jobs, int n) {
             s.q.push_back(&jobs[i]);
             s.seen[jobs[i].ws] = now;
         }
+        s.q_pending.fetch_add(n, std::memory_order_release);
     }
     s.cv_work.notify_one();
 }
@@ -952,7 +966,10 @@ int ba_solve_batch_device(mvo_ctx* ctx, mvo_ba_problem* ps, int n, mvo_ba_stats*
     {
         std::lock_guard<std::mutex> lk(S.m);
         for (int i = 0; i < n; ++i)
-            if (!jobs[i].done) S.q.push_back(&jobs[i]);
+            if (!jobs[i].done) {
+                S.q.push_back(&jobs[i]);
+                S.q_pending.fetch_add(1, std::memory_order_release);
+            }
     }
     S.cv_work.notify_one();
     service_wait(S, jobs.data(), n);

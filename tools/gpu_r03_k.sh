@@ -1,7 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-O=gpurun_out/r03m
+O=gpurun_out/r03n
 mkdir -p $O
 cat > /tmp/svc_test.py <<'PY'
 import sys, time, numpy as np
@@ -29,7 +29,7 @@ for v in "svc:X=1" "nosvc:MVO_BA_SERVICE=0"; do
   python - "$name" "$st" <<'PY'
 import json, sys
 try:
-    d = json.loads(open("gpurun_out/r03m/bench_%s_s%s.json" % (sys.argv[1], sys.argv[2])).read().strip().splitlines()[-1])
+    d = json.loads(open("gpurun_out/r03n/bench_%s_s%s.json" % (sys.argv[1], sys.argv[2])).read().strip().splitlines()[-1])
     r = d["roofline"]
     print(sys.argv[1], sys.argv[2], round(d["value"]), round(r["frac"], 4), r.get("avg_window_ms"), r.get("windows_in_flight"), round(r["avg_launch_ms"], 3), r["windows_per_launch"], d["secondary"].get("headline_host_us_per_frame"))
 except Exception as e:
