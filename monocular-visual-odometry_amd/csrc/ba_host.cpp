@@ -53,7 +53,7 @@ struct Carver {
 // Everything the host computes for one window; offsets are relative to the start of the device block.
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
-        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1;
+        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0;
     bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
@@ -626,8 +626,25 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
                 nsplit = nseq * npar;
                 const int msplit = (msteps + nsplit - 1) / nsplit;
-                uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, maxEg, maxEpose, nhp, G, p->fix_points);
-                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges);
+                // passes of the landmark-block phase: as few as keep its staged rows inside what the U chunk needs anyway
+                const size_t floor_area = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, 0, maxEpose, nhp, G, p->fix_points);
+                int npt = 1, pt_edges = maxEg;
+                for (; npt <= 8; ++npt) {
+                    pt_edges = 0;
+                    for (int g = 0; g < G; ++g) {
+                        const int Lg_ = wg_pt[g + 1] - wg_pt[g];
+                        for (int h = 0; h < npt; ++h) {
+                            int cnt = 0;
+                            for (int ll = wg_pt[g] + (int)((long long)Lg_ * h / npt); ll < wg_pt[g] + (int)((long long)Lg_ * (h + 1) / npt); ++ll) cnt += deg[ll];
+                            pt_edges = std::max(pt_edges, cnt);
+                        }
+                    }
+                    if ((size_t)BA_SXS * pt_edges <= floor_area || npt == 8) break;
+                }
+                P.npt = p->fix_points ? 1 : npt;
+                P.panel = (n + 1 > 32 || g_ba_block_solver) ? 1 : 0;
+                uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, pt_edges, maxEpose, nhp, G, p->fix_points);
+                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel);
                 fits = P.lds <= BA_LDS_BUDGET;
                 // rows in LDS only while ONE chunk of U and ONE pass of the pose-block rows still fit next to them: with more
                 // chunks / passes the barriers cost more than the registers save (measured: 2.76 vs 2.41 ms on the BA5 window)
@@ -789,6 +806,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.nseq = nseq;
     B.uarea = (int)uarea;
     B.e2_edges = P.e2_edges;
+    B.npt = P.npt;
+    B.panel = P.panel;
     B.slots = P.slots;
     B.ldu = ldu;
     B.nhp = nhp;

@@ -628,6 +628,7 @@ struct WgLds {
     short* ept;     // maxEg  local landmark index
     short* dup;     // maxEg  rank of the edge among the observations of its (landmark, pose): 0 for the first
     short* ptl;     // maxEg  local edge indices grouped by landmark
+    short* pti;     // maxEg  position of every edge in ptl (the inverse permutation)
     short* pts0;    // maxLg + 1 offsets into ptl
     short* eof;     // maxLg x nfree
 };
@@ -811,11 +812,11 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     {
         double* d = dyn + ba_pose_doubles(B.F) + 2 * (size_t)G + 8;
         W.SL = d;
-        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar) - 3 * 64 - BA_PANEL_DOUBLES;
+        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar, B.panel) - 3 * 64 - (B.panel ? BA_PANEL_DOUBLES : 0);
         W.colbuf = d;
         d += 3 * 64;
         W.pan = d;
-        d += BA_PANEL_DOUBLES;
+        d += B.panel ? BA_PANEL_DOUBLES : 0;
         W.Rl = d;
         d += nlow + B.nhp + 16;
         W.hpl = d;
@@ -850,6 +851,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         s += B.maxEg;
         W.ptl = s;
         s += B.maxEg;
+        W.pti = s;
+        s += B.maxEg;
         W.pts0 = s;
         s += B.maxLg + 1;
         W.eof = s;
@@ -859,7 +862,11 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         W.epose[el] = (short)B.e_pose[e_lo + el];
         W.ept[el] = (short)(B.e_point[e_lo + el] - pt_lo);
         W.dup[el] = B.dup_rank[e_lo + el];
-        W.ptl[el] = (short)(B.pt_edge_list[e_lo + el] - e_lo);
+        {
+            const int pe = B.pt_edge_list[e_lo + el] - e_lo;
+            W.ptl[el] = (short)pe;
+            W.pti[pe] = (short)el;
+        }
         W.uv[el] = B.e_uv[2 * (size_t)(e_lo + el)];  // (u and v in separate arrays)
         W.uv[B.maxEg + el] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
     }
@@ -995,16 +1002,12 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         if (!B.fix_points) {                                                                                        \
             const double* R = sR + 9 * (p);                                                                         \
             const double t0[3] = {f, 0, -x / z * f}, t1[3] = {0, f, -y / z * f};                                    \
-            double* Xs = stage + BA_SXS * (el);                                                                     \
             _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                         \
                 double j0 = -1. / z * (t0[0] * R[c] + t0[1] * R[3 + c] + t0[2] * R[6 + c]);                         \
                 double j1 = -1. / z * (t1[0] * R[c] + t1[1] * R[3 + c] + t1[2] * R[6 + c]);                         \
                 r.x[c] = sw * (B.lc00 * j0 + B.lc01 * j1);                                                          \
                 r.x[3 + c] = sw * (B.lc11 * j1);                                                                    \
             }                                                                                                       \
-            _Pragma("unroll") for (int c = 0; c < 6; ++c) Xs[c] = r.x[c];                                           \
-            Xs[6] = ee[0];                                                                                          \
-            Xs[7] = ee[1];                                                                                          \
         }                                                                                                           \
     }
         if (nslot > 0 && have0) BA_LINEARIZE(tid, er, e0_p, e0_sl, ee0)
@@ -1025,31 +1028,46 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         }
         __syncthreads();
         PH_END(0);
-        // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks (from the staged X~, e~)
+        // ================= PT: 3x3 landmark blocks H_ll, b_l of the own landmarks.  The rows [X~ | e~] of the edges are staged
+        // in the order of the landmark-grouped edge list, one slice of the range's landmarks per pass (B.npt passes: the area
+        // need not hold all edges at once), and read back sequentially by the landmark's thread.
         double maxdiag = 0;
         if (!B.fix_points) {
-            for (int l = tid; l < Lg; l += BA_THREADS) {
-                double h[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-                for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
-                    const double* X = stage + BA_SXS * W.ptl[k];
-                    const double e0 = X[6], e1 = X[7];
-                    h[0] += X[0] * X[0] + X[3] * X[3];
-                    h[1] += X[0] * X[1] + X[3] * X[4];
-                    h[2] += X[0] * X[2] + X[3] * X[5];
-                    h[3] += X[1] * X[1] + X[4] * X[4];
-                    h[4] += X[1] * X[2] + X[4] * X[5];
-                    h[5] += X[2] * X[2] + X[5] * X[5];
-                    b[0] -= X[0] * e0 + X[3] * e1;
-                    b[1] -= X[1] * e0 + X[4] * e1;
-                    b[2] -= X[2] * e0 + X[5] * e1;
+            for (int h = 0; h < B.npt; ++h) {
+                const int l_lo = (int)((long long)Lg * h / B.npt), l_hi = (int)((long long)Lg * (h + 1) / B.npt);
+                const int k_lo = W.pts0[l_lo], k_hi = W.pts0[l_hi];
+#define BA_BODY_STAGE_X(el, r, l_, sl_, ee)                                   \
+    const int k_ = W.pti[el];                                                \
+    if (k_ < k_lo || k_ >= k_hi) break;                                      \
+    double* Xs = stage + BA_SXS * (k_ - k_lo);                               \
+    _Pragma("unroll") for (int c = 0; c < 6; ++c) Xs[c] = r.x[c];            \
+    Xs[6] = ee[0];                                                           \
+    Xs[7] = ee[1];
+                BA_EDGES(BA_BODY_STAGE_X)
+                __syncthreads();
+                for (int l = l_lo + tid; l < l_hi; l += BA_THREADS) {
+                    double h6[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+                    for (int k = W.pts0[l]; k < W.pts0[l + 1]; ++k) {
+                        const double* X = stage + BA_SXS * (k - k_lo);
+                        const double e0 = X[6], e1 = X[7];
+                        h6[0] += X[0] * X[0] + X[3] * X[3];
+                        h6[1] += X[0] * X[1] + X[3] * X[4];
+                        h6[2] += X[0] * X[2] + X[3] * X[5];
+                        h6[3] += X[1] * X[1] + X[4] * X[4];
+                        h6[4] += X[1] * X[2] + X[4] * X[5];
+                        h6[5] += X[2] * X[2] + X[5] * X[5];
+                        b[0] -= X[0] * e0 + X[3] * e1;
+                        b[1] -= X[1] * e0 + X[4] * e1;
+                        b[2] -= X[2] * e0 + X[5] * e1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) W.Hll[BA_XS * l + i] = h6[i];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) W.bl[3 * l + i] = b[i];
+                    maxdiag = fmax(maxdiag, fmax(fabs(h6[0]), fmax(fabs(h6[3]), fabs(h6[5]))));
                 }
-#pragma unroll
-                for (int i = 0; i < 6; ++i) W.Hll[BA_XS * l + i] = h[i];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) W.bl[3 * l + i] = b[i];
-                maxdiag = fmax(maxdiag, fmax(fabs(h[0]), fmax(fabs(h[3]), fabs(h[5]))));
+                __syncthreads();  // (the staged rows are dead: the area takes the next pass / the rows of the pose-block chains)
             }
-            __syncthreads();  // (the staged X~ are dead: the area now takes the rows of the pose-block chains)
         }
         PH_END(2);
         // ================= pose blocks: partial [H_pp | -b_p] = M^T M over the own edges of every free pose, M = the rows

@@ -62,6 +62,8 @@ struct BaDev {
     int npar;    // pieces that run side by side on different waves (one chunk of the U area holds npar pieces)
     int nseq;    // chunks of the U area that are built and consumed one after the other
     int uarea;   // doubles of the multi-purpose U / staging area of a workgroup
+    int npt;     // passes of the landmark-block phase: pass h stages [X~ | e~] of the edges of the h-th slice of a range's landmarks
+    int panel;   // 1: the solver area has the panel of the block LDL^T behind it
     int e2_edges;  // edges per range whose Jacobian rows live in LDS (all of them, or those behind the first 512)
     int slots;   // kernel flavour the plan was made for: 0 = all rows in LDS, 1 / 2 = first 512 edges in registers
     int ldu;     // rows of the U buffer = 16 NT
@@ -129,7 +131,7 @@ struct BaServiceArgs {
 };
 
 // ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner
-__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int npar) {
+__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int npar, int panel) {
     // the solver area also stages the split-chain tiles and the slice reduction (never live together)
     // register solvers: the system is embedded into 32 / 64 rows (ba_kernels.hip: solve_wave)
     size_t a = n + 1 <= 32 ? 32 * 33 : (n + 1 <= 64 ? 64 * 65 : (size_t)(n + 1) * (size_t)(n + 2));
@@ -137,14 +139,14 @@ __host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int 
     const size_t sl = (size_t)((nlow + G - 1) / (G > 0 ? G : 1)) * (size_t)G;
     if (sp > a) a = sp;
     if (sl > a) a = sl;
-    return a + 3 * 64 + BA_PANEL_DOUBLES;  // + two column-broadcast buffers + scratch + the panel of the block solver
+    return a + 3 * 64 + (panel ? BA_PANEL_DOUBLES : 0);  // + two column-broadcast buffers + scratch (+ the panel of the block solver)
 }
 // per-pose state: q t (8) + backup (8), R (9), t (3), H_pp (36), b_p (6), dx (6), solution (6)
 __host__ __device__ inline size_t ba_pose_doubles(int F) { return (size_t)(F > 0 ? F : 1) * 82; }
 // The multi-purpose area must hold: one chunk of U (ucols columns at the odd pitch ldu + 1), the staged [X~ | e~] rows of
 // all edges, the back-substitution terms (3 per edge), the rows [A~ | e~] of the largest pose of any range (the pose-block
 // chains stage whole poses), and the pose-block exchange staging.
-__host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int maxEg, int maxEpose, int nhp, int G, int fix_points) {
+__host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int max_pt_edges, int maxEpose, int nhp, int G, int fix_points) {
     size_t hrows = 4096 / (size_t)(nhp > 0 ? nhp : 1);  // pose-block exchange staging: about 4096 values at a time
     if (hrows < 1) hrows = 1;
     if (hrows > (size_t)G) hrows = (size_t)G;
@@ -152,20 +154,20 @@ __host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int maxEg
     const size_t m = (size_t)BA_MSTRIDE * (size_t)(maxEpose > 0 ? maxEpose : 1);
     if (m > a) a = m;
     if (!fix_points) {
-        const size_t u = (size_t)ucols * (size_t)(ldu + 1), sx = (size_t)BA_SXS * maxEg;
+        const size_t u = (size_t)ucols * (size_t)(ldu + 1), sx = (size_t)BA_SXS * max_pt_edges;  // (edges of one landmark-block pass)
         if (u > a) a = u;
         if (sx > a) a = sx;
     }
     return a;
 }
 __host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int npar, int nfree, int maxEg,
-                                               int maxLg, int fix_points, size_t uarea, int e2_edges) {
-    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar) + (size_t)nlow + 2 * (size_t)nhp + 17 + (size_t)maxEg * 2 +
+                                               int maxLg, int fix_points, size_t uarea, int e2_edges, int panel) {
+    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar, panel) + (size_t)nlow + 2 * (size_t)nhp + 17 + (size_t)maxEg * 2 +
                (size_t)maxLg * 3;
     d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
     if (!fix_points) d += (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3);
     d += uarea + (size_t)e2_edges * BA_E2S;
-    size_t shorts = (size_t)maxEg * 4 + (size_t)maxLg + 1 + (size_t)maxLg * (nfree > 0 ? nfree : 1);
+    size_t shorts = (size_t)maxEg * 5 + (size_t)maxLg + 1 + (size_t)maxLg * (nfree > 0 ? nfree : 1);
     return d * 8 + ((shorts * 2 + 15) & ~(size_t)15) + 64;
 }
 
