@@ -147,7 +147,7 @@ struct BaService {
     hipStream_t resident_stream = nullptr;
     unsigned long long slot_seq[BA_SERVICE_SLOTS] = {0};
     BaJob* slot_job[BA_SERVICE_SLOTS] = {nullptr};
-    int slots_busy = 0, wgs_per_slot = 14;
+    int slots_busy = 0, wgs_per_slot = 13;
     std::atomic<int> q_pending{0};  // queued jobs (lets the scheduler poll without the mutex)
     std::condition_variable cv_slot;
     long long resident_jobs = 0, resident_starts = 0;
@@ -557,13 +557,15 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // matching) cannot finish before it got CUs on EVERY XCD.  A solver workgroup owns its CU, so a window never takes a
     // whole XCD: `ba_xcd_reserve` CUs (default 4 of 32) stay free on each.  Latency mode (default): one window per XCD,
     // up to 28 workgroups for the 5-keyframe window of the benchmark (~330 edges each); throughput mode: two windows per
-    // XCD, up to 14 (~670 edges each), half the CUs per window at some 25 % more time per solve.  Larger windows get more
+    // XCD, up to 13 (~720 edges each, 6 CUs of an XCD left free), half the CUs per window at some 40 % more time per solve.  Larger windows get more
     // workgroups: a range holds at most 1024 edges and must fit the LDS.
     static const int env_reserve = std::getenv("MVO_BA_XCD_RESERVE") ? std::atoi(std::getenv("MVO_BA_XCD_RESERVE")) : -1;
-    const int reserve = env_reserve >= 0 ? env_reserve : g_ba_xcd_reserve;
+    // (measured with 24 sequences in flight: 2 x 14 workgroups per XCD leave the extraction kernels too little -- 3150
+    // frames/s with the shards waiting for extraction --, 2 x 12 make the solves too slow -- 3550 --, 2 x 13 give 3800)
+    const int reserve = env_reserve >= 0 ? env_reserve : (ctx->ba_throughput_mode ? g_ba_xcd_reserve + 2 : g_ba_xcd_reserve);
     const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
     const int g_cap = ctx->ba_throughput_mode ? per_xcd / 2 : per_xcd;
-    service_for(ctx->device).wgs_per_slot = per_xcd / 2;
+    service_for(ctx->device).wgs_per_slot = std::max(service_for(ctx->device).wgs_per_slot, per_xcd / 2);
     int G = 1;
     while (G < g_cap && E > 160 * G) G = std::min(2 * G, g_cap);
     if (g_ba_wgs > 0) G = g_ba_wgs;

@@ -97,11 +97,11 @@ def test_batched_windows_equal_their_single_solves(mvo, simctx):
 
 
 def test_throughput_mode_cuts_the_window_into_fewer_workgroups(mvo, O, simctx):
-    """mvo_ba_set_mode(THROUGHPUT): the benchmarked window on 14 workgroups (two windows per XCD) -- more than 512 edges per range (the second
+    """mvo_ba_set_mode(THROUGHPUT): the benchmarked window on 13 workgroups (two windows per XCD, 6 CUs of it left to other kernels) -- more than 512 edges per range (the second
     edge of a thread keeps its rows in LDS), the Schur operands in two chunks -- still bit for bit the oracle."""
     simctx.ba_set_mode("throughput")
     st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
-    assert plan["wgs"] == 14 and plan["nsplit"] >= 2 and st["iterations"] == 50
+    assert plan["wgs"] == 13 and plan["nsplit"] >= 2 and st["iterations"] == 50
     _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
 
 
