@@ -471,12 +471,13 @@ def main(argv=None, env=None):
         secondary = {}
         if not args.no_secondary and args.ba_mode == "rebuild":
             frames0 = (s0.host_frames, s0.dev_frames)
-            one = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", True, frames=frames0, pool=s0.pool)
+            one = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", True, frames=frames0, pool=s0.pool, ba_cut="latency")
             one.run(max(5, args.warmup))
             nsingle = max(30, args.steps)
             dt = timed_run([one], nsingle, env.sync)
             secondary["single_sequence_fps"] = nsingle / dt
-            secondary["single_sequence_note"] = "1 shard, extraction+matching of frame i+1 overlapped with the BA of frame i (2 ctx)"
+            secondary["single_sequence_note"] = ("1 shard, latency cut of the window (mvo_ba_set_mode LATENCY: 28 workgroups), extraction+matching "
+                                                 "of frame i+1 overlapped with the BA of frame i (2 ctx)")
             st1 = one.state()
             nf = max(1, st1.frame_no)
             secondary["single_sequence_host_us_per_frame"] = {
@@ -485,7 +486,7 @@ def main(argv=None, env=None):
                 "between begin and end, i.e. during the solve), restore = bench scaffolding that puts the window's Frame/MapPoint "
                 "objects back to their initial state, build = buildBundleAdjustmentWindow marshalling, begin = flatten + plan + "
                 "upload + submit, end = wait for the solve + scatter into the objects")
-            one_serial = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", False, frames=frames0, pool=s0.pool)
+            one_serial = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", False, frames=frames0, pool=s0.pool, ba_cut="latency")
             one_serial.run(max(5, args.warmup))
             dt = timed_run([one_serial], nsingle, env.sync)
             secondary["single_sequence_serial_fps"] = nsingle / dt
@@ -609,7 +610,7 @@ def cpu_baseline_threads(args, shard, nthreads):
     O = graft.load_oracle()
     p = O.default_params(max_keypoints=args.max_kp)
     kw = dict(fix_points=args.ba == "pose_only")
-    per_thread = max(4, min(16, args.cpu_frames // 8))
+    per_thread = 4 if nthreads > 32 else max(4, min(16, args.cpu_frames // 8))  # (bounded: a few tens of seconds of wall clock)
     done = []
 
     def work(tid):

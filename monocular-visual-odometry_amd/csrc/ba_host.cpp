@@ -822,7 +822,9 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.lc11 = lc11;
     // Windows for the resident solver service are read by the device straight from this pinned image (the grid is already
     // running: a host-to-device copy into memory it may have cached would not be seen); every other window is uploaded.
-    P.service = g_ba_service && ctx->ba_throughput_mode && !g_ba_profile && !g_ba_block_solver && P.runnable &&
+    // (pose-only windows solve in a fraction of a millisecond: holding CUs resident for them would only take them from
+    // the callers' other kernels -- they keep the launch path)
+    P.service = g_ba_service && ctx->ba_throughput_mode && !p->fix_points && !g_ba_profile && !g_ba_block_solver && P.runnable &&
                 ba_solver_class(n) == 32 && P.slots != 0 && G <= service_for(ctx->device).wgs_per_slot;
     char* I = P.service ? ws.pin : D;  // where the kernel finds the inputs
     B.poses_in = (const double*)(I + P.o_pin);
