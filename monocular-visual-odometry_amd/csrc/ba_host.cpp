@@ -234,7 +234,7 @@ void BaService::run() {
                 posted_or_reaped = true;
             }
             if (resident && (q.empty() || q.front()->ws->plan.service)) {
-                // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 20 ms
+                // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 250 ms
                 if (slots_busy > 0) {
                     // poll WITHOUT the mutex (this thread is the only writer of the slot table): the clients need the mutex
                     // to submit and to wake up -- a scheduler that spins on it starves them
@@ -248,7 +248,7 @@ void BaService::run() {
                     }
                     continue;
                 }
-                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(20), [&] { return !q.empty(); })) stop_resident(lk);
+                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(250), [&] { return !q.empty(); })) stop_resident(lk);
                 continue;
             }
             if (q.empty()) {
