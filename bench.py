@@ -533,6 +533,10 @@ def main(argv=None, env=None):
         secondary["headline_host_us_per_frame"] = {
             k: round(sum(getattr(a, "ns_" + k) - getattr(b, "ns_" + k) for a, b in zip(st_after, st_before)) / nfr / 1e3, 1)
             for k in ("extract", "restore", "build", "begin", "end")}
+        per_shard = [sum(getattr(a, "ns_" + k) - getattr(b, "ns_" + k) for k in ("extract", "restore", "build", "begin", "end")) / 1e6
+                     for a, b in zip(st_after, st_before)]
+        secondary["headline_shard_busy_ms"] = {"min": round(min(per_shard), 1), "mean": round(sum(per_shard) / len(per_shard), 1),
+                                               "max": round(max(per_shard), 1), "timed_region_ms": round(elapsed * 1e3, 1)}
         cpu = None if args.no_cpu_baseline else cpu_baseline(args, shards[0])
         cpu_mt = None
         nthr = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads

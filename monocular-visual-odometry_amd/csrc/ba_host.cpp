@@ -149,6 +149,7 @@ struct BaService {
     BaJob* slot_job[BA_SERVICE_SLOTS] = {nullptr};
     int slots_busy = 0, wgs_per_slot = 13;
     std::atomic<int> q_pending{0};  // queued jobs (lets the scheduler poll without the mutex)
+    bool park_requested = false;    // mvo_synchronize: take an idle resident grid off the device now
     std::condition_variable cv_slot;
     long long resident_jobs = 0, resident_starts = 0;
     int start_resident();
@@ -234,7 +235,7 @@ void BaService::run() {
                 posted_or_reaped = true;
             }
             if (resident && (q.empty() || q.front()->ws->plan.service)) {
-                // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 250 ms
+                // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 3 ms
                 if (slots_busy > 0) {
                     // poll WITHOUT the mutex (this thread is the only writer of the slot table): the clients need the mutex
                     // to submit and to wake up -- a scheduler that spins on it starves them
@@ -248,7 +249,10 @@ void BaService::run() {
                     }
                     continue;
                 }
-                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(250), [&] { return !q.empty(); })) stop_resident(lk);
+                // (a device-wide synchronisation of the caller waits for the grid as well: it must not linger)
+                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(3), [&] { return !q.empty() || park_requested; })) stop_resident(lk);
+                else if (park_requested && q.empty() && slots_busy == 0) stop_resident(lk);
+                park_requested = false;
                 continue;
             }
             if (q.empty()) {
@@ -400,6 +404,7 @@ void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
     (void)hipStreamSynchronize(resident_stream);
     lk.lock();
     resident = false;
+    cv_done.notify_all();
 }
 void BaService::complete() {
     (void)hipSetDevice(device);
@@ -1088,6 +1093,24 @@ void ba_service_times(int device, double* out5) {
     if (!sp) return;
     std::lock_guard<std::mutex> lk(sp->m);
     out5[0] = sp->t_idle, out5[1] = sp->t_batch, out5[2] = sp->t_launch, out5[3] = sp->t_sync, out5[4] = sp->t_post;
+}
+// mvo_synchronize: nothing of this ctx is in flight any more; if the resident grid is idle it leaves right away, so that a
+// device-wide synchronisation issued next by the caller (hipDeviceSynchronize, torch.cuda.synchronize) does not wait for
+// its idle timeout
+void ba_service_park(int device) {
+    if (device < 0 || device >= 16) return;
+    BaService* sp;
+    {
+        std::lock_guard<std::mutex> lk(*g_service_start);
+        sp = g_service[device & 15];
+    }
+    if (!sp) return;
+    std::unique_lock<std::mutex> lk(sp->m);
+    if (!sp->resident) return;
+    sp->park_requested = true;
+    sp->cv_work.notify_all();
+    // wait (bounded) until the grid is gone or has work again
+    sp->cv_done.wait_for(lk, std::chrono::milliseconds(50), [&] { return !sp->resident || sp->slots_busy > 0 || !sp->q.empty(); });
 }
 void ba_resident_stats(int device, long long* windows, long long* grid_starts) {
     if (windows) *windows = 0;

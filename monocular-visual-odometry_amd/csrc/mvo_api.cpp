@@ -111,6 +111,7 @@ const char* mvo_last_error(const mvo_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int mvo_synchronize(mvo_ctx* ctx) {
     if (!ctx) return MVO_ERR_INVALID;
     MVO_HIP(hipStreamSynchronize(ctx->stream));
+    ba_service_park(ctx->device);
     return MVO_OK;
 }
 
