@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
+import test_gpu_ba as gpu_ba_tests
 from test_gpu_ba import _args, _bitwise, _fix
 
 SIM_DIR = os.path.join(ROOT, "tests", "sim")
@@ -216,3 +217,10 @@ def test_resident_solver_service(mvo, O, simlib):
     simlib.mvo_ba_launch_stats(0, C.byref(a), C.byref(b), C.byref(ms), 0)
     assert b.value >= 1 + len(pbs) * 3 + 1 and ms.value > 0
     c0.close()
+
+
+def test_kernel_source_against_the_independent_sequential_oracle(mvo, O, simctx):
+    """The two comparisons of tests/test_gpu_ba.py that do not go through the blocked twin, run on the emulated kernel: the
+    bench window up to gauge (every landmark with >= 2 views within 1e-4) and the converged BA10-shaped window."""
+    gpu_ba_tests.test_bench_window_matches_the_sequential_oracle_up_to_gauge(mvo, O, simctx)
+    gpu_ba_tests.test_ba10_converged_against_the_sequential_oracle(mvo, O, simctx)

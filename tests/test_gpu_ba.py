@@ -122,6 +122,55 @@ def test_full_ba_faithful_gauge_free(mvo, O, ctx, nfix):
     assert np.abs(r - ro).max() < 0.5, np.abs(r - ro).max()      # pixels
 
 
+def gauge_aligned_landmark_error(pb, P, X, Po, Xo):
+    """Similarity-aligns (P, X) onto (Po, Xo) and returns (max relative landmark difference over the landmarks observed from
+    at least two poses, number of those, indices of the single-view landmarks that differ by more than 1e-4, max relative
+    camera-centre difference).  Single-view landmarks have no depth: their position along the ray is only held by the LM
+    damping."""
+    ma, mr = X.mean(0), Xo.mean(0)
+    A, Bm = X - ma, Xo - mr
+    U_, S_, Vt = np.linalg.svd(Bm.T @ A)
+    D = np.eye(3)
+    D[2, 2] = np.sign(np.linalg.det(U_ @ Vt))
+    R = U_ @ D @ Vt
+    sc = (S_ * np.diag(D)).sum() / (A ** 2).sum()
+    t = mr - sc * R @ ma
+    Xa, Ca = sc * X @ R.T + t, sc * P[:, :3, 3] @ R.T + t
+    d = np.linalg.norm(Xa - Xo, axis=1) / np.abs(Xo).max()
+    views = np.zeros(len(Xo), int)
+    for p_, l_ in set(zip(pb["edge_pose"].tolist(), pb["edge_point"].tolist())):
+        views[l_] += 1
+    multi = views >= 2
+    loose_single = np.nonzero((d > 1e-4) & ~multi)[0]
+    return d[multi].max(), int(multi.sum()), loose_single, np.abs(Ca - Po[:, :3, 3]).max() / max(np.abs(Po[:, :3, 3]).max(), 1e-12)
+
+
+def test_bench_window_matches_the_sequential_oracle_up_to_gauge(mvo, O, ctx):
+    """The benchmarked BA5 window (no fixed vertex) against the SEQUENTIAL oracle -- an independent program with another
+    summation order: once the 7-dof gauge is factored out, EVERY landmark with a depth (>= 2 views) agrees within the
+    north-star 1e-4 (measured ~1e-6), and so do the camera centres; the only landmarks beyond it are single-view ones."""
+    pb = mvo.synth.ba_problem(5, 2000, 7)
+    P, X, st = ctx.bundle_adjustment(*_args(pb), fix_points=False)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), fix_points=False)
+    dmax, nmulti, loose, dc = gauge_aligned_landmark_error(pb, P, X, Po, Xo)
+    assert nmulti > 1900 and dmax < 1e-4 and dc < 1e-4, (dmax, nmulti, dc)
+    assert len(loose) < 20
+    assert abs(st["chi2_final"] - sto["chi2_final"]) < 1e-6 * sto["chi2_final"]
+
+
+def test_ba10_converged_against_the_sequential_oracle(mvo, O, ctx):
+    """BA10 shape, anchored, custom information matrix, run until the LM loop stops by itself (50 iterations leave this
+    low-parallax window path-dependent, see test_ba10_and_information_matrix): poses and landmarks of the device and of the
+    sequential oracle then agree far below 1e-4."""
+    pb = mvo.synth.ba_problem(10, 1500, 11, width=1242, height=375, K=mvo.synth.KITTI_K)
+    pb["poses0"][:2] = pb["poses_gt"][:2]
+    kw = dict(fix_points=False, pose_fixed=_fix(10, 2), info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5, max_iterations=1000)
+    P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
+    Po, Xo, sto = O.bundle_adjustment(*_args(pb), **kw)
+    assert st["terminated"] and sto["terminated"], (st, sto)
+    assert np.abs(P - Po).max() < 1e-8 and _rel(X, Xo) < 1e-6, (np.abs(P - Po).max(), _rel(X, Xo))
+
+
 def test_ba10_and_information_matrix(mvo, O, ctx):
     pb = mvo.synth.ba_problem(10, 1500, 11, width=1242, height=375, K=mvo.synth.KITTI_K)
     pb["poses0"][:2] = pb["poses_gt"][:2]

@@ -202,4 +202,40 @@ def test_blocked_and_sequential_oracle_are_the_same_algorithm(O, mvo):
 
     Xa, Ca, Ra = aligned(Xb, Pb, Xs)
     assert np.abs(Ca - Ps[:, :3, 3]).max() < 1e-4 * np.abs(Ps[:, :3, 3]).max() + 1e-5 and np.abs(Ra - Ps[:, :3, :3]).max() < 1e-4
-    assert np.quantile(np.linalg.norm(Xa - Xs, axis=1), 0.99) < 1e-4 * np.abs(Xs).max()
+    # landmarks: the MAXIMUM over every landmark that has a depth at all, i.e. that is observed from at least two poses.  The
+    # excluded ones are listed explicitly: landmarks with ONE observation (parallax 0) -- their position along the viewing
+    # ray is in the null space of the problem (only the LM damping holds it), so two summation orders may leave them
+    # anywhere on that ray; across the ray they agree like the others.
+    d = np.linalg.norm(Xa - Xs, axis=1) / np.abs(Xs).max()
+    views = np.zeros(len(Xs), int)
+    seen = set()
+    for p_, l_ in zip(pb["edge_pose"], pb["edge_point"]):
+        if (p_, l_) not in seen:
+            seen.add((p_, l_))
+            views[l_] += 1
+    multi = views >= 2
+    assert multi.sum() > 1900 and d[multi].max() < 1e-4, (multi.sum(), d[multi].max())
+    single = np.nonzero(~multi & (views == 1))[0]
+    assert set(np.nonzero(d > 1e-4)[0]) <= set(single), "a landmark with parallax differs by more than 1e-4"
+    obs_pose = {l_: p_ for p_, l_ in zip(pb["edge_pose"], pb["edge_point"]) if views[l_] == 1}
+    for l_ in single:
+        ray = Xs[l_] - Ps[obs_pose[l_], :3, 3]
+        ray /= np.linalg.norm(ray)
+        diff = Xa[l_] - Xs[l_]
+        across = np.linalg.norm(diff - (diff @ ray) * ray) / np.abs(Xs).max()
+        assert across < 1e-4, (l_, across)                     # (off the ray they are as tight as everybody else)
+
+
+def test_orders_meet_at_the_optimum_ba10(O, mvo):
+    """BASELINE configs[3] shape, anchored (two poses fixed), custom information matrix: after 50 iterations the landmarks of
+    this low-parallax window are still moving (the two summation orders differ by 2e-4 there, and by 1e-3 after 300 -- one
+    order has stopped by the 10-failed-trials rule, the other has not), so the comparison is made where it is meaningful:
+    both orders run until the LM loop stops by itself and must then agree FAR below the north-star 1e-4."""
+    pb = mvo.synth.ba_problem(10, 1500, 11, width=1242, height=375, K=mvo.synth.KITTI_K)
+    pb["poses0"][:2] = pb["poses_gt"][:2]
+    kw = dict(fix_points=False, pose_fixed=_fix(10, 2), info=(2.0, 0.3, 0.3, 1.5), huber_delta=1.5, max_iterations=1000)
+    plan = dict(wgs=28, nsplit=2, wg_pt_start=np.linspace(0, 1500, 29).astype(np.int32))
+    Ps, Xs, sts = O.bundle_adjustment(*_args(pb), **kw)
+    Pb, Xb, stb, _ = O.bundle_adjustment_blocked(*_args(pb), plan=plan, **kw)
+    assert sts["terminated"] and stb["terminated"] and sts["iterations"] < 1000 and stb["iterations"] < 1000
+    assert np.abs(Pb - Ps).max() < 1e-9 and _rel(Xb, Xs) < 1e-7, (np.abs(Pb - Ps).max(), _rel(Xb, Xs))
