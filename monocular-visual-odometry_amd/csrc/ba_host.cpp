@@ -35,7 +35,8 @@ int g_ba_same_l2 = 1;   // 0 = always write-through hand-offs
 int g_ba_profile = 0;   // 1 = launch the instrumented kernel (per-phase cycle counters)
 int g_ba_cu_share = 0;   // CUs a solver grid may take (0 = all)
 int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
-int g_ba_service = 1;     // 1 = throughput-mode windows of the 5-pose class go to the resident solver service
+int g_ba_service = 1;     // throughput-mode windows of the 5-pose class and the resident solver service: 0 = never, 1 = while the
+                          // offered load fills most of its slots (BaService::wanted), 2 = always
 int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
@@ -152,6 +153,15 @@ struct BaService {
     bool park_requested = false;    // mvo_synchronize: take an idle resident grid off the device now
     std::condition_variable cv_slot;
     long long resident_jobs = 0, resident_starts = 0;
+    // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
+    // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
+    // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
+    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Hysteresis + 20 ms dwell.
+    std::mutex m_demand;
+    std::chrono::steady_clock::time_point sub_t[32], svc_flip{};
+    long long sub_n = 0, svc_flips = 0;
+    bool svc_on = false;
+    bool wanted();
     int start_resident();
     bool reap_locked();
     void stop_resident(std::unique_lock<std::mutex>& lk);
@@ -334,6 +344,27 @@ void BaService::run() {
         }
         cv_flight.notify_all();
     }
+}
+bool BaService::wanted() {
+    if (g_ba_service != 1) return g_ba_service == 2;
+    std::lock_guard<std::mutex> lk(m_demand);
+    const auto now = std::chrono::steady_clock::now();
+    if (sub_n > 0 && now - sub_t[(sub_n - 1) & 31] > std::chrono::milliseconds(50)) {  // demand stopped: start over
+        sub_n = 0;
+        svc_on = false;
+    }
+    sub_t[sub_n++ & 31] = now;
+    if (sub_n >= 32 && now - svc_flip > std::chrono::milliseconds(20)) {
+        const double span = std::chrono::duration<double>(now - sub_t[sub_n & 31]).count();  // (the oldest of the 32)
+        const double load = 31.0 / std::max(span, 1e-6) * 3.8e-3;                           // slots of the grid kept busy
+        const bool want = svc_on ? load > 0.4 * BA_SERVICE_SLOTS : load >= 0.56 * BA_SERVICE_SLOTS;
+        if (want != svc_on) {
+            svc_on = want;
+            svc_flip = now;
+            ++svc_flips;
+        }
+    }
+    return svc_on;
 }
 // finished windows of the resident grid -> their clients (service mutex held); true if any slot was freed
 bool BaService::reap_locked() {
@@ -567,10 +598,17 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     static const int env_reserve = std::getenv("MVO_BA_XCD_RESERVE") ? std::atoi(std::getenv("MVO_BA_XCD_RESERVE")) : -1;
     // (measured with 24 sequences in flight: 2 x 14 workgroups per XCD leave the extraction kernels too little -- 3150
     // frames/s with the shards waiting for extraction --, 2 x 12 make the solves too slow -- 3550 --, 2 x 13 give 3800)
-    const int reserve = env_reserve >= 0 ? env_reserve : (ctx->ba_throughput_mode ? g_ba_xcd_reserve + 2 : g_ba_xcd_reserve);
+    // throughput mode = "many sequences share this GPU".  Windows the resident service can take (full BA, 5-pose class) go
+    // there with the throughput cut while the demand keeps its slots busy; below that they take the launch path with the
+    // latency cut (BaService::wanted).  Other windows of the mode keep the throughput cut on the launch path.
+    bool throughput = ctx->ba_throughput_mode != 0;
+    const bool svc_class = throughput && !p->fix_points && !g_ba_profile && !g_ba_block_solver && P.runnable && ba_solver_class(n) == 32;
+    const bool svc = svc_class && service_for(ctx->device).wanted();
+    if (svc_class && !svc && g_ba_service == 1) throughput = false;
+    const int reserve = env_reserve >= 0 ? env_reserve : (throughput ? g_ba_xcd_reserve + 2 : g_ba_xcd_reserve);
     const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
-    const int g_cap = ctx->ba_throughput_mode ? per_xcd / 2 : per_xcd;
-    service_for(ctx->device).wgs_per_slot = std::max(service_for(ctx->device).wgs_per_slot, per_xcd / 2);
+    const int g_cap = throughput ? per_xcd / 2 : per_xcd;
+    if (throughput) service_for(ctx->device).wgs_per_slot = std::max(service_for(ctx->device).wgs_per_slot, per_xcd / 2);
     int G = 1;
     while (G < g_cap && E > 160 * G) G = std::min(2 * G, g_cap);
     if (g_ba_wgs > 0) G = g_ba_wgs;
@@ -829,8 +867,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // running: a host-to-device copy into memory it may have cached would not be seen); every other window is uploaded.
     // (pose-only windows solve in a fraction of a millisecond: holding CUs resident for them would only take them from
     // the callers' other kernels -- they keep the launch path)
-    P.service = g_ba_service && ctx->ba_throughput_mode && !p->fix_points && !g_ba_profile && !g_ba_block_solver && P.runnable &&
-                ba_solver_class(n) == 32 && P.slots != 0 && G <= service_for(ctx->device).wgs_per_slot;
+    P.service = svc && P.slots != 0 && G <= service_for(ctx->device).wgs_per_slot;
     char* I = P.service ? ws.pin : D;  // where the kernel finds the inputs
     B.poses_in = (const double*)(I + P.o_pin);
     B.poses_out = (double*)(D + P.o_pout);

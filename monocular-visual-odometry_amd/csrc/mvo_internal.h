@@ -95,6 +95,7 @@ MVO_HD inline int pyr_regions(const PyrInfo& P, const ResizeEntry* tabs, int l, 
 // k_fast_harris output: every 64 x 16 tile owns FT_TILE_CAP record slots (3x3 NMS leaves at most one survivor per
 // 2 x 2 pixels: 256 per tile) and one count, in pinned host memory
 #define FT_TILE_CAP 256
+#define FT_ROW_TILES 128  // tiles per tile row the in-kernel ordering handles (images up to 8192 px wide)
 inline size_t orb_detect_counts_bytes(int n_tiles) { return ((size_t)n_tiles * 4 + 63) / 64 * 64; }
 inline size_t orb_detect_host_bytes(int n_tiles) {
     return orb_detect_counts_bytes(n_tiles) + (size_t)n_tiles * FT_TILE_CAP * sizeof(DevCandidate);
@@ -135,6 +136,10 @@ struct mvo_ctx {
     uint8_t *d_raw = nullptr, *d_blur = nullptr;
     size_t pyr_bytes = 0;
     ResizeEntry* d_tabs = nullptr;
+    // k_fast_harris: per-tile record slots + line counts in device memory, arrival counter per tile row (self re-arming)
+    void* d_fh_slots = nullptr;
+    void* d_fh_line = nullptr;
+    int32_t* d_fh_arrive = nullptr;
     std::vector<DevCandidate> last_cand;  // canonical candidate list of the last detection (debug getter)
     DevDescKp* d_kp = nullptr;
     uint8_t* d_desc = nullptr;      // descriptors of the current extraction (one of the two halves below)

@@ -161,6 +161,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
         off = round_up(off + (size_t)L.stride * (L.h + 2 * MVO_BORDER) + 256, 256);
         L.tiles_x = (L.w + 63) / 64;
         L.tiles_y = (L.h + 15) / 16;
+        if (L.tiles_x > FT_ROW_TILES) return mvo_set_err(ctx, MVO_ERR_INVALID, "image too wide", hipSuccess);
         L.tile_off = tiles;
         tiles += L.tiles_x * L.tiles_y;
         L.cell_off = cells;
@@ -179,6 +180,13 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     free_dev(ctx->d_raw);
     free_dev(ctx->d_blur);
     free_dev(ctx->d_tabs);
+    free_dev(ctx->d_fh_slots);
+    free_dev(ctx->d_fh_line);
+    free_dev(ctx->d_fh_arrive);
+    MVO_HIP(hipMalloc((void**)&ctx->d_fh_slots, (size_t)tiles * FT_TILE_CAP * sizeof(DevCandidate)));
+    MVO_HIP(hipMalloc((void**)&ctx->d_fh_line, (size_t)tiles * 16));
+    MVO_HIP(hipMalloc((void**)&ctx->d_fh_arrive, (size_t)tiles * 4));
+    MVO_HIP(hipMemsetAsync(ctx->d_fh_arrive, 0, (size_t)tiles * 4, ctx->stream));
     MVO_HIP(hipMalloc((void**)&ctx->d_raw, bytes));
     MVO_HIP(hipMalloc((void**)&ctx->d_blur, bytes));
     MVO_HIP(hipMemsetAsync(ctx->d_raw, 0, bytes, ctx->stream));
@@ -281,50 +289,32 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     const PyrInfo& P = ctx->pyr;
     ctx->pyr_valid = ctx->blur_valid = false;
     if ((r = orb_launch_pyramid(ctx, d_img, stride, channels, P.nlevels))) return r;
-    // the kernel delivers per-tile survivor counts and finished records into the pinned buffer itself
+    // the kernel delivers per-tile-row counts and ordered record lists into the pinned buffer itself
     if ((r = mvo_ensure_pinned(ctx, orb_detect_host_bytes(P.n_tiles)))) return r;
     if ((r = orb_launch_detect(ctx, ctx->h_pin))) return r;
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
     ht.lap(0);
     MVO_HIP(hipEventSynchronize(ctx->ev));
     ht.lap(1);
-    // canonical order (level, row, column) = the order cv::FAST emits: inside a tile row the tiles interleave line by
-    // line; every tile's slot is row-major already, so one cursor per tile column restores it
+    // canonical order (level, row, column) = the order cv::FAST emits: the kernel delivers every tile row as one ordered
+    // list (at the slot of the row's first tile, its length at that tile's count); the rows are appended in order
     const int32_t* counts = (const int32_t*)ctx->h_pin;
     const DevCandidate* slots = (const DevCandidate*)(ctx->h_pin + orb_detect_counts_bytes(P.n_tiles));
     std::vector<DevCandidate>& all = ctx->last_cand;
     all.clear();
     int level_start[MVO_MAX_LEVELS + 1] = {0};
-    int cursor[512];
     for (int l = 0; l < P.nlevels; ++l) {
         const LevelInfo& L = P.lv[l];
         level_start[l] = (int)all.size();
-        if (L.tiles_x > 512) return mvo_set_err(ctx, MVO_ERR_INVALID, "image too wide", hipSuccess);
         for (int ty = 0; ty < L.tiles_y; ++ty) {
             const int t0 = L.tile_off + ty * L.tiles_x;
-            int left = 0;
-            for (int tx = 0; tx < L.tiles_x; ++tx) {
-                cursor[tx] = 0;
-                left += counts[t0 + tx];
+            // the lists are freshly written by the device: pull the next row's lines in while this one is copied
+            if (ty + 1 < L.tiles_y) {
+                const char* base = (const char*)(slots + (size_t)(t0 + L.tiles_x) * FT_TILE_CAP);
+                for (int b = 0, nb = counts[t0 + L.tiles_x] * (int)sizeof(DevCandidate); b < nb; b += 64) __builtin_prefetch(base + b);
             }
-            // the slots are 4 KB apart and freshly written by the device: pull the next tile row's lines in while this
-            // one is merged (the hardware prefetcher cannot follow the slot pattern)
-            if (ty + 1 < L.tiles_y)
-                for (int tx = 0; tx < L.tiles_x; ++tx) {
-                    const char* base = (const char*)(slots + (size_t)(t0 + L.tiles_x + tx) * FT_TILE_CAP);
-                    for (int b = 0, nb = counts[t0 + L.tiles_x + tx] * (int)sizeof(DevCandidate); b < nb; b += 64)
-                        __builtin_prefetch(base + b);
-                }
-            for (int y = ty * 16; left > 0 && y < ty * 16 + 16; ++y)
-                for (int tx = 0; tx < L.tiles_x; ++tx) {
-                    const DevCandidate* sl = slots + (size_t)(t0 + tx) * FT_TILE_CAP;
-                    const int cnt = counts[t0 + tx];
-                    int& c = cursor[tx];
-                    while (c < cnt && sl[c].y == y) {
-                        all.push_back(sl[c++]);
-                        --left;
-                    }
-                }
+            const DevCandidate* row = slots + (size_t)t0 * FT_TILE_CAP;
+            all.insert(all.end(), row, row + counts[t0]);
         }
     }
     level_start[P.nlevels] = (int)all.size();
@@ -376,8 +366,10 @@ int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int
         hk[i].cx = (int16_t)cv_round(k.x * scale);
         hk[i].cy = (int16_t)cv_round(k.y * scale);
         hk[i].level = k.octave;
-        hk[i].a = (float)std::cos((double)angle);
-        hk[i].b = (float)std::sin((double)angle);
+        double sn, cs;  // one argument reduction for both (glibc: the same bits as sin() and cos())
+        ::sincos((double)angle, &sn, &cs);
+        hk[i].a = (float)cs;
+        hk[i].b = (float)sn;
         const LevelInfo& L = P.lv[k.octave];
         // the tap window must stay inside the 32-px frame
         if (hk[i].cx < -12 || hk[i].cx > L.w + 11 || hk[i].cy < -12 || hk[i].cy > L.h + 11)

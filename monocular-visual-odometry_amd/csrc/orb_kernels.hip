@@ -331,12 +331,17 @@ __device__ __forceinline__ int wave_sum(int v) {
 //   2. the tile's survivors, row-major (= the order cv::FAST emits inside the tile), one WAVE per survivor round-robin:
 //      7x7 Harris response (49 lanes, Sobel sums) and the intensity-centroid angle over the 749-px disc, wave shuffle
 //      reductions -- the same integer sums and float expressions as the stand-alone form had;
-//   3. the finished 16-byte records go straight into the tile's slot of the pinned host buffer, the count beside them.
-// No candidate list is compacted on the device: the global order (level, row, column) interleaves the tiles of a tile
-// row line by line, which the host restores while it copies the ~10^4 records out of the slots (orb_host.cpp) -- a
-// device-wide scan would need a second launch or a serial single-workgroup tail (tried: 40-100 us of exposed latency).
+//   3. the finished 16-byte records go into the tile's slot in device memory, the 16 line counts beside them;
+//   4. the workgroup that arrives LAST for its tile row (arrival counter per row, self re-arming) puts the row in order:
+//      the global order (level, row, column) = the order cv::FAST emits interleaves the tiles of a tile row line by line
+//      -- an exclusive scan over (line, tile) of the line counts gives every record its place -- and writes the row as ONE
+//      contiguous list into the pinned host buffer, its length beside it.  The host appends ~100 row lists per frame
+//      (orb_host.cpp) instead of walking 64000 (line, tile) cursors; rows do not wait for each other (a device-wide scan
+//      would need a second launch or a serial single-workgroup tail: tried, 40-100 us of exposed latency).
 __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__ raw, PyrInfo P, int thr,
-                                                     int32_t* __restrict__ tile_count, DevCandidate* __restrict__ slots) {
+                                                     int32_t* __restrict__ row_count, DevCandidate* __restrict__ rows,
+                                                     u64* __restrict__ dslots, u64* __restrict__ dline,
+                                                     int32_t* __restrict__ arrive) {
     __shared__ uint32_t pix[FT_PH * (FT_PW / 4)];
     __shared__ uint8_t sc[FT_SH * 68];
     __shared__ u64 rowmask[FT_H];
@@ -390,14 +395,16 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
             if (lane >= o) inc += u;
         }
         if (tid < FT_H) rowstart[tid] = inc - cnt;
-        if (tid == FT_H - 1) {
-            rowstart[FT_H] = inc;
-            tile_count[blockIdx.x] = inc;
-        }
+        if (tid == FT_H - 1) rowstart[FT_H] = inc;
+        // the 16 line counts (<= 64 each) as bytes: two words, written through to where the row's last workgroup reads them
+        u64 packed = (u64)(tid < FT_H ? cnt : 0) << (8 * (tid & 7));
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) packed |= (u64)__shfl_xor((long long)packed, o);
+        if (tid == 0 || tid == 8) __hip_atomic_store(dline + 2 * (size_t)blockIdx.x + (tid >> 3), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     const int total = rowstart[FT_H];
-    DevCandidate* out = slots + (size_t)blockIdx.x * FT_TILE_CAP;
+    u64* out = dslots + (size_t)blockIdx.x * FT_TILE_CAP * 2;
     const int step = L.stride;
     const int ndisc = c_disc_n;
     // this lane's pixels of the intensity-centroid disc (k = lane, lane + 64, ...): offsets and (u, v) once per workgroup,
@@ -457,8 +464,98 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
             cd.level_score = (lvl << 16) | sc[(r + 1) * 68 + (lx + 1)];
             cd.harris = (fa * fb - fc * fc - 0.04f * (fa + fb) * (fa + fb)) * scale_sq_sq;
             cd.angle = fast_atan2_deg((float)m01, (float)m10);
-            out[i] = cd;
+            static_assert(sizeof(DevCandidate) == 16, "record = two 64-bit words");
+            u64 w[2];
+            __builtin_memcpy(w, &cd, 16);
+            __hip_atomic_store(out + 2 * i, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(out + 2 * i + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    // ---- 4. the tile row's last workgroup orders the row
+    __shared__ int s_last;
+    __shared__ int s_off[FT_H * FT_ROW_TILES];          // exclusive scan over (line, tile)
+    __shared__ uint16_t s_tstart[FT_ROW_TILES][FT_H + 1];  // line starts inside every tile
+    __shared__ int s_tpre[FT_ROW_TILES + 1];            // records before tile tx in (tile, slot) enumeration
+    __shared__ int s_wsum[4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int t0 = L.tile_off + ty * L.tiles_x;  // first tile of the row: names the row
+    if (tid == 0) {
+        const int last = __hip_atomic_fetch_add(arrive + t0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == L.tiles_x - 1;
+        if (last) __hip_atomic_store(arrive + t0, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    const int ntx = L.tiles_x;
+    for (int q = tid; q < ntx; q += 256) {
+        const u64 a = __hip_atomic_load(dline + 2 * (size_t)(t0 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 b = __hip_atomic_load(dline + 2 * (size_t)(t0 + q) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int acc = 0;
+#pragma unroll
+        for (int y = 0; y < FT_H; ++y) {
+            s_tstart[q][y] = (uint16_t)acc;
+            acc += (int)(((y < 8 ? a : b) >> (8 * (y & 7))) & 0xff);
+        }
+        s_tstart[q][FT_H] = (uint16_t)acc;
+    }
+    __syncthreads();
+    {   // exclusive scan of cnt(line y, tile q) in (y, q) order and of the tile totals: 8 consecutive entries per thread
+        const int nent = FT_H * ntx;
+        int v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = 8 * tid + k;
+            const int y = e / ntx, q = e - y * ntx;
+            v[k] = e < nent ? (int)s_tstart[q][y + 1] - (int)s_tstart[q][y] : 0;
+            sum += v[k];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int w2 = 0; w2 < wave; ++w2) run += s_wsum[w2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int e = 8 * tid + k;
+            if (e < nent) s_off[e] = run;
+            run += v[k];
+        }
+        if (tid == 0) {
+            int acc = 0;
+            for (int q = 0; q < ntx; ++q) {
+                s_tpre[q] = acc;
+                acc += s_tstart[q][FT_H];
+            }
+            s_tpre[ntx] = acc;
+            row_count[t0] = acc;
+        }
+    }
+    __syncthreads();
+    const int row_total = s_tpre[ntx];
+    u64* dst = reinterpret_cast<u64*>(rows + (size_t)t0 * FT_TILE_CAP);
+    for (int k = tid; k < row_total; k += 256) {
+        int lo = 0, hi = ntx;  // tile q with s_tpre[q] <= k < s_tpre[q + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_tpre[mid] <= k) lo = mid; else hi = mid;
+        }
+        const int q = lo, c = k - s_tpre[q];
+        int y = 0;
+#pragma unroll
+        for (int yy = 1; yy < FT_H; ++yy)
+            if (c >= (int)s_tstart[q][yy]) y = yy;
+        const int d = s_off[y * ntx + q] + c - (int)s_tstart[q][y];
+        const u64* src = dslots + ((size_t)(t0 + q) * FT_TILE_CAP + c) * 2;
+        const u64 w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dst[2 * d] = w0;
+        dst[2 * d + 1] = w1;
     }
 }
 
@@ -692,7 +789,7 @@ int orb_launch_detect(mvo_ctx* ctx, uint8_t* host) {
     DevCandidate* slots = reinterpret_cast<DevCandidate*>(host + orb_detect_counts_bytes(P.n_tiles));
     ProfScope ps(ctx, "k_fast_harris");
     hipLaunchKernelGGL(k_fast_harris, dim3(P.n_tiles), dim3(256), 0, ctx->stream, ctx->d_raw, P, ctx->orb.fast_threshold,
-                       counts, slots);
+                       counts, slots, (u64*)ctx->d_fh_slots, (u64*)ctx->d_fh_line, ctx->d_fh_arrive);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

@@ -97,13 +97,21 @@ def test_batched_windows_equal_their_single_solves(mvo, simctx):
         assert np.array_equal(P, Pb) and np.array_equal(X, Xb) and st["trials"] == stb["trials"]
 
 
-def test_throughput_mode_cuts_the_window_into_fewer_workgroups(mvo, O, simctx):
-    """mvo_ba_set_mode(THROUGHPUT): the benchmarked window on 13 workgroups (two windows per XCD, 6 CUs of it left to other kernels) -- more than 512 edges per range (the second
-    edge of a thread keeps its rows in LDS), the Schur operands in two chunks -- still bit for bit the oracle."""
+def test_throughput_mode_cuts_the_window_into_fewer_workgroups(mvo, O, simctx, simlib):
+    """mvo_ba_set_mode(THROUGHPUT) under load (forced here: ba_service = 2): the benchmarked window on 13 workgroups (two
+    windows per XCD, 6 CUs of it left to other kernels) -- more than 512 edges per range (the second edge of a thread keeps
+    its rows in LDS), the Schur operands in two chunks -- still bit for bit the oracle.  Without load (the default policy,
+    ba_service = 1, a lone caller) the same mode keeps the latency cut on the launch path."""
     simctx.ba_set_mode("throughput")
-    st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
-    assert plan["wgs"] == 13 and plan["nsplit"] >= 2 and st["iterations"] == 50
-    _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
+    simlib.mvo_debug_set(b"ba_service", 2)
+    try:
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
+        assert plan["wgs"] == 13 and plan["nsplit"] >= 2 and st["iterations"] == 50
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True)
+    finally:
+        simlib.mvo_debug_set(b"ba_service", 1)
+    st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=3)
+    assert plan["wgs"] == 28
 
 
 @pytest.mark.parametrize("block", [0, 1])
@@ -188,6 +196,7 @@ def test_resident_solver_service(mvo, O, simlib):
     a, b = C.c_longlong(), C.c_longlong()
     ms = C.c_double()
     simlib.mvo_ba_launch_stats(0, C.byref(a), C.byref(b), C.byref(ms), 1)
+    simlib.mvo_debug_set(b"ba_service", 2)      # (the default policy only brings the grid up under load)
     pbs = [mvo.synth.ba_problem(4, 500 + 60 * k, 70 + k) for k in range(5)]
     c0 = Ctx()
     c0.ba_set_mode("throughput")
@@ -217,6 +226,7 @@ def test_resident_solver_service(mvo, O, simlib):
     simlib.mvo_ba_launch_stats(0, C.byref(a), C.byref(b), C.byref(ms), 0)
     assert b.value >= 1 + len(pbs) * 3 + 1 and ms.value > 0
     c0.close()
+    simlib.mvo_debug_set(b"ba_service", 1)
 
 
 def test_kernel_source_against_the_independent_sequential_oracle(mvo, O, simctx):

@@ -49,3 +49,51 @@ def test_concurrent_contexts_reproduce_the_serial_results(mvo):
     for s in range(n_threads):
         for r in range(rounds):
             assert results[s][r] == expected[s], "thread %d round %d differs from the lone-ctx result" % (s, r)
+
+
+def test_throughput_mode_follows_the_load(mvo):
+    """mvo_ba_set_mode(THROUGHPUT) = "many sequences share this GPU": a lone caller's windows keep the launch path and the
+    latency cut (the resident grid would hold 2 x 13 CUs of every XCD for nothing); 24 callers submitting back to back
+    bring the resident solver service up, and their windows move to its slots.  Whatever the route, a result equals one of
+    the two cuts' results bit for bit."""
+    pb = mvo.synth.ba_problem(5, 2000, 7)
+    args = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+    ref = mvo.Context(0)
+    lat = ref.bundle_adjustment(*args, fix_points=False)
+    assert ref.ba_plan()["wgs"] == 28
+    ref.ba_set_mode("throughput")
+    mvo.debug_set("ba_service", 2)
+    try:
+        svc = ref.bundle_adjustment(*args, fix_points=False)
+        assert ref.ba_plan()["wgs"] == 13
+    finally:
+        mvo.debug_set("ba_service", 1)
+    ref.synchronize()
+    ref.ba_launch_stats(reset=True)
+    lone = ref.bundle_adjustment(*args, fix_points=False)                       # default policy, no load
+    assert ref.ba_plan()["wgs"] == 28 and lone[0].tobytes() == lat[0].tobytes()
+    assert ref.ba_launch_stats()["resident_windows"] == 0
+    ok = {(r[0].tobytes(), r[1].tobytes()) for r in (lat, svc)}
+    errors, routes = [], []
+
+    def worker(k):
+        try:
+            c = mvo.Context(0)
+            c.ba_set_mode("throughput")
+            for _ in range(40):
+                P, X, st = c.bundle_adjustment(*args, fix_points=False)
+                assert (P.tobytes(), X.tobytes()) in ok
+                routes.append(c.ba_plan()["wgs"])
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(24)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    stats = ref.ba_launch_stats()
+    assert stats["resident_windows"] > 200 and routes.count(13) > 200, (stats, routes.count(13), routes.count(28))
+    ref.close()

@@ -10,7 +10,7 @@ img = mvo.synth.small_test_image(1, 640, 480)
 errs = []
 def work(k):
     try:
-        c = mvo.Context(0); c.ba_set_mode("throughput")
+        c = mvo.Context(0); c.ba_set_mode("throughput"); mvo.debug_set("ba_service", 2)
         ce = mvo.Context(0, max_keypoints=2000) if with_extract else None
         for r in range(reps):
             pb = pbs[(k + r) % len(pbs)]
