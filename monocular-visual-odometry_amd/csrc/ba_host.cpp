@@ -349,10 +349,9 @@ bool BaService::wanted() {
     if (g_ba_service != 1) return g_ba_service == 2;
     std::lock_guard<std::mutex> lk(m_demand);
     const auto now = std::chrono::steady_clock::now();
-    if (sub_n > 0 && now - sub_t[(sub_n - 1) & 31] > std::chrono::milliseconds(50)) {  // demand stopped: start over
-        sub_n = 0;
-        svc_on = false;
-    }
+    // a pause of the callers (a barrier, a synchronisation, the end of a run) is not low demand: the estimate starts over,
+    // the decision stands
+    if (sub_n > 0 && now - sub_t[(sub_n - 1) & 31] > std::chrono::milliseconds(10)) sub_n = 0;
     sub_t[sub_n++ & 31] = now;
     if (sub_n >= 32 && now - svc_flip > std::chrono::milliseconds(20)) {
         const double span = std::chrono::duration<double>(now - sub_t[sub_n & 31]).count();  // (the oldest of the 32)

@@ -70,8 +70,10 @@ PW_FN bool jacobi_cs(double a, double b, double p, double* c, double* s) {
 // ---------------------------------------------------------------------------------------------------------
 // Wave-uniform one-sided Jacobi SVD of a small matrix held in registers.  At: N rows of length M = the columns
 // of the matrix.  On exit row i = sigma_i u_i, Vt row i = v_i, W descending (stable for equal values).
+// `ls` (optional): N * (M + N) doubles of LDS private to the calling wave -- the final ordering then goes through it
+// (a permuted store and an ordered load) instead of through a second register copy of both matrices.
 template <int N, int M>
-PW_FN void svd_small(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N]) {
+PW_FN void svd_small(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N], double* ls = nullptr) {
     PW_UNROLL
     for (int i = 0; i < N; i++) {
         PW_UNROLL
@@ -112,6 +114,44 @@ PW_FN void svd_small(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N]) {
         }
         if (!changed) break;
     }
+    if (ls) {
+        double W0[N];
+        int rank[N];
+        PW_UNROLL
+        for (int i = 0; i < N; i++) {
+            double sd = 0;
+            PW_UNROLL
+            for (int k = 0; k < M; k++) sd += At[i][k] * At[i][k];
+            W0[i] = sqrt(sd);
+            W[i] = W0[i];
+        }
+        PW_UNROLL
+        for (int i = 0; i < N; i++) {
+            int r = 0;
+            PW_UNROLL
+            for (int j = 0; j < N; j++) r += (W0[j] > W0[i]) || (W0[j] == W0[i] && j < i);
+            rank[i] = r;
+        }
+        PW_UNROLL
+        for (int i = 0; i < N; i++) {
+            double* row = ls + rank[i] * (M + N);
+            PW_UNROLL
+            for (int k = 0; k < M; k++) row[k] = At[i][k];
+            PW_UNROLL
+            for (int k = 0; k < N; k++) row[M + k] = Vt[i][k];
+        }
+        PW_UNROLL
+        for (int p = 0; p < N; p++) {
+            PW_UNROLL
+            for (int i = 0; i < N; i++) W[p] = rank[i] == p ? W0[i] : W[p];
+            const double* row = ls + p * (M + N);
+            PW_UNROLL
+            for (int k = 0; k < M; k++) At[p][k] = row[k];
+            PW_UNROLL
+            for (int k = 0; k < N; k++) Vt[p][k] = row[M + k];
+        }
+        return;
+    }
     double W0[N], A0[N][M], V0[N][N];
     int rank[N];
     PW_UNROLL
@@ -149,14 +189,14 @@ PW_FN void svd_small(double (&At)[N][M], double (&Vt)[N][N], double (&W)[N]) {
 
 // cv::solve / cvInvert with DECOMP_SVD: X (N x NB) = pinv(A (M x N)) B (M x NB), wave-uniform.
 template <int M, int N, int NB>
-PW_FN void svd_solve_small(const double (&A)[M][N], const double (&B)[M][NB], double (&X)[N][NB]) {
+PW_FN void svd_solve_small(const double (&A)[M][N], const double (&B)[M][NB], double (&X)[N][NB], double* ls = nullptr) {
     double At[N][M], Vt[N][N], W[N];
     PW_UNROLL
     for (int i = 0; i < N; i++) {
         PW_UNROLL
         for (int k = 0; k < M; k++) At[i][k] = A[k][i];
     }
-    svd_small<N, M>(At, Vt, W);
+    svd_small<N, M>(At, Vt, W, ls);
     double thr = 0;
     PW_UNROLL
     for (int i = 0; i < N; i++) {
@@ -359,13 +399,26 @@ struct Camera {
     double fu, fv, uc, vc;
 };
 
+struct EpnpPoints {
+    double pws[kModelPoints][3];
+    double us[kModelPoints][2];
+    double alphas[kModelPoints][4];
+    double cws[4][3];
+};
+
 struct HypLds {
+    // operands every lane reads (uniform addresses = LDS broadcasts) instead of carrying private copies: the 6 x 10 system,
+    // the four null-space vectors and the 5 points with their control points -- ~330 registers per lane otherwise
+    EpnpPoints e;
+    double l6[6][10];
+    double v4[4][12];
+    double rho[6];
+    double sort_ls[3][5 * 11];  // per beta variant (= per wave): staging of svd_small's final ordering
     double At[144];  // M^T M, then the rotated rows
     double Vt[144];  // accumulated rotations = eigenvectors of M^T M
     double M[2 * kModelPoints * 12];
     double alphas[kModelPoints * 4];
     double us[kModelPoints * 2];
-    double l6x10[60];
     double var_err[3];  // per beta variant: mean reprojection error, R, t
     double var_R[3][9];
     double var_t[3][3];
@@ -442,7 +495,7 @@ PW_FN void qr_solve_6x4(double (&A)[6][4], double (&b)[6], double (&X)[4]) {
 }
 
 template <int NC>
-PW_FN void solve_betas_system(const double (&l)[6][10], const double (&rho)[6], const int (&cols)[NC], double (&b)[NC]) {
+PW_FN void solve_betas_system(const double (&l)[6][10], const double (&rho)[6], const int (&cols)[NC], double (&b)[NC], double* ls) {
     double L[6][NC], rhs[6][1], x[NC][1];
     PW_UNROLL
     for (int i = 0; i < 6; i++) {
@@ -450,16 +503,16 @@ PW_FN void solve_betas_system(const double (&l)[6][10], const double (&rho)[6], 
         for (int k = 0; k < NC; k++) L[i][k] = l[i][cols[k]];
         rhs[i][0] = rho[i];
     }
-    svd_solve_small<6, NC, 1>(L, rhs, x);
+    svd_solve_small<6, NC, 1>(L, rhs, x, ls);
     PW_UNROLL
     for (int k = 0; k < NC; k++) b[k] = x[k][0];
 }
 
-PW_FN void find_betas(const double (&l)[6][10], const double (&rho)[6], int variant, double (&betas)[4]) {
+PW_FN void find_betas(const double (&l)[6][10], const double (&rho)[6], int variant, double (&betas)[4], double* ls) {
     if (variant == 1) {  // [B11 B12 B13 B14]
         const int cols[4] = {0, 1, 3, 6};
         double b[4];
-        solve_betas_system<4>(l, rho, cols, b);
+        solve_betas_system<4>(l, rho, cols, b, ls);
         if (b[0] < 0) {
             betas[0] = sqrt(-b[0]);
             betas[1] = -b[1] / betas[0];
@@ -477,14 +530,14 @@ PW_FN void find_betas(const double (&l)[6][10], const double (&rho)[6], int vari
     if (variant == 2) {  // [B11 B12 B22]
         const int cols[3] = {0, 1, 2};
         double b[3];
-        solve_betas_system<3>(l, rho, cols, b);
+        solve_betas_system<3>(l, rho, cols, b, ls);
         b0 = b[0];
         b1 = b[1];
         b2 = b[2];
     } else {  // [B11 B12 B22 B13 B23]
         const int cols[5] = {0, 1, 2, 3, 4};
         double b[5];
-        solve_betas_system<5>(l, rho, cols, b);
+        solve_betas_system<5>(l, rho, cols, b, ls);
         b0 = b[0];
         b1 = b[1];
         b2 = b[2];
@@ -522,13 +575,6 @@ PW_FN void gauss_newton(const double (&l)[6][10], const double (&rho)[6], double
         for (int i = 0; i < 4; i++) betas[i] += x[i];
     }
 }
-
-struct EpnpPoints {
-    double pws[kModelPoints][3];
-    double us[kModelPoints][2];
-    double alphas[kModelPoints][4];
-    double cws[4][3];
-};
 
 // epnp::compute_R_and_t: control points in the camera frame from the betas, Arun alignment, mean reprojection
 // error.  v[i] = eigenvector of the (i+1)-th smallest eigenvalue.
@@ -680,13 +726,18 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
             a[0] = 1.0f - a[1] - a[2] - a[3];
         }
     }
-    // M (2n x 12) and M^T M through LDS, one entry per lane and pass
-    PW_UNROLL
-    for (int i = 0; i < n; i++) {
-        PW_UNROLL
-        for (int k = 0; k < 4; k++) s.alphas[4 * i + k] = e.alphas[i][k];
-        s.us[2 * i] = e.us[i][0];
-        s.us[2 * i + 1] = e.us[i][1];
+    // M (2n x 12) and M^T M through LDS, one entry per lane and pass; the points themselves stay in LDS from here on
+    PW_LANES(l, kHypLanes) {
+        if (l == 0) {
+            s.e = e;
+            PW_UNROLL
+            for (int i = 0; i < n; i++) {
+                PW_UNROLL
+                for (int k = 0; k < 4; k++) s.alphas[4 * i + k] = e.alphas[i][k];
+                s.us[2 * i] = e.us[i][0];
+                s.us[2 * i + 1] = e.us[i][1];
+            }
+        }
     }
     PW_SYNC();
     PW_LANES(l, kHypLanes) {
@@ -726,36 +777,27 @@ PW_FN void epnp_hypothesis(HypLds& s, const float* p3, const float* p2, const in
                 dy[k] = vy[3 * pa[i] + k] - vy[3 * pb[i] + k];
             }
             const double d = dot3(dx, dy);
-            s.l6x10[l] = xs[c] == ys[c] ? d : 2.0f * d;
+            s.l6[i][c] = xs[c] == ys[c] ? d : 2.0f * d;
+        } else if (l >= 64 && l < 64 + 48) {  // the four eigenvectors of the smallest eigenvalues
+            const int i = (l - 64) / 12, k = (l - 64) % 12;
+            s.v4[i][k] = s.Vt[12 * s.js.perm[11 - i] + k];
+        } else if (l >= 128 && l < 128 + 6) {
+            const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+            s.rho[l - 128] = dist2(s.e.cws[pa[l - 128]], s.e.cws[pb[l - 128]]);
         }
     }
     PW_SYNC();
-    double l6[6][10], rho[6], v[4][12];
-    PW_UNROLL
-    for (int i = 0; i < 6; i++) {
-        PW_UNROLL
-        for (int c = 0; c < 10; c++) l6[i][c] = s.l6x10[10 * i + c];
-    }
-    PW_UNROLL
-    for (int i = 0; i < 4; i++) {
-        const double* src = s.Vt + 12 * s.js.perm[11 - i];
-        PW_UNROLL
-        for (int k = 0; k < 12; k++) v[i][k] = src[k];
-    }
-    rho[0] = dist2(e.cws[0], e.cws[1]);
-    rho[1] = dist2(e.cws[0], e.cws[2]);
-    rho[2] = dist2(e.cws[0], e.cws[3]);
-    rho[3] = dist2(e.cws[1], e.cws[2]);
-    rho[4] = dist2(e.cws[1], e.cws[3]);
-    rho[5] = dist2(e.cws[2], e.cws[3]);
+    const double(&l6)[6][10] = s.l6;
+    const double(&v)[4][12] = s.v4;
+    const double(&rho)[6] = s.rho;
     // the three beta initialisations (epnp::find_betas_approx_1/2/3 + Gauss-Newton + compute_R_and_t) are
     // independent: wave w takes variant w + 1
     PW_WAVES(w, kHypLanes / kWave) {
         for (int variant = 1 + w; variant <= 3; variant += kHypLanes / kWave) {
             double betas[4], R[3][3], t[3];
-            find_betas(l6, rho, variant, betas);
+            find_betas(l6, rho, variant, betas, s.sort_ls[variant - 1]);
             gauss_newton(l6, rho, betas);
-            s.var_err[variant - 1] = compute_R_and_t(e, cam, v, betas, R, t);
+            s.var_err[variant - 1] = compute_R_and_t(s.e, cam, v, betas, R, t);
             PW_UNROLL
             for (int i = 0; i < 3; i++) {
                 PW_UNROLL

@@ -43,7 +43,7 @@ int sim_epnp_debug(const float* p3, const float* p2, const int32_t* idx, const d
     double R[3][3], t[3];
     pw::epnp_hypothesis(lds, p3, p2, idx, cam, R, t);
     for (int p = 0; p < 12; p++) memcpy(ut + 12 * p, lds.Vt + 12 * lds.js.perm[p], 12 * sizeof(double));
-    memcpy(l6x10, lds.l6x10, sizeof(lds.l6x10));
+    memcpy(l6x10, lds.l6, sizeof(lds.l6));
     for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++) Rt[3 * i + j] = R[i][j];
         Rt[9 + i] = t[i];

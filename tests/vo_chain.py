@@ -202,7 +202,8 @@ class OracleChain:
         m = O.match_features(ref.desc, fr.desc, 1, 2.0, 1.0, ref.xy, fr.xy, 100.0)
         a, b = ref.xy[m["queryIdx"]], fr.xy[m["trainIdx"]]
         inl = O.find_essential_inliers(a, b, K, 0.999, 1.0)["inliers"]
-        mi = m[inl]
+        mi = m[inl].copy()
+        mi["imgIdx"] = -1                                       # cv::DMatch(queryIdx, trainIdx, distance), motion_estimation.cpp:174-179
         T = self.motion_from_1_to_2(O, fr, ref)
         _, p_cur = O.triangulate_points(a[inl], b[inl], K, T[:3, :3], T[:3, 3])
         keep, _ = O.retain_good_triangulation(p_cur, fr.T, ref.T, 1.0, 20.0)
