@@ -147,11 +147,18 @@ typedef struct {
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317; caller VisualOdometry::callBundleAdjustment_,
  * src/vo/vo.cpp:458-462). */
 int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
-/* How a window is cut into workgroups (no reference counterpart: g2o is single-threaded).  LATENCY (default): about 300
- * observations per workgroup -- the 5-keyframe window of the benchmark runs on the 32 CUs of one XCD, shortest solve.
- * THROUGHPUT: about 600 per workgroup -- half the CUs per window at ~15 % more time per solve, for callers that keep many
- * sequences in flight on one GPU.  The summation order (hence the last bits of the result) follows the cut; every cut is
- * deterministic and is what mvo_debug_get_ba_plan reports. */
+/* How this ctx shares the GPU (no reference counterpart: g2o and cv::ORB are single-threaded).
+ * LATENCY (default): one sequence wants its frame back as fast as possible -- a window is cut into ~300 observations per
+ * workgroup (the 5-keyframe window of the benchmark: 28 CUs of one XCD, shortest solve) and solved by a launch of its own;
+ * the detection kernel also puts its candidates in order on the device.
+ * THROUGHPUT: many sequences are in flight on this GPU -- CU time counts, not latency.  While the offered load keeps it
+ * busy (submission rate x solve time >= 9 of its 16 slots; hysteresis), 5-keyframe windows are cut into ~700 observations
+ * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
+ * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
+ * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
+ * calling thread (~75 us of host time per frame instead of ~8 us of kernel time).
+ * The summation order of a solve (hence the last bits of its result) follows the cut; every cut is deterministic and is what
+ * mvo_debug_get_ba_plan reports.  Results of the extraction do not depend on the mode. */
 #define MVO_BA_MODE_LATENCY 0
 #define MVO_BA_MODE_THROUGHPUT 1
 int mvo_ba_set_mode(mvo_ctx* ctx, int mode);

@@ -198,7 +198,7 @@ int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes);
 
 // orb_kernels.hip
 int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int channels, int nlevels);
-int orb_launch_detect(mvo_ctx* ctx, uint8_t* host);
+int orb_launch_detect(mvo_ctx* ctx, uint8_t* host, bool ordered);
 int orb_launch_blur(mvo_ctx* ctx, int nlevels);
 int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps, uint8_t* desc_host);
 // match_kernels.hip

@@ -291,30 +291,69 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     if ((r = orb_launch_pyramid(ctx, d_img, stride, channels, P.nlevels))) return r;
     // the kernel delivers per-tile-row counts and ordered record lists into the pinned buffer itself
     if ((r = mvo_ensure_pinned(ctx, orb_detect_host_bytes(P.n_tiles)))) return r;
-    if ((r = orb_launch_detect(ctx, ctx->h_pin))) return r;
+    // a ctx in throughput mode (many sequences share the GPU) leaves the ordering of a tile row to this thread: the GPU time
+    // of the ordering step (~8 us of kernel tail) is worth more there than ~75 us of a host thread that has company
+    const bool ordered = !ctx->ba_throughput_mode;
+    if ((r = orb_launch_detect(ctx, ctx->h_pin, ordered))) return r;
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
     ht.lap(0);
     MVO_HIP(hipEventSynchronize(ctx->ev));
     ht.lap(1);
-    // canonical order (level, row, column) = the order cv::FAST emits: the kernel delivers every tile row as one ordered
-    // list (at the slot of the row's first tile, its length at that tile's count); the rows are appended in order
     const int32_t* counts = (const int32_t*)ctx->h_pin;
     const DevCandidate* slots = (const DevCandidate*)(ctx->h_pin + orb_detect_counts_bytes(P.n_tiles));
     std::vector<DevCandidate>& all = ctx->last_cand;
     all.clear();
     int level_start[MVO_MAX_LEVELS + 1] = {0};
-    for (int l = 0; l < P.nlevels; ++l) {
-        const LevelInfo& L = P.lv[l];
-        level_start[l] = (int)all.size();
-        for (int ty = 0; ty < L.tiles_y; ++ty) {
-            const int t0 = L.tile_off + ty * L.tiles_x;
-            // the lists are freshly written by the device: pull the next row's lines in while this one is copied
-            if (ty + 1 < L.tiles_y) {
-                const char* base = (const char*)(slots + (size_t)(t0 + L.tiles_x) * FT_TILE_CAP);
-                for (int b = 0, nb = counts[t0 + L.tiles_x] * (int)sizeof(DevCandidate); b < nb; b += 64) __builtin_prefetch(base + b);
+    if (ordered) {
+        // canonical order (level, row, column) = the order cv::FAST emits: the kernel delivers every tile row as one ordered
+        // list (at the slot of the row's first tile, its length at that tile's count); the rows are appended in order
+        for (int l = 0; l < P.nlevels; ++l) {
+            const LevelInfo& L = P.lv[l];
+            level_start[l] = (int)all.size();
+            for (int ty = 0; ty < L.tiles_y; ++ty) {
+                const int t0 = L.tile_off + ty * L.tiles_x;
+                // the lists are freshly written by the device: pull the next row's lines in while this one is copied
+                if (ty + 1 < L.tiles_y) {
+                    const char* base = (const char*)(slots + (size_t)(t0 + L.tiles_x) * FT_TILE_CAP);
+                    for (int b = 0, nb = counts[t0 + L.tiles_x] * (int)sizeof(DevCandidate); b < nb; b += 64) __builtin_prefetch(base + b);
+                }
+                const DevCandidate* row = slots + (size_t)t0 * FT_TILE_CAP;
+                all.insert(all.end(), row, row + counts[t0]);
             }
-            const DevCandidate* row = slots + (size_t)t0 * FT_TILE_CAP;
-            all.insert(all.end(), row, row + counts[t0]);
+        }
+    } else {
+        int cursor[FT_ROW_TILES];
+        // canonical order (level, row, column) = the order cv::FAST emits: inside a tile row the tiles interleave line by
+        // line; every tile's slot is row-major already, so one cursor per tile column restores it
+        for (int l = 0; l < P.nlevels; ++l) {
+            const LevelInfo& L = P.lv[l];
+            level_start[l] = (int)all.size();
+            for (int ty = 0; ty < L.tiles_y; ++ty) {
+                const int t0 = L.tile_off + ty * L.tiles_x;
+                int left = 0;
+                for (int tx = 0; tx < L.tiles_x; ++tx) {
+                    cursor[tx] = 0;
+                    left += counts[t0 + tx];
+                }
+                // the slots are 4 KB apart and freshly written by the device: pull the next tile row's lines in while this
+                // one is merged (the hardware prefetcher cannot follow the slot pattern)
+                if (ty + 1 < L.tiles_y)
+                    for (int tx = 0; tx < L.tiles_x; ++tx) {
+                        const char* base = (const char*)(slots + (size_t)(t0 + L.tiles_x + tx) * FT_TILE_CAP);
+                        for (int b = 0, nb = counts[t0 + L.tiles_x + tx] * (int)sizeof(DevCandidate); b < nb; b += 64)
+                            __builtin_prefetch(base + b);
+                    }
+                for (int y = ty * 16; left > 0 && y < ty * 16 + 16; ++y)
+                    for (int tx = 0; tx < L.tiles_x; ++tx) {
+                        const DevCandidate* sl = slots + (size_t)(t0 + tx) * FT_TILE_CAP;
+                        const int cnt = counts[t0 + tx];
+                        int& c = cursor[tx];
+                        while (c < cnt && sl[c].y == y) {
+                            all.push_back(sl[c++]);
+                            --left;
+                        }
+                    }
+            }
         }
     }
     level_start[P.nlevels] = (int)all.size();

@@ -338,10 +338,13 @@ __device__ __forceinline__ int wave_sum(int v) {
 //      contiguous list into the pinned host buffer, its length beside it.  The host appends ~100 row lists per frame
 //      (orb_host.cpp) instead of walking 64000 (line, tile) cursors; rows do not wait for each other (a device-wide scan
 //      would need a second launch or a serial single-workgroup tail: tried, 40-100 us of exposed latency).
+//   order_rows == 0 (a ctx in throughput mode): steps 3/4 are skipped -- every tile writes its records and its count straight
+//   into its own slot of the pinned buffer and the host thread interleaves the tiles of a row (8 us less kernel time per
+//   frame for ~75 us more of the host thread).
 __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__ raw, PyrInfo P, int thr,
                                                      int32_t* __restrict__ row_count, DevCandidate* __restrict__ rows,
                                                      u64* __restrict__ dslots, u64* __restrict__ dline,
-                                                     int32_t* __restrict__ arrive) {
+                                                     int32_t* __restrict__ arrive, int order_rows) {
     __shared__ uint32_t pix[FT_PH * (FT_PW / 4)];
     __shared__ uint8_t sc[FT_SH * 68];
     __shared__ u64 rowmask[FT_H];
@@ -400,11 +403,13 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         u64 packed = (u64)(tid < FT_H ? cnt : 0) << (8 * (tid & 7));
 #pragma unroll
         for (int o = 1; o < 8; o <<= 1) packed |= (u64)__shfl_xor((long long)packed, o);
-        if (tid == 0 || tid == 8) __hip_atomic_store(dline + 2 * (size_t)blockIdx.x + (tid >> 3), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (order_rows && (tid == 0 || tid == 8))
+            __hip_atomic_store(dline + 2 * (size_t)blockIdx.x + (tid >> 3), packed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!order_rows && tid == FT_H - 1) row_count[blockIdx.x] = inc;
     }
     __syncthreads();
     const int total = rowstart[FT_H];
-    u64* out = dslots + (size_t)blockIdx.x * FT_TILE_CAP * 2;
+    u64* out = order_rows ? dslots + (size_t)blockIdx.x * FT_TILE_CAP * 2 : reinterpret_cast<u64*>(rows + (size_t)blockIdx.x * FT_TILE_CAP);
     const int step = L.stride;
     const int ndisc = c_disc_n;
     // this lane's pixels of the intensity-centroid disc (k = lane, lane + 64, ...): offsets and (u, v) once per workgroup,
@@ -467,15 +472,25 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
             static_assert(sizeof(DevCandidate) == 16, "record = two 64-bit words");
             u64 w[2];
             __builtin_memcpy(w, &cd, 16);
-            __hip_atomic_store(out + 2 * i, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(out + 2 * i + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (order_rows) {
+                __hip_atomic_store(out + 2 * i, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(out + 2 * i + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                out[2 * i] = w[0];
+                out[2 * i + 1] = w[1];
+            }
         }
     }
+    if (!order_rows) return;
     // ---- 4. the tile row's last workgroup orders the row
+    // (dynamic LDS, sized by the host for the widest level: orb_detect_order_lds)
+    extern __shared__ int s_dyn[];
+    const int mtx = P.lv[0].tiles_x;                     // level 0 is the widest
     __shared__ int s_last;
-    __shared__ int s_off[FT_H * FT_ROW_TILES];          // exclusive scan over (line, tile)
-    __shared__ uint16_t s_tstart[FT_ROW_TILES][FT_H + 1];  // line starts inside every tile
-    __shared__ int s_tpre[FT_ROW_TILES + 1];            // records before tile tx in (tile, slot) enumeration
+    int* s_off = s_dyn;                                  // [FT_H * mtx] exclusive scan over (line, tile)
+    int* s_tpre = s_off + FT_H * mtx;                    // [mtx + 1] records before tile tx in (tile, slot) enumeration
+    typedef uint16_t TileStarts[FT_H + 1];
+    TileStarts* s_tstart = reinterpret_cast<TileStarts*>(s_tpre + mtx + 1);  // [mtx][17] line starts inside every tile
     __shared__ int s_wsum[4];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -783,13 +798,15 @@ int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int chann
 
 // detection: FAST + NMS + Harris + angle in one launch; per-tile survivor counts and records land in the pinned buffer
 // `host` = [int32 count x n_tiles (padded to 64 B)][DevCandidate x n_tiles x FT_TILE_CAP]
-int orb_launch_detect(mvo_ctx* ctx, uint8_t* host) {
+int orb_launch_detect(mvo_ctx* ctx, uint8_t* host, bool ordered) {
     const PyrInfo& P = ctx->pyr;
     int32_t* counts = reinterpret_cast<int32_t*>(host);
     DevCandidate* slots = reinterpret_cast<DevCandidate*>(host + orb_detect_counts_bytes(P.n_tiles));
     ProfScope ps(ctx, "k_fast_harris");
-    hipLaunchKernelGGL(k_fast_harris, dim3(P.n_tiles), dim3(256), 0, ctx->stream, ctx->d_raw, P, ctx->orb.fast_threshold,
-                       counts, slots, (u64*)ctx->d_fh_slots, (u64*)ctx->d_fh_line, ctx->d_fh_arrive);
+    // (level 0 is the widest level: its tile count per row sizes the ordering step's tables)
+    const size_t lds = ordered ? ((size_t)FT_H * P.lv[0].tiles_x + P.lv[0].tiles_x + 1) * 4 + (size_t)P.lv[0].tiles_x * (FT_H + 1) * 2 : 0;
+    hipLaunchKernelGGL(k_fast_harris, dim3(P.n_tiles), dim3(256), lds, ctx->stream, ctx->d_raw, P, ctx->orb.fast_threshold,
+                       counts, slots, (u64*)ctx->d_fh_slots, (u64*)ctx->d_fh_line, ctx->d_fh_arrive, ordered ? 1 : 0);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }

@@ -229,3 +229,20 @@ def test_row_stride_bgra_and_large_frames(mvo, O, ctx):
     k, d = ctx.calc_descriptors(big, k, reuse_pyramid=True)
     kb, db = O.calc_descriptors(big, kb, p)
     assert np.array_equal(d, db) and len(k) > 4000
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (1242, 375), (333, 251)])
+def test_both_candidate_orderings_bit_exact(mvo, O, w, h):
+    """The canonical (level, row, column) order of the candidates is restored either by the kernel (the last workgroup of
+    a tile row, default) or by the host thread (a ctx in throughput mode leaves the GPU that time): both must deliver the
+    oracle's list, element for element."""
+    img = mvo.synth.small_test_image(5 * w + h, w, h)
+    for mode in ("latency", "throughput"):
+        c = mvo.Context(0, max_keypoints=3000)
+        c.ba_set_mode(mode)
+        p = O.default_params(**c.params)
+        for rep in range(3):                         # (the arrival counters re-arm themselves)
+            k = c.calc_keypoints(img, cap=8192)
+            assert_struct_equal(k, O.calc_keypoints(img, p).astype(k.dtype), "calcKeyPoints, %s mode, run %d" % (mode, rep))
+            _cand_cmp(mvo, c.debug_candidates(), O.candidates(img, p))
+        c.close()
