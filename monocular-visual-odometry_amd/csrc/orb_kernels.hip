@@ -476,8 +476,8 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
                 __hip_atomic_store(out + 2 * i, w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(out + 2 * i + 1, w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
-                out[2 * i] = w[0];
-                out[2 * i + 1] = w[1];
+                // ONE 16-byte store per record: the slot is host memory, every store is a PCIe write of its own
+                reinterpret_cast<ulonglong2*>(out)[i] = make_ulonglong2(w[0], w[1]);
             }
         }
     }
@@ -569,8 +569,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         const u64* src = dslots + ((size_t)(t0 + q) * FT_TILE_CAP + c) * 2;
         const u64 w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const u64 w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        dst[2 * d] = w0;
-        dst[2 * d + 1] = w1;
+        reinterpret_cast<ulonglong2*>(dst)[d] = make_ulonglong2(w0, w1);  // (one PCIe write per record)
     }
 }
 
