@@ -38,6 +38,7 @@ int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
 int g_ba_service = 1;     // throughput-mode windows of the 5-pose class and the resident solver service: 0 = never, 1 = while the
                           // offered load fills most of its slots (BaService::wanted), 2 = always
 int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
+int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
 namespace {
@@ -654,8 +655,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 wg_pose[(size_t)g * (F + 1) + F] = acc;
             }
         }
-        // column pieces of the Schur chains: with one chunk, as many pieces side by side as there are idle waves; otherwise
-        // one piece per chunk, as few chunks as the LDS budget allows (a wave keeps the running sums of <= 2 tile pairs)
+        // column pieces of the Schur chains: as many pieces side by side (on different waves) as there are idle waves, in
+        // every chunk; as few chunks as the LDS budget allows (a wave keeps the running sums of <= 2 tile pairs)
         const int msteps = (3 * maxLg + 3) / 4;
         // where the Jacobian rows of the edges live: all in LDS when the range has the room (fewest registers: the
         // kernel flavour without register-resident rows), else the first 512 of a range in the registers of its threads
@@ -666,7 +667,9 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
             P.slots = all_lds ? 0 : (maxEg > BA_THREADS ? 2 : 1);
             for (int q = 1; q <= max_seq && !fits; ++q) {
                 nseq = q;
-                npar = (do_schur && q == 1) ? std::max(1, BA_WAVES / npair) : 1;
+                // (pieces side by side in every chunk: the chains of a chunk are half as long, the idle waves take the other half)
+                npar = do_schur ? std::max(1, BA_WAVES / npair) : 1;
+                if (q > 1 && g_ba_chunk_pieces == 1) npar = 1;
                 if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
                 nsplit = nseq * npar;
                 const int msplit = (msteps + nsplit - 1) / nsplit;
