@@ -157,9 +157,10 @@ struct BaService {
     // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
     // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
     // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
-    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Hysteresis + 20 ms dwell.
+    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: at once (20 ms after
+    // the last change at the earliest); going: after 50 ms of low demand in a row.
     std::mutex m_demand;
-    std::chrono::steady_clock::time_point sub_t[32], svc_flip{};
+    std::chrono::steady_clock::time_point sub_t[32], svc_flip{}, low_since{};
     long long sub_n = 0, svc_flips = 0;
     bool svc_on = false;
     bool wanted();
@@ -352,16 +353,32 @@ bool BaService::wanted() {
     const auto now = std::chrono::steady_clock::now();
     // a pause of the callers (a barrier, a synchronisation, the end of a run) is not low demand: the estimate starts over,
     // the decision stands
-    if (sub_n > 0 && now - sub_t[(sub_n - 1) & 31] > std::chrono::milliseconds(10)) sub_n = 0;
+    if (sub_n > 0 && now - sub_t[(sub_n - 1) & 31] > std::chrono::milliseconds(10)) {
+        sub_n = 0;
+        low_since = {};
+    }
     sub_t[sub_n++ & 31] = now;
-    if (sub_n >= 32 && now - svc_flip > std::chrono::milliseconds(20)) {
+    if (sub_n >= 32) {
         const double span = std::chrono::duration<double>(now - sub_t[sub_n & 31]).count();  // (the oldest of the 32)
         const double load = 31.0 / std::max(span, 1e-6) * 3.8e-3;                           // slots of the grid kept busy
-        const bool want = svc_on ? load > 0.4 * BA_SERVICE_SLOTS : load >= 0.56 * BA_SERVICE_SLOTS;
-        if (want != svc_on) {
-            svc_on = want;
-            svc_flip = now;
-            ++svc_flips;
+        if (!svc_on) {
+            if (load >= 0.56 * BA_SERVICE_SLOTS && now - svc_flip > std::chrono::milliseconds(20)) {
+                svc_on = true;
+                svc_flip = now;
+                ++svc_flips;
+            }
+        } else if (load > 0.4 * BA_SERVICE_SLOTS) {
+            low_since = {};
+        } else {
+            // leaving takes 50 ms of low demand in a row: the last steps of a run (callers finishing one after the other)
+            // look like low demand for a few milliseconds
+            if (low_since == std::chrono::steady_clock::time_point{}) low_since = now;
+            if (now - low_since > std::chrono::milliseconds(50)) {
+                svc_on = false;
+                svc_flip = now;
+                low_since = {};
+                ++svc_flips;
+            }
         }
     }
     return svc_on;

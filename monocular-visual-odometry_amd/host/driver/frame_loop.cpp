@@ -156,7 +156,9 @@ void* frame_loop_create(const frame_loop_cfg* cfg) {
     Loop* L = new Loop();
     L->c = *cfg;
     if (!L->c.ctx_ba) L->c.ctx_ba = L->c.ctx;
+    // (both contexts of the sequence: the mode also tells the detection who restores the candidate order)
     (void)mvo_ba_set_mode(L->c.ctx_ba, cfg->ba_throughput ? MVO_BA_MODE_THROUGHPUT : MVO_BA_MODE_LATENCY);
+    (void)mvo_ba_set_mode(L->c.ctx, cfg->ba_throughput ? MVO_BA_MODE_THROUGHPUT : MVO_BA_MODE_LATENCY);
     L->kps.resize((size_t)cfg->max_kp + 16);
     L->matches.resize((size_t)cfg->max_kp + 16);
     if (cfg->track) {
