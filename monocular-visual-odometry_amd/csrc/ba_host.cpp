@@ -62,7 +62,7 @@ struct BaPlan {
     std::vector<int> wg_pt;
     // device block layout
     size_t o_desc = 0, o_pin = 0, o_ptsin = 0, o_wpt = 0, o_wed = 0, o_wps = 0, o_ep = 0, o_el = 0, o_uv = 0, o_ptstart = 0,
-           o_ptl = 0, o_eof = 0, o_dup = 0, o_slot = 0, o_sp = 0, o_pkt = 0, upload_end = 0;
+           o_ptl = 0, o_eof = 0, o_dup = 0, o_slot = 0, o_sp = 0, o_pkt = 0, upload_end = 0, x_end = 0;
     size_t o_stats = 0, o_pout = 0, o_pts = 0, o_xp = 0, o_xr = 0, o_xh = 0, o_xc = 0, total = 0;
     // pinned mirror layout (behind the upload staging)
     size_t m_stats = 0, m_poses = 0, m_pts = 0, m_trace = 0, pin_total = 0;
@@ -76,6 +76,7 @@ struct BaWorkspace {
     char* pin = nullptr;
     size_t pin_cap = 0;
     unsigned seq = 0;  // launch sequence number (tags)
+    size_t x_sig[5] = {0, 0, 0, 0, 0};  // layout of the exchange areas the device block was last used with
     hipEvent_t ready = nullptr;
     BaPlan plan;
     bool in_flight = false;
@@ -788,7 +789,15 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     }
 
     // ---- layout
+    // The exchange areas come FIRST: their sizes depend on (G, n) only, so windows of one shape find them where the last one
+    // left them -- memory that only ever held granules, matched by tag.  When their layout does change they are cleared
+    // (below): bytes that once held ordinary data must never be taken for a published value.
     Carver cv;
+    P.o_xp = cv.take((size_t)G * npk * 16);
+    P.o_xr = cv.take((size_t)npk * 16);
+    P.o_xh = cv.take((size_t)G * nhp * 16);
+    P.o_xc = cv.take((size_t)2 * G * 4 * 8);
+    P.x_end = cv.off;
     P.o_desc = cv.take(sizeof(BaDev));
     P.o_pin = cv.take((size_t)F * 128);
     P.o_ptsin = cv.take((size_t)L * 24);
@@ -809,10 +818,6 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.o_stats = cv.take(sizeof(BaStatsDev));
     P.o_pout = cv.take((size_t)F * 128);
     P.o_pts = cv.take((size_t)L * 24);
-    P.o_xp = cv.take((size_t)G * npk * 16);
-    P.o_xr = cv.take((size_t)npk * 16);
-    P.o_xh = cv.take((size_t)G * nhp * 16);
-    P.o_xc = cv.take((size_t)2 * G * 4 * 8);
     P.total = cv.off;
     Carver pc;
     pc.off = P.upload_end;
@@ -823,9 +828,14 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.pin_total = pc.off;
     int r = ws_reserve(ctx, ws, P.total, P.pin_total);
     if (r) return r;
-    if (++ws.seq >= (1u << 20)) {  // tag space exhausted: start over on clean exchange memory
-        MVO_HIP(hipMemsetAsync(ws.dev + P.upload_end, 0, ws.dev_cap - P.upload_end, ctx->stream));
-        ws.seq = 1;
+    const size_t sig[5] = {P.o_xp, P.o_xr, P.o_xh, P.o_xc, P.x_end};
+    const bool moved = std::memcmp(sig, ws.x_sig, sizeof sig) != 0;
+    if (++ws.seq >= (1u << 20) || moved) {  // tag space exhausted / exchange areas laid out anew: clean exchange memory
+        MVO_HIP(hipMemsetAsync(ws.dev, 0, std::max(P.x_end, ws.x_sig[4]), ctx->stream));
+        // (a window for the resident grid is not ordered behind this stream: wait here; layout changes are rare)
+        if (svc) MVO_HIP(hipStreamSynchronize(ctx->stream));
+        if (ws.seq >= (1u << 20)) ws.seq = 1;
+        std::memcpy(ws.x_sig, sig, sizeof sig);
     }
 
     // ---- upload image
@@ -921,7 +931,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
 
 int ba_upload(mvo_ctx* ctx, BaWorkspace& ws) {
     if (ws.plan.service) return MVO_OK;  // (the resident grid reads the pinned image itself)
-    MVO_HIP(hipMemcpyAsync(ws.dev, ws.pin, ws.plan.upload_end, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(ws.dev + ws.plan.x_end, ws.pin + ws.plan.x_end, ws.plan.upload_end - ws.plan.x_end, hipMemcpyHostToDevice, ctx->stream));
     MVO_HIP(hipEventRecord(ws.ready, ctx->stream));
     return MVO_OK;
 }

@@ -18,5 +18,6 @@ for i in 1 2; do
   (cd _ab_old && timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/old_$i.json 2> $O/old_$i.err); pr $O/old_$i.json
   timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/new_$i.json 2> $O/new_$i.err; pr $O/new_$i.json
 done
-timeout 200 python bench.py --track --steps 20 --no-cpu-baseline --no-secondary > $O/track.json 2> $O/track.err; pr $O/track.json
+
+
 timeout 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-secondary > $O/new_k60.json 2> $O/new_k60.err; pr $O/new_k60.json
