@@ -431,6 +431,10 @@ def main(argv=None, env=None):
                             trials_per_solve=trials / max(solves, 1), launch_thread_ms=launch.get("service_ms"),
                             timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2))
             tr = pmc_traffic("k_ba_lm")
+            if resident:
+                # the resident grid: bytes per WINDOW of the profiled run (its dispatches span the run) x the windows of this one
+                trw = pmc_traffic("k_ba_service_per_window")
+                tr = (trw[0] * launch["windows"], trw[1]) if trw else None
             # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command (tools/collect_evidence.sh); the
             # hand-offs are 8-byte accesses, a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported
             # uncorrected

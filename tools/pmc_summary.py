@@ -1,7 +1,8 @@
 """Turns rocprofv3 counter-collection CSVs (one --pmc pass each, --kernel-trace only) into the per-kernel summary that
 bench.py reads (profiles/rNN_pmc_fetch_write_size_per_kernel.csv) or into a plain table for other counters.
 
-  python tools/pmc_summary.py fetch_write <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> "<command>"
+  python tools/pmc_summary.py fetch_write <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> "<command>" [windows]
+      (windows = BA windows the profiled command solved: adds the row k_ba_service_per_window = the resident grid's totals / windows)
   python tools/pmc_summary.py table <counter_collection.csv> <out.txt> "<command>"
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB per dispatch; the summary keeps them as reported (the gfx950
@@ -31,6 +32,7 @@ def main():
     mode = sys.argv[1]
     if mode == "fetch_write":
         fetch, write, out, cmd = sys.argv[2:6]
+        windows = int(sys.argv[6]) if len(sys.argv) > 6 else 0
         F, W = collect(fetch), collect(write)
         with open(out, "w") as o:
             o.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only), %s\n" % cmd)
@@ -40,6 +42,9 @@ def main():
             for k in sorted(set(F) | set(W)):
                 fv, wv = F.get(k, {}).get("FETCH_SIZE", []), W.get(k, {}).get("WRITE_SIZE", [])
                 o.write("%s,%d,%.2f,%.2f\n" % (k, max(len(fv), len(wv)), sum(fv) / max(len(fv), 1), sum(wv) / max(len(wv), 1)))
+                if k == "k_ba_service" and windows > 0:
+                    # the resident grid is a handful of dispatches that span the run: per window = its totals / the windows solved
+                    o.write("k_ba_service_per_window,%d,%.2f,%.2f\n" % (windows, sum(fv) / windows, sum(wv) / windows))
     else:
         src, out, cmd = sys.argv[2:5]
         A = collect(src)
