@@ -158,11 +158,12 @@ struct BaService {
     // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
     // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
     // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
-    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: at once (20 ms after
-    // the last change at the earliest); going: after 50 ms of low demand in a row.
+    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: 32 submissions in a row
+    // at a rate that fills 10 slots; going: the 40-ms average below 8 slots for 80 ms in a row (BaService::wanted).
     std::mutex m_demand;
-    std::chrono::steady_clock::time_point sub_t[32], svc_flip{}, low_since{};
-    long long sub_n = 0, svc_flips = 0;
+    std::chrono::steady_clock::time_point sub_t[32], svc_flip{}, low_since{}, sub_last{};
+    long long sub_n = 0, sub_total = 0, svc_flips = 0;
+    double rate_avg = 0;  // submissions / s, exponentially averaged
     bool svc_on = false;
     bool wanted();
     int start_resident();
@@ -352,34 +353,46 @@ bool BaService::wanted() {
     if (g_ba_service != 1) return g_ba_service == 2;
     std::lock_guard<std::mutex> lk(m_demand);
     const auto now = std::chrono::steady_clock::now();
-    // a pause of the callers (a barrier, a synchronisation, the end of a run) is not low demand: the estimate starts over,
-    // the decision stands
-    if (sub_n > 0 && now - sub_t[(sub_n - 1) & 31] > std::chrono::milliseconds(10)) {
+    const double kSolve = 3.8e-3, kTau = 40e-3;  // nominal solve time of a window on a slot; time constant of the rate average
+    const double dt = sub_total ? std::chrono::duration<double>(now - sub_last).count() : 0.0;
+    if (sub_total && dt > 0.1) {
+        // the callers paused (a barrier, a synchronisation, the end of a run): not low demand -- the decision stands, the
+        // averages start over from where the decision would put them
         sub_n = 0;
+        rate_avg = svc_on ? 0.65 * BA_SERVICE_SLOTS / kSolve : 0.0;
         low_since = {};
+    } else {
+        if (dt > 0.01) sub_n = 0;  // (the 32-submission window restarts after a gap; the average bridges it)
+        rate_avg *= std::exp(-dt / kTau);
     }
+    const double load_avg = rate_avg * kSolve;  // slots kept busy, averaged over ~40 ms, as of just before this submission
+    rate_avg += 1.0 / kTau;
+    sub_last = now;
+    ++sub_total;
     sub_t[sub_n++ & 31] = now;
-    if (sub_n >= 32) {
-        const double span = std::chrono::duration<double>(now - sub_t[sub_n & 31]).count();  // (the oldest of the 32)
-        const double load = 31.0 / std::max(span, 1e-6) * 3.8e-3;                           // slots of the grid kept busy
-        if (!svc_on) {
-            if (load >= 0.56 * BA_SERVICE_SLOTS && now - svc_flip > std::chrono::milliseconds(20)) {
+    if (!svc_on) {
+        // coming: 32 submissions in a row at a rate that fills 10 of the 16 slots (bursts of a slower loop never get there)
+        if (sub_n >= 32 && now - svc_flip > std::chrono::milliseconds(20)) {
+            const double span = std::chrono::duration<double>(now - sub_t[sub_n & 31]).count();  // (the oldest of the 32)
+            if (31.0 / std::max(span, 1e-6) * kSolve >= 0.625 * BA_SERVICE_SLOTS) {
                 svc_on = true;
                 svc_flip = now;
-                ++svc_flips;
-            }
-        } else if (load > 0.4 * BA_SERVICE_SLOTS) {
-            low_since = {};
-        } else {
-            // leaving takes 50 ms of low demand in a row: the last steps of a run (callers finishing one after the other)
-            // look like low demand for a few milliseconds
-            if (low_since == std::chrono::steady_clock::time_point{}) low_since = now;
-            if (now - low_since > std::chrono::milliseconds(50)) {
-                svc_on = false;
-                svc_flip = now;
                 low_since = {};
+                rate_avg = std::max(rate_avg, 0.65 * BA_SERVICE_SLOTS / kSolve);
                 ++svc_flips;
             }
+        }
+    } else if (load_avg > 0.5 * BA_SERVICE_SLOTS) {
+        low_since = {};
+    } else {
+        // going: the average below half the slots for 80 ms in a row (the last steps of a run -- callers finishing one after
+        // the other -- and the first ones after a pause look like low demand for a few milliseconds)
+        if (low_since == std::chrono::steady_clock::time_point{}) low_since = now;
+        if (now - low_since > std::chrono::milliseconds(80)) {
+            svc_on = false;
+            svc_flip = now;
+            low_since = {};
+            ++svc_flips;
         }
     }
     return svc_on;
