@@ -130,7 +130,7 @@ class Shard:
     """One sequence: its frames resident in HBM, its own ctx/stream(s), its pool of BA windows, its native loop."""
 
     def __init__(self, mvo, torch, device, shard_id, args, ba_mode, pipeline, frames=None, pool=None, ba_cut=None,
-                 host_frames=False, chain=False, fix_points=None):
+                 host_frames=False, chain=False, fix_points=None, ctxs=None):
         self.mvo = mvo
         self.torch = torch
         self.from_host, self.chain = host_frames, chain
@@ -138,8 +138,12 @@ class Shard:
         self.ba_cut = ba_cut or (args.ba_cut if args.ba_cut != "auto" else ("throughput" if args.streams > 8 else "latency"))
         self.id = shard_id
         self.args = args
-        self.ctx = mvo.Context(device, max_keypoints=args.max_kp)
-        self.ctx_ba = mvo.Context(device, max_keypoints=args.max_kp) if pipeline else self.ctx
+        if ctxs is not None:
+            self.ctx, self.ctx_ba = ctxs
+        else:
+            self.ctx = mvo.Context(device, max_keypoints=args.max_kp)
+            # the BA half of the sequence: a sibling context on the same stream (no hardware queue of its own)
+            self.ctx_ba = self.ctx.sibling() if pipeline else self.ctx
         if frames is None:
             seq = mvo.synth.Sequence(args.width, args.height, args.frames, seed=1234 + shard_id, tex_size=1024)
             host = [seq.frame(i) for i in range(args.frames)]

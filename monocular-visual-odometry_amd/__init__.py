@@ -114,6 +114,18 @@ class Context:
         if orb_params:
             self.orb_configure(**orb_params)
 
+    def sibling(self):
+        """A second context of this host thread on THIS context's stream (mvo_create_sibling); close it before its parent."""
+        c = Context.__new__(Context)
+        c.lib = self.lib
+        h = C.c_void_p()
+        r = self.lib.mvo_create_sibling(self.h, C.byref(h))
+        if r != MVO_OK:
+            raise MvoError(r, "mvo_create_sibling failed")
+        c.h, c.device, c.params = h, self.device, dict(self.params)
+        c._parent = self   # (keeps the parent alive as long as the sibling)
+        return c
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.mvo_destroy(self.h)

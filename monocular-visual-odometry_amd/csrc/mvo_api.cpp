@@ -84,6 +84,25 @@ int mvo_create(mvo_ctx** out, int device) {
     return MVO_OK;
 }
 
+int mvo_create_sibling(mvo_ctx* parent, mvo_ctx** out) {
+    if (!out) return MVO_ERR_INVALID;
+    *out = nullptr;
+    if (!parent) return MVO_ERR_INVALID;
+    if (hipSetDevice(parent->device) != hipSuccess) return MVO_ERR_NO_DEVICE;
+    mvo_ctx* ctx = new mvo_ctx();
+    ctx->device = parent->device;
+    ctx->stream = parent->stream;  // no stream (= no share of a hardware queue) of its own
+    ctx->owns_stream = false;
+    if (hipEventCreateWithFlags(&ctx->ev, hipEventDisableTiming) != hipSuccess) {
+        delete ctx;
+        return MVO_ERR_NO_DEVICE;
+    }
+    ctx->orb = parent->orb;
+    ctx->orb_configured = true;
+    *out = ctx;
+    return MVO_OK;
+}
+
 void mvo_destroy(mvo_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
@@ -102,7 +121,7 @@ void mvo_destroy(mvo_ctx* ctx) {
         (void)hipEventDestroy(e.second);
     }
     (void)hipEventDestroy(ctx->ev);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 

@@ -120,6 +120,7 @@ struct ProfEntry {
 struct mvo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool owns_stream = true;  // false: a sibling ctx on its parent's stream (mvo_create_sibling)
     std::string err;
     // --- ORB
     mvo_orb_params orb{};

@@ -97,3 +97,27 @@ def test_throughput_mode_follows_the_load(mvo):
     stats = ref.ba_launch_stats()
     assert stats["resident_windows"] > 200 and routes.count(13) > 200, (stats, routes.count(13), routes.count(28))
     ref.close()
+
+
+def test_sibling_context_shares_the_stream_and_nothing_else(mvo):
+    """mvo_create_sibling: the second context of a sequence works on its parent's stream (no hardware queue of its own) but
+    keeps its own workspaces and mode; results equal those of independent contexts."""
+    img = mvo.synth.small_test_image(3, 320, 240)
+    pb = mvo.synth.ba_problem(4, 500, 40)
+    args = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
+    ref = mvo.Context(0, max_keypoints=800)
+    k_ref = ref.calc_keypoints(img)
+    P_ref, X_ref, _ = ref.bundle_adjustment(*args, fix_points=False, max_iterations=10)
+    ref.close()
+    parent = mvo.Context(0, max_keypoints=800)
+    sib = parent.sibling()
+    for _ in range(3):
+        P, X, st = sib.bundle_adjustment(*args, fix_points=False, max_iterations=10)
+        k = parent.calc_keypoints(img)
+        assert k.tobytes() == k_ref.tobytes() and P.tobytes() == P_ref.tobytes() and X.tobytes() == X_ref.tobytes()
+    sib.ba_set_mode("throughput")                            # the mode is the sibling's own
+    assert parent.calc_keypoints(img).tobytes() == k_ref.tobytes()
+    sib.close()
+    k = parent.calc_keypoints(img)                           # the parent (and its stream) outlive the sibling
+    assert k.tobytes() == k_ref.tobytes()
+    parent.close()
