@@ -159,7 +159,7 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * workgroup (the 5-keyframe window of the benchmark: 28 CUs of one XCD, shortest solve) and solved by a launch of its own;
  * the detection kernel also puts its candidates in order on the device.
  * THROUGHPUT: many sequences are in flight on this GPU -- CU time counts, not latency.  While the offered load keeps it
- * busy (submission rate x solve time >= 9 of its 16 slots; hysteresis), 5-keyframe windows are cut into ~700 observations
+ * busy (64 submissions in a row at a rate x solve time of >= 10 of its 16 slots; it leaves after 80 ms below 8), 5-keyframe windows are cut into ~700 observations
  * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
  * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
@@ -259,6 +259,10 @@ int mvo_debug_ba_service_times(int device, double* out5);
  * the last reset of mvo_ba_launch_stats (those windows count as one launch each there, `ms` = their solve times on the
  * device clock). */
 int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_starts);
+/* Test hook: replays the resident solver service's demand estimate (see mvo_ba_set_mode) over n submission times (seconds,
+ * ascending); decisions[i] = 1 if a window submitted at times[i] would go to the resident grid.  Returns the number of
+ * changes of mind.  Touches no device. */
+int mvo_debug_ba_demand_replay(const double* times, int n, uint8_t* decisions);
 /* When enabled every kernel launch is bracketed by hipEvents on the ctx stream; times accumulate per
  * kernel name until reset. */
 int mvo_profile_enable(mvo_ctx* ctx, int on);

@@ -41,6 +41,15 @@ int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or 
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
+// The demand estimate of the resident solver service (a plain state machine over submission times, so that it can be
+// replayed by the tests: mvo_debug_ba_demand_replay).
+struct BaDemand {
+    double t[64] = {0}, flip = -1e9, low_since = -1, last = 0, rate_avg = 0;  // rate_avg: submissions / s, exponentially averaged
+    long long n = 0, total = 0, flips = 0;
+    bool on = false;
+    bool submit(double now);
+};
+
 namespace {
 
 struct Carver {
@@ -158,13 +167,10 @@ struct BaService {
     // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
     // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
     // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
-    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: 32 submissions in a row
+    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: 64 submissions in a row
     // at a rate that fills 10 slots; going: the 40-ms average below 8 slots for 80 ms in a row (BaService::wanted).
     std::mutex m_demand;
-    std::chrono::steady_clock::time_point sub_t[32], svc_flip{}, low_since{}, sub_last{};
-    long long sub_n = 0, sub_total = 0, svc_flips = 0;
-    double rate_avg = 0;  // submissions / s, exponentially averaged
-    bool svc_on = false;
+    BaDemand demand;
     bool wanted();
     int start_resident();
     bool reap_locked();
@@ -349,53 +355,59 @@ void BaService::run() {
         cv_flight.notify_all();
     }
 }
-bool BaService::wanted() {
-    if (g_ba_service != 1) return g_ba_service == 2;
-    std::lock_guard<std::mutex> lk(m_demand);
-    const auto now = std::chrono::steady_clock::now();
+}  // namespace
+// Offered load of service-class windows -> should they go to the resident grid?  `now` in seconds (any monotonic origin).
+bool BaDemand::submit(double now) {
     const double kSolve = 3.8e-3, kTau = 40e-3;  // nominal solve time of a window on a slot; time constant of the rate average
-    const double dt = sub_total ? std::chrono::duration<double>(now - sub_last).count() : 0.0;
-    if (sub_total && dt > 0.1) {
+    const double dt = total ? now - last : 0.0;
+    if (total && dt > 0.1) {
         // the callers paused (a barrier, a synchronisation, the end of a run): not low demand -- the decision stands, the
         // averages start over from where the decision would put them
-        sub_n = 0;
-        rate_avg = svc_on ? 0.65 * BA_SERVICE_SLOTS / kSolve : 0.0;
-        low_since = {};
+        n = 0;
+        rate_avg = on ? 0.65 * BA_SERVICE_SLOTS / kSolve : 0.0;
+        low_since = -1;
     } else {
-        if (dt > 0.01) sub_n = 0;  // (the 32-submission window restarts after a gap; the average bridges it)
+        if (dt > 0.01) n = 0;  // (the 64-submission window restarts after a gap; the average bridges it)
         rate_avg *= std::exp(-dt / kTau);
     }
     const double load_avg = rate_avg * kSolve;  // slots kept busy, averaged over ~40 ms, as of just before this submission
     rate_avg += 1.0 / kTau;
-    sub_last = now;
-    ++sub_total;
-    sub_t[sub_n++ & 31] = now;
-    if (!svc_on) {
-        // coming: 32 submissions in a row at a rate that fills 10 of the 16 slots (bursts of a slower loop never get there)
-        if (sub_n >= 32 && now - svc_flip > std::chrono::milliseconds(20)) {
-            const double span = std::chrono::duration<double>(now - sub_t[sub_n & 31]).count();  // (the oldest of the 32)
-            if (31.0 / std::max(span, 1e-6) * kSolve >= 0.625 * BA_SERVICE_SLOTS) {
-                svc_on = true;
-                svc_flip = now;
-                low_since = {};
+    last = now;
+    ++total;
+    t[n++ & 63] = now;
+    if (!on) {
+        // coming: 64 submissions in a row at a rate that fills 10 of the 16 slots (the bursts of a slower loop never get there,
+        // nor does a chance cluster of independent arrivals at half that rate)
+        if (n >= 64 && now - flip > 0.02) {
+            const double span = now - t[n & 63];  // (the oldest of the 64)
+            if (63.0 / std::max(span, 1e-6) * kSolve >= 0.625 * BA_SERVICE_SLOTS) {
+                on = true;
+                flip = now;
+                low_since = -1;
                 rate_avg = std::max(rate_avg, 0.65 * BA_SERVICE_SLOTS / kSolve);
-                ++svc_flips;
+                ++flips;
             }
         }
     } else if (load_avg > 0.5 * BA_SERVICE_SLOTS) {
-        low_since = {};
+        low_since = -1;
     } else {
         // going: the average below half the slots for 80 ms in a row (the last steps of a run -- callers finishing one after
         // the other -- and the first ones after a pause look like low demand for a few milliseconds)
-        if (low_since == std::chrono::steady_clock::time_point{}) low_since = now;
-        if (now - low_since > std::chrono::milliseconds(80)) {
-            svc_on = false;
-            svc_flip = now;
-            low_since = {};
-            ++svc_flips;
+        if (low_since < 0) low_since = now;
+        if (now - low_since > 0.08) {
+            on = false;
+            flip = now;
+            low_since = -1;
+            ++flips;
         }
     }
-    return svc_on;
+    return on;
+}
+namespace {
+bool BaService::wanted() {
+    if (g_ba_service != 1) return g_ba_service == 2;
+    std::lock_guard<std::mutex> lk(m_demand);
+    return demand.submit(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
 }
 // finished windows of the resident grid -> their clients (service mutex held); true if any slot was freed
 bool BaService::reap_locked() {
@@ -1227,4 +1239,11 @@ void ba_launch_stats(int device, long long* launches, long long* windows, double
         s.t_idle = s.t_batch = s.t_launch = s.t_sync = s.t_post = 0;
         s.resident_jobs = s.resident_starts = 0;
     }
+}
+
+// test hook: the service's demand estimate replayed over a list of submission times (seconds, ascending)
+int ba_demand_replay(const double* times, int n, unsigned char* decisions) {
+    BaDemand d;
+    for (int i = 0; i < n; ++i) decisions[i] = d.submit(times[i]) ? 1 : 0;
+    return (int)d.flips;
 }

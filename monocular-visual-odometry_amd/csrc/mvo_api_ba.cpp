@@ -6,6 +6,7 @@
 
 #include "mvo_internal.h"
 
+int ba_demand_replay(const double* times, int n, unsigned char* decisions);  // ba_host.cpp
 extern int g_ba_use_mfma, g_ba_wgs, g_ba_same_l2, g_ba_profile, g_ba_block_solver, g_ba_cu_share, g_ba_xcd_reserve, g_ba_edge_rows, g_ba_service, g_ba_chunk_pieces;  // ba_host.cpp
 // mvo_debug_set("ba_*", v): validation paths and planner overrides the tests compare
 int ba_debug_set(const char* key, int value) {
@@ -122,6 +123,11 @@ int mvo_debug_get_ba_trace(mvo_ctx* ctx, mvo_ba_handle* handle, double* rows, in
 int mvo_debug_get_ba_plan(mvo_ctx* ctx, mvo_ba_handle* handle, int* wgs, int* nsplit, int32_t* wg_pt_start, int cap) {
     if (!ctx) return MVO_ERR_INVALID;
     return ba_get_plan(ctx, handle, wgs, nsplit, wg_pt_start, cap);
+}
+
+int mvo_debug_ba_demand_replay(const double* times, int n, uint8_t* decisions) {
+    if (!times || !decisions || n < 0) return MVO_ERR_INVALID;
+    return ba_demand_replay(times, n, decisions);
 }
 
 int mvo_debug_get_ba_phases(mvo_ctx* ctx, long long* cycles, int n, int* wgs) {
