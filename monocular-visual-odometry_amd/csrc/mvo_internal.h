@@ -212,7 +212,7 @@ int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_
                              int32_t* d_idx, float* d_px, uint8_t* d_desc_out, int32_t* d_n);
 int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_p2, int n, const int32_t* d_subsets,
                                 int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
-                                uint8_t* d_masks);
+                                uint8_t* d_masks, double* h_models, int32_t* h_counts);
 int track_launch_pnp_refine(mvo_ctx* ctx, const float* d_p3, const float* d_p2, const uint8_t* d_masks, int n,
                             const TrackCamera& cam, const double* d_models, const int32_t* d_counts, int n_hyp,
                             double confidence, int forced_best, int mode, double* d_Mg, double* d_mg,

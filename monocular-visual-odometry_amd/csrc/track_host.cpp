@@ -22,6 +22,8 @@ struct mvo_track_state {
     uint8_t* d_best_mask = nullptr;
     int cap_n = 0;
     int32_t* d_subsets = nullptr;
+    uint8_t* d_in = nullptr;  // pairs + subsets of a solvePnPRansac call, contiguous like their pinned staging (one upload)
+    size_t cap_in = 0;
     double* d_models = nullptr;
     int32_t* d_counts = nullptr;
     double* d_out = nullptr;
@@ -95,6 +97,14 @@ int ensure_pnp(mvo_ctx* ctx, int n, int n_hyp) {
         s->cap_h = cap;
     }
     if (!s->d_out) MVO_HIP(hipMalloc((void**)&s->d_out, 16 * sizeof(double)));
+    const size_t in_need = (size_t)n * 20 + (size_t)n_hyp * 20 + 64;
+    if (in_need > s->cap_in) {
+        free_dev(s->d_in);
+        s->cap_in = 0;
+        const size_t cap = in_need + in_need / 2 + 4096;
+        MVO_HIP(hipMalloc((void**)&s->d_in, cap));
+        s->cap_in = cap;
+    }
     const size_t need = (size_t)n_hyp * (size_t)n;
     if (need > s->cap_masks) {
         free_dev(s->d_masks);
@@ -190,6 +200,7 @@ void track_release(mvo_ctx* ctx) {
     free_dev(s->d_Mg);
     free_dev(s->d_mg);
     free_dev(s->d_best_mask);
+    free_dev(s->d_in);
     free_dev(s->d_subsets);
     free_dev(s->d_models);
     free_dev(s->d_counts);
@@ -305,26 +316,24 @@ int mvo_map_points_in_view(mvo_ctx* ctx, mvo_map* map, const double* T_w_c, doub
         s->cap_view = c;
     }
     if (!s->d_view_n) MVO_HIP(hipMalloc((void**)&s->d_view_n, 4));
-    int r = track_launch_map_in_view(ctx, map->d_pos, map->d_desc, map->n, a, s->d_view_idx, s->d_view_px,
-                                     s->d_view_desc, s->d_view_n);
+    // the kernel writes the count, the indices and the pixels straight into the pinned buffer (the descriptors of the survivors
+    // stay in HBM for the matcher): one synchronisation, no copy
+    int r = mvo_ensure_pinned(ctx, 192 + (size_t)map->n * 12);
     if (r) return r;
-    if ((r = mvo_ensure_pinned(ctx, 16 + (size_t)map->n * 12))) return r;
-    // count first (4 bytes), then exactly the survivors
-    MVO_HIP(hipMemcpyAsync(ctx->h_pin, s->d_view_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MVO_HIP(hipStreamSynchronize(ctx->stream));  // (nothing of an earlier call may still be reading the staging buffer)
+    int32_t* h_n = reinterpret_cast<int32_t*>(ctx->h_pin);
+    int32_t* h_idx = reinterpret_cast<int32_t*>(ctx->h_pin + 64);
+    float* h_px = reinterpret_cast<float*>(ctx->h_pin + 64 + ((size_t)map->n * 4 + 63) / 64 * 64);  // (float2 stores)
+    if ((r = track_launch_map_in_view(ctx, map->d_pos, map->d_desc, map->n, a, h_idx, h_px, s->d_view_desc, h_n))) return r;
     MVO_HIP(hipStreamSynchronize(ctx->stream));
-    int cnt;
-    std::memcpy(&cnt, ctx->h_pin, 4);
+    const int cnt = *h_n;
     *n = cnt;
     if (d_desc_out) *d_desc_out = s->d_view_desc;
     if (ctx->prof) mvo_prof_collect(ctx);
     if (cnt > cap) return mvo_set_err(ctx, MVO_ERR_CAPACITY, "mvo_map_points_in_view: output buffers too small", hipSuccess);
     if (cnt) {
-        MVO_HIP(hipMemcpyAsync(ctx->h_pin + 16, s->d_view_idx, (size_t)cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MVO_HIP(hipMemcpyAsync(ctx->h_pin + 16 + (size_t)cnt * 4, s->d_view_px, (size_t)cnt * 8, hipMemcpyDeviceToHost,
-                               ctx->stream));
-        MVO_HIP(hipStreamSynchronize(ctx->stream));
-        std::memcpy(idx, ctx->h_pin + 16, (size_t)cnt * 4);
-        std::memcpy(px, ctx->h_pin + 16 + (size_t)cnt * 4, (size_t)cnt * 8);
+        std::memcpy(idx, h_idx, (size_t)cnt * 4);
+        std::memcpy(px, h_px, (size_t)cnt * 8);
     }
     return MVO_OK;
 }
@@ -353,9 +362,12 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     MVO_HIP(hipSetDevice(ctx->device));
     int r = ensure_pnp(ctx, n, n_hyp);
     if (r) return r;
-    // stage pairs + subsets
+    // stage pairs + subsets: ONE upload; the kernels deliver their results into the pinned buffer themselves (models and
+    // counts by the hypothesis kernel, the refined pose and the inlier mask by the refinement kernel): no copy comes back
     const size_t b3 = (size_t)n * 12, b2 = (size_t)n * 8, bs = (size_t)n_hyp * kModel * 4;
-    if ((r = mvo_ensure_pinned(ctx, std::max(b3 + b2 + bs, (size_t)n_hyp * 100 + (size_t)n + 512)))) return r;
+    const size_t o_out = (b3 + b2 + bs + 63) / 64 * 64, o_counts = o_out + 128, o_models = o_counts + ((size_t)n_hyp * 4 + 63) / 64 * 64,
+                 o_mask = o_models + (size_t)n_hyp * 96;
+    if ((r = mvo_ensure_pinned(ctx, o_mask + (size_t)n + 64))) return r;
     MVO_HIP(hipStreamSynchronize(ctx->stream));
     std::memcpy(ctx->h_pin, pts3d, b3);
     std::memcpy(ctx->h_pin + b3, pts2d, b2);
@@ -364,35 +376,31 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
         for (int i = 0; i < kModel; ++i) subsets[i] = i;
     else
         draw_subsets(n, n_hyp, subsets);
-    MVO_HIP(hipMemcpyAsync(s->d_p3, ctx->h_pin, b3, hipMemcpyHostToDevice, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(s->d_p2, ctx->h_pin + b3, b2, hipMemcpyHostToDevice, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(s->d_subsets, subsets, bs, hipMemcpyHostToDevice, ctx->stream));
+    MVO_HIP(hipMemcpyAsync(s->d_in, ctx->h_pin, b3 + b2 + bs, hipMemcpyHostToDevice, ctx->stream));
+    const float* d_p3 = reinterpret_cast<const float*>(s->d_in);
+    const float* d_p2 = reinterpret_cast<const float*>(s->d_in + b3);
+    const int32_t* d_subsets = reinterpret_cast<const int32_t*>(s->d_in + b3 + b2);
+    uint8_t* h_out = ctx->h_pin + o_out;
+    uint8_t* h_counts = ctx->h_pin + o_counts;
+    uint8_t* h_models = ctx->h_pin + o_models;
+    uint8_t* h_mask = ctx->h_pin + o_mask;
     const TrackCamera cam{fx, fy, cx, cy};
     const float thr2 = (float)((double)reprojection_error * (double)reprojection_error);
-    if ((r = track_launch_pnp_hypotheses(ctx, s->d_p3, s->d_p2, n, s->d_subsets, n_hyp, cam, thr2, s->d_models, s->d_counts,
-                                         s->d_masks)))
+    if ((r = track_launch_pnp_hypotheses(ctx, d_p3, d_p2, n, d_subsets, n_hyp, cam, thr2, s->d_models, s->d_counts, s->d_masks,
+                                         reinterpret_cast<double*>(h_models), reinterpret_cast<int32_t*>(h_counts))))
         return r;
     // The refinement kernel replays the sequential bookkeeping of RANSACPointSetRegistrator::run over the counts and
     // refines the model it selects; the host repeats the replay (its own libm) on the counts that come back with
     // the result and only launches again if it disagrees -- one host round trip per call.
     const int mode = n == kModel ? 1 : 0;
     const double dev_conf = g_pnp_replay_skew ? 0.5 : confidence;
-    if ((r = track_launch_pnp_refine(ctx, s->d_p3, s->d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp, dev_conf,
-                                     mode == 1 ? 0 : -1, mode, s->d_Mg, s->d_mg, s->d_best_mask, s->d_out)))
+    if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp, dev_conf,
+                                     mode == 1 ? 0 : -1, mode, s->d_Mg, s->d_mg, h_mask, reinterpret_cast<double*>(h_out))))
         return r;
-    // (the staging area is reused for the read-back: same stream, so the copies below run after the uploads above)
-    uint8_t* h_out = ctx->h_pin;
-    uint8_t* h_counts = h_out + 128;
-    uint8_t* h_models = h_counts + (size_t)n_hyp * 4;
-    uint8_t* h_mask = h_models + (size_t)n_hyp * 96;
     auto fetch = [&]() -> int {
-        MVO_HIP(hipMemcpyAsync(h_out, s->d_out, 12 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        MVO_HIP(hipMemcpyAsync(h_mask, s->d_best_mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
         MVO_HIP(hipStreamSynchronize(ctx->stream));
         return MVO_OK;
     };
-    MVO_HIP(hipMemcpyAsync(h_counts, s->d_counts, (size_t)n_hyp * 4, hipMemcpyDeviceToHost, ctx->stream));
-    MVO_HIP(hipMemcpyAsync(h_models, s->d_models, (size_t)n_hyp * 96, hipMemcpyDeviceToHost, ctx->stream));
     if ((r = fetch())) return r;
     s->counts.assign(reinterpret_cast<int32_t*>(h_counts), reinterpret_cast<int32_t*>(h_counts) + n_hyp);
     s->models.resize((size_t)n_hyp * 12);
@@ -419,8 +427,8 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     std::memcpy(out, h_out, sizeof(out));
     if (best >= 0 && (int)out[10] != best) {  // the device's replay chose differently: refine the right hypothesis
         s->info[5] = -n_hyp;                  // (visible to tests through mvo_debug_get_pnp)
-        if ((r = track_launch_pnp_refine(ctx, s->d_p3, s->d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp,
-                                         confidence, best, mode, s->d_Mg, s->d_mg, s->d_best_mask, s->d_out)))
+        if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp,
+                                         confidence, best, mode, s->d_Mg, s->d_mg, h_mask, reinterpret_cast<double*>(h_out))))
             return r;
         if ((r = fetch())) return r;
         std::memcpy(out, h_out, sizeof(out));

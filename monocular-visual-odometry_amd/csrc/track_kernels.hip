@@ -85,7 +85,8 @@ int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_
 __global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* __restrict__ p3, const float* __restrict__ p2, int n,
                                                         const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
                                                         double* __restrict__ models, int32_t* __restrict__ counts,
-                                                        uint8_t* __restrict__ masks) {
+                                                        uint8_t* __restrict__ masks, double* __restrict__ h_models,
+                                                        int32_t* __restrict__ h_counts) {
     __shared__ pw::HypLds lds;
     const int h = blockIdx.x;
     const pw::Camera c{cam.fx, cam.fy, cam.cx, cam.cy};
@@ -101,6 +102,12 @@ __global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* _
             m[9 + i] = t[i];
         }
         counts[h] = good;
+        // the same record straight into the caller's pinned buffer (the refinement kernel reads the device copy: its replay of
+        // the RANSAC bookkeeping is a chain of dependent loads)
+        double* hm = h_models + 12 * (size_t)h;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) hm[i] = m[i];
+        h_counts[h] = good;
     }
 }
 
@@ -229,10 +236,10 @@ int track_launch_em_mask(mvo_ctx* ctx, const double* d_q1, const double* d_q2, i
 
 int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_p2, int n, const int32_t* d_subsets,
                                 int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
-                                uint8_t* d_masks) {
+                                uint8_t* d_masks, double* h_models, int32_t* h_counts) {
     ProfScope ps(ctx, "k_pnp_hypotheses");
     hipLaunchKernelGGL(k_pnp_hypotheses, dim3(n_hyp), dim3(pw::kHypLanes), 0, ctx->stream, d_p3, d_p2, n, d_subsets, cam, thr2,
-                       d_models, d_counts, d_masks);
+                       d_models, d_counts, d_masks, h_models, h_counts);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }
