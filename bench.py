@@ -564,7 +564,7 @@ def main(argv=None, env=None):
                                       len(s0.pool), args.ba_poses, args.ba_points, int(E_avg))
                        if args.ba_mode == "rebuild" else "S%d extract+match, BA mode %s" % (args.width, args.ba_mode),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
-                       "frame_loop": "native (host/driver/frame_loop.cpp)" + (", extraction of frame i+1 overlapped with BA of frame i" if pipeline else ""),
+                       "frame_loop": "native (host/driver/frame_loop.cpp)" + (", extraction of frame i+1 overlapped with BA of frame i (a ctx + its sibling per sequence, THROUGHPUT mode when > 8 sequences)" if pipeline else ""),
                        "keypoints": st.n_kp, "matches": st.n_match,
                        "ba_trials_per_solve": trials / max(solves, 1),
                        "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers) every "
