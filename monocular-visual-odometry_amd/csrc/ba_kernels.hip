@@ -1353,6 +1353,10 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                             }
                         }
                     }
+                    if (PROF) {  // (instrumented kernel only: separates the clearing from the per-edge fill in the timeline)
+                        __syncthreads();
+                        STAMP(2);
+                    }
 #define BA_BODY_UFILL(el, r, l_, sl_, ee)                                                          \
     const int l = l_, sl = sl_;                                                                   \
     if (sl < 0 || 3 * l + 2 < c0 || 3 * l >= c1 || (has_dups && W.dup[el] != rank)) break;         \
