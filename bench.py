@@ -143,7 +143,9 @@ class Shard:
         else:
             self.ctx = mvo.Context(device, max_keypoints=args.max_kp)
             # the BA half of the sequence: a sibling context on the same stream (no hardware queue of its own)
-            self.ctx_ba = self.ctx.sibling() if pipeline else self.ctx
+            # (MVO_BENCH_SEPARATE_CTX=1: a full second context with a stream of its own -- the round-2 arrangement, kept for the A/B)
+            separate = os.environ.get("MVO_BENCH_SEPARATE_CTX") == "1"
+            self.ctx_ba = (mvo.Context(device, max_keypoints=args.max_kp) if separate else self.ctx.sibling()) if pipeline else self.ctx
         if frames is None:
             seq = mvo.synth.Sequence(args.width, args.height, args.frames, seed=1234 + shard_id, tex_size=1024)
             host = [seq.frame(i) for i in range(args.frames)]

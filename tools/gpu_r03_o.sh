@@ -1,4 +1,5 @@
 #!/bin/bash
+# A/B on one box: two full contexts (= two streams) per sequence vs a context + its sibling (mvo_create_sibling)
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=$PWD/gpurun_out/r03o
@@ -13,4 +14,4 @@ except Exception as e:
     print(sys.argv[1], "failed", e)
 PY
 }
-for v in a0:0 b1:1 a0b:0 b1b:1; do n=${v%%:*}; o=${v#*:}; MVO_BENCH_CTX_ORDER=$o timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/$n.json 2> $O/$n.err; pr $O/$n.json; done
+for v in separate:1 sibling:0 separate_b:1 sibling_b:0; do n=${v%%:*}; o=${v#*:}; MVO_BENCH_SEPARATE_CTX=$o timeout 200 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary > $O/$n.json 2> $O/$n.err; pr $O/$n.json; done
