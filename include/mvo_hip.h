@@ -60,7 +60,7 @@ int mvo_create(mvo_ctx** ctx, int device);
  * of its calls can be in progress at once (the bundle adjustment of frame i between its _begin and _end, the extraction of
  * frame i+1 meanwhile).  The HIP runtime spreads its streams over a fixed number of hardware queues in the order of their
  * creation; with two streams per sequence the extraction streams of 24 sequences ended up three to a queue on half of the
- * queues (measured: 3510 -> 3875 frames/s with sibling contexts).  Destroy the sibling before its parent. */
+ * queues (measured: 3443 / 3551 -> 3874 / 3910 frames/s with sibling contexts).  Destroy the sibling before its parent. */
 int mvo_create_sibling(mvo_ctx* parent, mvo_ctx** ctx);
 void mvo_destroy(mvo_ctx* ctx);
 const char* mvo_last_error(const mvo_ctx* ctx);
