@@ -221,8 +221,7 @@ void BaService::run() {
             // With the resident grid on the device this thread is its scheduler: it polls the completion words of the busy slots
             // (pinned host memory the device writes), hands finished windows back and posts queued windows to free slots.  A
             // slot is held exactly as long as the device works on it, not until the client comes back for the result.
-            bool posted_or_reaped = false;
-            if (resident && reap_locked()) posted_or_reaped = true;
+            if (resident) (void)reap_locked();
             while (!q.empty() && q.front()->ws->plan.service) {
                 // ---- resident solver service: no launch per window -- the job goes to a free slot of the resident grid
                 if (!flights.empty()) {  // (launch-path grids and the resident grid never share the device)
@@ -252,7 +251,6 @@ void BaService::run() {
                 mb->flags = (ba_u64)(j->ws->seq << 12) | ((ba_u64)(j->use_mfma ? 1 : 0) << 32) | ((ba_u64)(g_ba_same_l2 ? 1 : 0) << 33);
                 __atomic_store_n(&mb->seq, j->seq, __ATOMIC_RELEASE);  // (fields first, the sequence number last)
                 j->slot = sl;
-                posted_or_reaped = true;
             }
             if (resident && (q.empty() || q.front()->ws->plan.service)) {
                 // nothing for the launch path: keep polling while slots are busy; an idle grid is taken off after 3 ms

@@ -944,8 +944,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     for (int c = 0; c < 6; ++c) er.a0[c] = er.a1[c] = er.x[c] = 0;
     const bool have0 = SLOTS > 0 && tid < Eg, have1 = SLOTS > 1 && tid + BA_THREADS < Eg;
     const int e0_p = have0 ? W.epose[tid] : 0, e0_l = have0 ? W.ept[tid] : 0, e0_sl = have0 ? sSlot[e0_p] : -1;
-    const int e1_p = have1 ? W.epose[tid + BA_THREADS] : 0, e1_l = have1 ? W.ept[tid + BA_THREADS] : 0,
-              e1_sl = have1 ? sSlot[e1_p] : -1;
     constexpr int nslot = SLOTS;
     constexpr int e2_first = SLOTS == 0 ? 0 : BA_THREADS;  // first edge of the E2 area
 // BA_EDGES(BODY): BODY(el, rows, landmark, slot, e~ pair) for this thread's edges -- from its registers (edge `tid`), from the
@@ -965,6 +963,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         ee_[0] = q_[18];                                                     \
         ee_[1] = q_[19];                                                     \
         const int p1_ = W.epose[el_];                                        \
+        (void)p1_;                                                           \
         BODY(el_, r1_, W.ept[el_], sSlot[p1_], ee_)                          \
     } while (0);
 #define BA_EDGES(BODY)                                                       \

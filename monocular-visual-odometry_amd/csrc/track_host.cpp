@@ -17,16 +17,12 @@ struct mvo_map {
 
 struct mvo_track_state {
     // PnP: pairs, subsets, per-hypothesis results, refinement scratch
-    float *d_p3 = nullptr, *d_p2 = nullptr;
     double *d_Mg = nullptr, *d_mg = nullptr;
-    uint8_t* d_best_mask = nullptr;
     int cap_n = 0;
-    int32_t* d_subsets = nullptr;
     uint8_t* d_in = nullptr;  // pairs + subsets of a solvePnPRansac call, contiguous like their pinned staging (one upload)
     size_t cap_in = 0;
     double* d_models = nullptr;
     int32_t* d_counts = nullptr;
-    double* d_out = nullptr;
     int cap_h = 0;
     uint8_t* d_masks = nullptr;
     size_t cap_masks = 0;
@@ -46,8 +42,6 @@ struct mvo_track_state {
     std::vector<int32_t> em_counts;  // record of the last call: [iterations evaluated x 10]
     int32_t em_info[5] = {-1, -1, 0, 0, 0};
     // map points in view
-    int32_t* d_view_idx = nullptr;
-    float* d_view_px = nullptr;
     uint8_t* d_view_desc = nullptr;
     int32_t* d_view_n = nullptr;
     int cap_view = 0;
@@ -71,32 +65,23 @@ mvo_track_state* state(mvo_ctx* ctx) {
 int ensure_pnp(mvo_ctx* ctx, int n, int n_hyp) {
     mvo_track_state* s = state(ctx);
     if (n > s->cap_n) {
-        free_dev(s->d_p3);
-        free_dev(s->d_p2);
         free_dev(s->d_Mg);
         free_dev(s->d_mg);
-        free_dev(s->d_best_mask);
         s->cap_n = 0;
         const int cap = std::max(4096, n + n / 2);
-        MVO_HIP(hipMalloc((void**)&s->d_p3, (size_t)cap * 3 * sizeof(float)));
-        MVO_HIP(hipMalloc((void**)&s->d_p2, (size_t)cap * 2 * sizeof(float)));
         MVO_HIP(hipMalloc((void**)&s->d_Mg, (size_t)cap * 3 * sizeof(double)));
         MVO_HIP(hipMalloc((void**)&s->d_mg, (size_t)cap * 2 * sizeof(double)));
-        MVO_HIP(hipMalloc((void**)&s->d_best_mask, (size_t)cap));
         s->cap_n = cap;
     }
     if (n_hyp > s->cap_h) {
-        free_dev(s->d_subsets);
         free_dev(s->d_models);
         free_dev(s->d_counts);
         s->cap_h = 0;
         const int cap = std::max(128, n_hyp);
-        MVO_HIP(hipMalloc((void**)&s->d_subsets, (size_t)cap * 5 * sizeof(int32_t)));
         MVO_HIP(hipMalloc((void**)&s->d_models, (size_t)cap * 12 * sizeof(double)));
         MVO_HIP(hipMalloc((void**)&s->d_counts, (size_t)cap * sizeof(int32_t)));
         s->cap_h = cap;
     }
-    if (!s->d_out) MVO_HIP(hipMalloc((void**)&s->d_out, 16 * sizeof(double)));
     const size_t in_need = (size_t)n * 20 + (size_t)n_hyp * 20 + 64;
     if (in_need > s->cap_in) {
         free_dev(s->d_in);
@@ -195,19 +180,12 @@ bool invert_pose_lu(const double* T, double* out, int rows = 3) {
 void track_release(mvo_ctx* ctx) {
     mvo_track_state* s = ctx->track;
     if (!s) return;
-    free_dev(s->d_p3);
-    free_dev(s->d_p2);
     free_dev(s->d_Mg);
     free_dev(s->d_mg);
-    free_dev(s->d_best_mask);
     free_dev(s->d_in);
-    free_dev(s->d_subsets);
     free_dev(s->d_models);
     free_dev(s->d_counts);
-    free_dev(s->d_out);
     free_dev(s->d_masks);
-    free_dev(s->d_view_idx);
-    free_dev(s->d_view_px);
     free_dev(s->d_view_desc);
     free_dev(s->d_view_n);
     free_dev(s->d_tri_in);
@@ -305,13 +283,9 @@ int mvo_map_points_in_view(mvo_ctx* ctx, mvo_map* map, const double* T_w_c, doub
     MVO_HIP(hipSetDevice(ctx->device));
     mvo_track_state* s = state(ctx);
     if (map->n > s->cap_view) {
-        free_dev(s->d_view_idx);
-        free_dev(s->d_view_px);
         free_dev(s->d_view_desc);
         s->cap_view = 0;
         const int c = std::max(4096, map->n + map->n / 2);
-        MVO_HIP(hipMalloc((void**)&s->d_view_idx, (size_t)c * 4));
-        MVO_HIP(hipMalloc((void**)&s->d_view_px, (size_t)c * 8));
         MVO_HIP(hipMalloc((void**)&s->d_view_desc, (size_t)c * 32));
         s->cap_view = c;
     }
