@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -582,7 +583,32 @@ void service_wait(BaService& s, BaJob* jobs, int n) {
 
 // ------------------------------------------------------------------------------------------------ planning + staging
 // Builds the plan of a window and writes the upload image (descriptor included) into the pinned staging buffer.
+// MVO_HOST_TIMING=1: wall clock of the stages of ba_stage (printed every 200 windows to stderr; development aid)
+struct StageTimes {
+    double acc[4] = {0, 0, 0, 0};
+    long n = 0;
+    std::chrono::steady_clock::time_point t;
+    bool on = std::getenv("MVO_HOST_TIMING") != nullptr;
+    void start() {
+        if (on) t = std::chrono::steady_clock::now();
+    }
+    void lap(int k) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(now - t).count();
+        t = now;
+    }
+    void done() {
+        if (!on || ++n % 200) return;
+        std::fprintf(stderr, "[mvo ba_stage us/window] plan %.1f tables %.1f reserve %.1f image %.1f\n", acc[0] / 200, acc[1] / 200,
+                     acc[2] / 200, acc[3] / 200);
+        acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    }
+};
+static thread_local StageTimes g_stage_times;
+
 int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_trace) {
+    g_stage_times.start();
     BaPlan& P = ws.plan;
     P = BaPlan();
     const int F = p->n_poses, L = p->n_points;
@@ -752,6 +778,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
             G = next;
         }
     }
+    g_stage_times.lap(0);
     P.nsplit = nsplit;
     P.npar = npar;
     P.nseq = nseq;
@@ -849,6 +876,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.m_pts = pc.take((size_t)std::max(L, 1) * 24);
     P.m_trace = pc.take(sizeof(BaTraceRow) * BA_TRACE_MAX);
     P.pin_total = pc.off;
+    g_stage_times.lap(1);
     int r = ws_reserve(ctx, ws, P.total, P.pin_total);
     if (r) return r;
     const size_t sig[5] = {P.o_xp, P.o_xr, P.o_xh, P.o_xc, P.x_end};
@@ -861,6 +889,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         std::memcpy(ws.x_sig, sig, sizeof sig);
     }
 
+    g_stage_times.lap(2);
     // ---- upload image
     char* h = ws.pin;
     char* D = ws.dev;
@@ -949,6 +978,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.trace = want_trace ? (BaTraceRow*)(ws.pin + P.m_trace) : nullptr;
     std::memcpy(h + P.o_desc, &B, sizeof(B));
     std::memset(ws.pin + P.m_stats, 0, sizeof(BaStatsDev));
+    g_stage_times.lap(3);
+    g_stage_times.done();
     return MVO_OK;
 }
 
