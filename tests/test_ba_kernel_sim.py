@@ -234,3 +234,13 @@ def test_kernel_source_against_the_independent_sequential_oracle(mvo, O, simctx)
     bench window up to gauge (every landmark with >= 2 views within 1e-4) and the converged BA10-shaped window."""
     gpu_ba_tests.test_bench_window_matches_the_sequential_oracle_up_to_gauge(mvo, O, simctx)
     gpu_ba_tests.test_ba10_converged_against_the_sequential_oracle(mvo, O, simctx)
+
+
+def test_windows_of_changing_shape_on_one_context(mvo, O, simctx):
+    """One ctx, windows whose workgroup count / pose count change from call to call: the exchange areas sit at the head of the
+    pooled device block and are cleared whenever their layout changes (a granule is matched by its tag alone -- bytes that
+    held another window's data must never pass for one).  Every solve still equals the oracle bit for bit."""
+    shapes = [(5, 2000, 7), (4, 500, 70), (5, 2000, 8), (3, 40, 5), (7, 900, 31), (4, 500, 71), (5, 2000, 7)]
+    for F, L, seed in shapes:
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(F, L, seed), fix_points=False, max_iterations=3)
+    _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True, max_iterations=3)
