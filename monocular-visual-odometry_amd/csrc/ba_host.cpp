@@ -39,6 +39,7 @@ int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
 int g_ba_service = 1;     // throughput-mode windows of the 5-pose class and the resident solver service: 0 = never, 1 = while the
                           // offered load fills most of its slots (BaService::wanted), 2 = always
 int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
+int g_ba_uv_global = 1;     // 0 = measurements always in LDS (the form before the second half of round 3)
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 
@@ -65,7 +66,7 @@ struct Carver {
 // Everything the host computes for one window; offsets are relative to the start of the device block.
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
-        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0;
+        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0, uv_global = 0;
     bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
@@ -73,7 +74,7 @@ struct BaPlan {
     // device block layout
     size_t o_desc = 0, o_pin = 0, o_ptsin = 0, o_wpt = 0, o_wed = 0, o_wps = 0, o_ep = 0, o_el = 0, o_uv = 0, o_ptstart = 0,
            o_ptl = 0, o_eof = 0, o_dup = 0, o_slot = 0, o_sp = 0, o_pkt = 0, upload_end = 0, x_end = 0;
-    size_t o_stats = 0, o_pout = 0, o_pts = 0, o_xp = 0, o_xr = 0, o_xh = 0, o_xc = 0, total = 0;
+    size_t o_uvd = 0, o_stats = 0, o_pout = 0, o_pts = 0, o_xp = 0, o_xr = 0, o_xh = 0, o_xc = 0, total = 0;
     // pinned mirror layout (behind the upload staging)
     size_t m_stats = 0, m_poses = 0, m_pts = 0, m_trace = 0, pin_total = 0;
     bool runnable = true;  // false: nothing to optimise (no free vertex)
@@ -662,6 +663,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // up to 28 workgroups for the 5-keyframe window of the benchmark (~330 edges each); throughput mode: two windows per
     // XCD, up to 13 (~720 edges each, 6 CUs of an XCD left free), half the CUs per window at some 40 % more time per solve.  Larger windows get more
     // workgroups: a range holds at most 1024 edges and must fit the LDS.
+    static const bool plan_trace = std::getenv("MVO_BA_PLAN_TRACE") != nullptr;  // development aid: the planner's LDS fits
     static const int env_reserve = std::getenv("MVO_BA_XCD_RESERVE") ? std::atoi(std::getenv("MVO_BA_XCD_RESERVE")) : -1;
     // (measured with 24 sequences in flight: 2 x 14 workgroups per XCD leave the extraction kernels too little -- 3150
     // frames/s with the shards waiting for extraction --, 2 x 12 make the solves too slow -- 3550 --, 2 x 13 give 3800)
@@ -758,8 +760,15 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 P.npt = p->fix_points ? 1 : npt;
                 P.panel = (n + 1 > 32 || g_ba_block_solver) ? 1 : 0;
                 uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, pt_edges, maxEpose, nhp, G, p->fix_points);
-                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel);
+                // ranges of more than 512 edges (the throughput cut) keep their measurements in device memory: read once or
+                // twice per trial from L2, and 16 bytes per edge of LDS go to the U chunks instead (BA5 on 13 workgroups: two
+                // chunks where three were needed)
+                P.uv_global = (!all_lds && maxEg > BA_THREADS && g_ba_uv_global) ? 1 : 0;
+                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel, P.uv_global);
                 fits = P.lds <= BA_LDS_BUDGET;
+                if (plan_trace)
+                    std::fprintf(stderr, "[mvo plan] G %d rows_in_lds %d chunks %d pieces %d pt_passes %d maxEg %d maxLg %d uarea %zu B lds %zu B (budget %d) %s\n",
+                                 G, all_lds, nseq, npar, P.npt, maxEg, maxLg, uarea * 8, P.lds, BA_LDS_BUDGET, fits ? "fits" : "-");
                 // rows in LDS only while ONE chunk of U and ONE pass of the pose-block rows still fit next to them: with more
                 // chunks / passes the barriers cost more than the registers save (measured: 2.76 vs 2.41 ms on the BA5 window)
                 if (all_lds && g_ba_edge_rows != 0) {
@@ -868,6 +877,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.o_stats = cv.take(sizeof(BaStatsDev));
     P.o_pout = cv.take((size_t)F * 128);
     P.o_pts = cv.take((size_t)L * 24);
+    P.o_uvd = cv.take((size_t)E * 16 + 16);
     P.total = cv.off;
     Carver pc;
     pc.off = P.upload_end;
@@ -932,6 +942,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.nseq = nseq;
     B.uarea = (int)uarea;
     B.e2_edges = P.e2_edges;
+    B.uv_global = P.uv_global;
+    B.uv_dev = (double*)(D + P.o_uvd);
     B.npt = P.npt;
     B.panel = P.panel;
     B.slots = P.slots;

@@ -614,7 +614,8 @@ struct WgLds {
     double* pan;    // BA_PANEL_DOUBLES: panel rows of the block solver
     double* Rl;     // nlow + nhp (+16) packed entries of the summed Schur system (+ pose blocks)
     double* hpl;    // nhp own pose-block partials (waiting for the next Schur exchange, or the only ones when G = 1)
-    double* uv;     // maxEg x 2 (u and v in separate arrays)
+    double* uv;     // maxEg x 2 (u and v in separate arrays); not carved when the measurements stay in device memory:
+    double* uvg;    // this range's (u, v) pairs in device memory (BaDev::uv_global)
     double* pts;    // maxLg x 3
     double* bak;    // maxLg x 3
     double* Hll;    // maxLg x 6 (pitch BA_XS)
@@ -643,8 +644,9 @@ __device__ __forceinline__ double edge_error(const BaDev& B, const WgLds& W, int
     Xc[0] = R[0] * X0 + R[1] * X1 + R[2] * X2 + t[0];
     Xc[1] = R[3] * X0 + R[4] * X1 + R[5] * X2 + t[1];
     Xc[2] = R[6] * X0 + R[7] * X1 + R[8] * X2 + t[2];
-    const double e0 = W.uv[el] - (Xc[0] / Xc[2] * B.f + B.cx);
-    const double e1 = W.uv[B.maxEg + el] - (Xc[1] / Xc[2] * B.f + B.cy);
+    const double mu = B.uv_global ? W.uvg[2 * el] : W.uv[el], mv = B.uv_global ? W.uvg[2 * el + 1] : W.uv[B.maxEg + el];
+    const double e0 = mu - (Xc[0] / Xc[2] * B.f + B.cx);
+    const double e1 = mv - (Xc[1] / Xc[2] * B.f + B.cy);
     ew[0] = B.lc00 * e0 + B.lc01 * e1;
     ew[1] = B.lc11 * e1;
     return ew[0] * ew[0] + ew[1] * ew[1];
@@ -822,7 +824,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         W.hpl = d;
         d += B.nhp + 1;
         W.uv = d;
-        d += (size_t)B.maxEg * 2;
+        d += B.uv_global ? 0 : (size_t)B.maxEg * 2;
+        W.uvg = B.uv_dev + 2 * (size_t)e_lo;  // (uv_global: this range's measurements in device memory)
         W.pts = d;
         d += (size_t)B.maxLg * 3;
         // (sizes are zero in pose-only mode: every pointer stays an LDS address, no null pointers in this struct)
@@ -867,8 +870,13 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             W.ptl[el] = (short)pe;
             W.pti[pe] = (short)el;
         }
-        W.uv[el] = B.e_uv[2 * (size_t)(e_lo + el)];  // (u and v in separate arrays)
-        W.uv[B.maxEg + el] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
+        if (B.uv_global) {  // (thread `el % 512` is also the only reader of edge el's measurement)
+            W.uvg[2 * el] = B.e_uv[2 * (size_t)(e_lo + el)];
+            W.uvg[2 * el + 1] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
+        } else {
+            W.uv[el] = B.e_uv[2 * (size_t)(e_lo + el)];  // (u and v in separate arrays)
+            W.uv[B.maxEg + el] = B.e_uv[2 * (size_t)(e_lo + el) + 1];
+        }
     }
     for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = B.pts_in[3 * (size_t)pt_lo + i];
     for (int i = tid; i <= Lg; i += BA_THREADS) W.pts0[i] = (short)(B.pt_edge_start[pt_lo + i] - e_lo);

@@ -65,6 +65,8 @@ struct BaDev {
     int npt;     // passes of the landmark-block phase: pass h stages [X~ | e~] of the edges of the h-th slice of a range's landmarks
     int panel;   // 1: the solver area has the panel of the block LDL^T behind it
     int e2_edges;  // edges per range whose Jacobian rows live in LDS (all of them, or those behind the first 512)
+    int uv_global;  // 1: the measurements (u, v) of a range stay in device memory (read once per trial) instead of LDS
+    double* uv_dev;  // their device copy (E x 2; a window of the resident service has its inputs in pinned host memory)
     int slots;   // kernel flavour the plan was made for: 0 = all rows in LDS, 1 / 2 = first 512 edges in registers
     int ldu;     // rows of the U buffer = 16 NT
     int nhp;     // pose-block exchange entries per workgroup = BA_HP nfree + 1 (last: max |diag H_ll|)
@@ -161,9 +163,9 @@ __host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int max_p
     return a;
 }
 __host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int npar, int nfree, int maxEg,
-                                               int maxLg, int fix_points, size_t uarea, int e2_edges, int panel) {
-    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar, panel) + (size_t)nlow + 2 * (size_t)nhp + 17 + (size_t)maxEg * 2 +
-               (size_t)maxLg * 3;
+                                               int maxLg, int fix_points, size_t uarea, int e2_edges, int panel, int uv_global = 0) {
+    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar, panel) + (size_t)nlow + 2 * (size_t)nhp + 17 +
+               (uv_global ? 0 : (size_t)maxEg * 2) + (size_t)maxLg * 3;
     d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
     if (!fix_points) d += (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3);
     d += uarea + (size_t)e2_edges * BA_E2S;
