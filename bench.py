@@ -7,7 +7,9 @@
 One rank per GPU.  Every rank owns `--streams` independent sequence shards (S640, seed 1234 + shard id), each
 driven by its own host thread through the native frame loop (host/driver/frame_loop.cpp): the path is serial inside
 a sequence and embarrassingly parallel across sequences, so this is how one GPU is filled.  A "step" =
-one frame of every shard of the rank:
+`--frames-per-step` (default 10) consecutive frames of every shard of the rank (one batch of synthetic input: 240 frames
+with 24 shards; the timed region of the driver's `--steps 20` is then ~1 s instead of 0.13 s, where the start and the
+tail of the region -- shards entering and leaving one after the other -- weighed 8 %), per frame:
   extract (image already resident in HBM) -> descriptors stay in HBM -> match against the previous frame's descriptors
   (2-NN Hamming + Lowe ratio + de-dup) -> bundle adjustment of a NEW BA5 window (5 poses / 2000 landmarks / ~10k edges,
   50 LM iterations): every frame the window is marshalled from Frame / MapPoint objects into pointer lists as
@@ -48,6 +50,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=24, help="sequence shards in flight per GPU")
+    ap.add_argument("--frames-per-step", type=int, default=10,
+                    help="consecutive frames every shard advances in one step (a step = one batch: streams x this many frames)")
     ap.add_argument("--ba", default="full", choices=["full", "pose_only"],
                     help="full = points + poses free (reference is_fix_map_pts=false branch, no vertex fixed)")
     ap.add_argument("--ba-mode", default="rebuild", choices=["rebuild", "resident", "none"],
@@ -330,6 +334,49 @@ def pmc_traffic(kernel):
     return best
 
 
+def kernel_resources(kernel):
+    """Registers / spills / scratch of `kernel` as the compiler reported them for the shipped build
+    (profiles/r*_kernel_resources.csv, written by tools/kernel_resources.py from hipcc -Rpass-analysis=kernel-resource-usage
+    over csrc/).  None if absent."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_resources.csv"))):
+        try:
+            cols = None
+            for line in open(path):
+                if line.startswith("#"):
+                    continue
+                f = [x.strip() for x in line.rstrip("\n").split(";")]
+                if cols is None:
+                    cols = f
+                    continue
+                if f[0] == kernel:
+                    best = dict(zip(cols[1:], [int(x) if x.lstrip("-").isdigit() else x for x in f[1:]]), source=os.path.relpath(path, ROOT))
+        except (OSError, ValueError, IndexError):
+            pass
+    return best
+
+
+def pmc_mfma_busy(kernel):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs of the grid) of `kernel` from the newest committed PMC pass
+    (profiles/r*_pmc_mfma_busy.txt; the summary's header names the command).  (fraction, source) or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_mfma_busy.txt"))):
+        try:
+            cols = None
+            for line in open(path):
+                if line.startswith("#"):
+                    continue
+                f = [x.strip() for x in line.split(",")]
+                if cols is None:
+                    cols = {name: i for i, name in enumerate(f)}
+                    continue
+                if f[0] == kernel:
+                    best = (float(f[cols["SQ_VALU_MFMA_BUSY_CYCLES"]]), float(f[cols["GRBM_GUI_ACTIVE"]]), os.path.relpath(path, ROOT))
+        except (OSError, ValueError, KeyError, IndexError):
+            pass
+    return best
+
+
 class GpuEnv:
     """What main() needs from the machine: the process group, the device, barriers and shards.  tests/ substitute a CPU
     stand-in (gloo, stub shards) to execute the N > 1 control flow without a GPU."""
@@ -373,21 +420,24 @@ def run_benchmark(args, env):
         if dist is not None:
             dist.barrier()
 
-    run_steps(shards, args.warmup)
+    fps_ = max(1, args.frames_per_step)
+    nframes = args.steps * fps_          # frames per shard inside the timed region
+    run_steps(shards, args.warmup * fps_)
     st_before = [s.state() for s in shards]
     shards[0].ctx.ba_launch_stats(reset=True)
-    elapsed_local = timed_run(shards, args.steps, barrier)
+    elapsed_local = timed_run(shards, nframes, barrier)
     launch = shards[0].ctx.ba_launch_stats()
     launch["service_ms"] = shards[0].ctx.ba_service_times()
     launch["elapsed_ms"] = elapsed_local * 1e3
     st_after = [s.state() for s in shards]
     elapsed = max_over_ranks(dist, elapsed_local, env.device)
-    frames_total = world * args.streams * args.steps
+    frames_total = world * args.streams * nframes
     # ---- the one collective: gather the trajectories (frames x 12 f64 per shard)
-    traj = np.stack([np.stack(s.traj[-args.steps:]) for s in shards])           # [streams, steps, 12]
+    traj = np.stack([np.stack(s.traj[-nframes:]) for s in shards])           # [streams, frames, 12]
     traj_all = gather_trajectories(dist, traj, env.device)
-    assert traj_all.shape == (world, args.streams, args.steps, 12) and np.isfinite(traj_all).all()
+    assert traj_all.shape == (world, args.streams, nframes, 12) and np.isfinite(traj_all).all()
     return dict(world=world, rank=rank, dist=dist, shards=shards, pipeline=pipeline, elapsed=elapsed, value=frames_total / elapsed,
+                nframes=nframes,
                 launch=launch, st_before=st_before, st_after=st_after, traj_all=traj_all)
 
 
@@ -445,18 +495,31 @@ def main(argv=None, env=None):
             # hand-offs are 8-byte accesses, a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported
             # uncorrected
             roof["traffic"], roof["traffic_source"] = (tr[0], tr[1]) if tr else (None, None)
-            per_kernel["k_ba_lm"] = (launch.get("elapsed_ms", 0.0) if resident else launch["ms"]) / max(args.steps * args.streams, 1)
+            # what the compiler gave the dominant kernel (build remarks of the shipped sources) and how busy its matrix cores
+            # were in the single-window PMC pass (SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the CUs the window occupies)
+            roof["resources"] = kernel_resources("k_ba_service<32,2>" if resident else "k_ba_lm<false,32,1>")
+            mb = pmc_mfma_busy("k_ba_lm")
+            if mb:
+                wgs = 28  # the profiled single-window launch: latency cut, one workgroup per CU, 4 SIMDs each
+                roof["mfma_busy"] = round(mb[0] / max(mb[1] * wgs * 4, 1.0), 4)
+                roof["mfma_busy_source"] = mb[2] + " (single-window launch, %d CUs)" % wgs
+            per_kernel["k_ba_lm"] = (launch.get("elapsed_ms", 0.0) if resident else launch["ms"]) / max(R["nframes"] * args.streams, 1)
         else:
             roof = None
         # ---- per-kernel durations of the other kernels: HIP events on the ctx stream of ONE shard running the serial loop
-        # with nothing else on the GPU (next to a running solver launch a kernel's blocks wait for its CUs -- 2 waves x
-        # 256 VGPRs per SIMD -- and the events would show the wait, not the kernel)
-        kshard = env.make_shard(shard_ids(rank, args.streams)[0], args, args.ba_mode, False,
-                                frames=(s0.host_frames, s0.dev_frames), pool=s0.pool)
+        # with NOTHING else on the GPU: no solver window is submitted (--ba-mode none for this shard) and the resident solver
+        # grid of the headline run has left (mvo_synchronize parks it; next to a resident grid a kernel's blocks wait for its
+        # CUs and the events show the wait, not the kernel -- the round-3 line carried 3x the rocprofv3 durations that way)
+        for s_ in shards:
+            s_.ctx.synchronize()
+        time.sleep(0.02)
+        env.sync()
+        kshard = env.make_shard(shard_ids(rank, args.streams)[0], args, "none", False,
+                                frames=(s0.host_frames, s0.dev_frames), pool=s0.pool, ba_cut="latency")
         kshard.run(3)
         kshard.ctx.profile_enable(True)
         kshard.ctx.profile_reset()
-        nprof = min(20, max(args.steps, 5))
+        nprof = 20
         kshard.run(nprof)
         prof = kshard.ctx.profile_get()
         kshard.ctx.profile_enable(False)
@@ -483,7 +546,7 @@ def main(argv=None, env=None):
             frames0 = (s0.host_frames, s0.dev_frames)
             one = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", True, frames=frames0, pool=s0.pool, ba_cut="latency")
             one.run(max(5, args.warmup))
-            nsingle = max(30, args.steps)
+            nsingle = max(100, min(R["nframes"], 300))
             dt = timed_run([one], nsingle, env.sync)
             secondary["single_sequence_fps"] = nsingle / dt
             secondary["single_sequence_note"] = ("1 shard, latency cut of the window (mvo_ba_set_mode LATENCY: 28 workgroups), extraction+matching "
@@ -505,7 +568,7 @@ def main(argv=None, env=None):
             res = [env.make_shard(s.id, args, "resident", False, frames=(s.host_frames, s.dev_frames), pool=s.pool[:1])
                    for s in shards[:12]]
             run_steps(res, max(5, args.warmup))
-            nres = max(20, args.steps // 2)
+            nres = max(20, R["nframes"] // 4)
             dt = timed_run(res, nres, env.sync)
             secondary["resident_window_fps"] = len(res) * nres / dt
             secondary["resident_window_note"] = ("round-1 mode, %d shards, serial frame loop: ONE pre-uploaded window re-solved "
@@ -518,7 +581,7 @@ def main(argv=None, env=None):
                 vs = [env.make_shard(s.id, args, "rebuild", pipeline, frames=(s.host_frames, s.dev_frames), pool=s.pool, **kw)
                       for s in shards]
                 run_steps(vs, max(5, args.warmup))
-                nv = max(20, args.steps // 2)
+                nv = max(40, R["nframes"] // 4)
                 dt_ = timed_run(vs, nv, env.sync)
                 inl = vs[0].state().n_inliers
                 for v_ in vs:
@@ -565,7 +628,9 @@ def main(argv=None, env=None):
                                    % (args.width, args.width, args.height, args.max_kp + 1, args.ba_poses, args.ba,
                                       len(s0.pool), args.ba_poses, args.ba_points, int(E_avg))
                        if args.ba_mode == "rebuild" else "S%d extract+match, BA mode %s" % (args.width, args.ba_mode),
-                       "streams_per_gpu": args.streams, "frames_per_step": args.streams * world,
+                       "streams_per_gpu": args.streams, "frames_per_step": args.streams * world * max(1, args.frames_per_step),
+                       "step": "%d consecutive frames of each of the %d sequence shards (timed region = %d frames)"
+                               % (max(1, args.frames_per_step), args.streams * world, args.streams * world * R["nframes"]),
                        "frame_loop": "native (host/driver/frame_loop.cpp)" + (", extraction of frame i+1 overlapped with BA of frame i (a ctx + its sibling per sequence, THROUGHPUT mode when > 8 sequences)" if pipeline else ""),
                        "keypoints": st.n_kp, "matches": st.n_match,
                        "ba_trials_per_solve": trials / max(solves, 1),

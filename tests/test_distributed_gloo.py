@@ -57,15 +57,16 @@ WORKER = textwrap.dedent("""
         def init_process_group(self, d): d.init_process_group("gloo")
         def sync(self): pass
         def make_shard(self, sid, args, ba_mode, pipeline, **kw): return StubShard(sid)
-    args = bench.parse(["--gpus", str(world), "--steps", "4", "--warmup", "2", "--streams", "3"])
+    # a step = --frames-per-step consecutive frames of every shard: 4 steps x 3 frames timed after 2 x 3 warm-up frames
+    args = bench.parse(["--gpus", str(world), "--steps", "4", "--warmup", "2", "--streams", "3", "--frames-per-step", "3"])
     R = bench.run_benchmark(args, StubEnv())
-    assert R["world"] == world and R["traj_all"].shape == (world, 3, 4, 12)
+    assert R["world"] == world and R["nframes"] == 12 and R["traj_all"].shape == (world, 3, 12, 12)
     for r in range(world):
         for s_ in range(3):
             sid = r * 3 + s_
-            assert np.array_equal(R["traj_all"][r, s_, :, 0], 1000.0 * sid + np.arange(2, 6)), R["traj_all"][r, s_, :, 0]
+            assert np.array_equal(R["traj_all"][r, s_, :, 0], 1000.0 * sid + np.arange(6, 18)), R["traj_all"][r, s_, :, 0]
     assert R["elapsed"] >= 0.01 * world                                    # MAX over ranks
-    assert abs(R["value"] - world * 3 * 4 / R["elapsed"]) < 1e-9           # whole-job aggregate
+    assert abs(R["value"] - world * 3 * 12 / R["elapsed"]) < 1e-9          # whole-job aggregate
     import torch.distributed as dist2
     dist2.barrier()
     dist2.destroy_process_group()
