@@ -473,6 +473,8 @@ def main(argv=None, env=None):
                 roof.update(kernel="k_ba_service (resident k_ba_lm body)", avg_launch_ms=busy_ms, launches=max(1, launch.get("resident_grid_starts", 1)),
                             windows_per_launch=launch["windows"], avg_window_ms=avg_ms,
                             windows_in_flight=launch["ms"] / max(busy_ms, 1e-9),
+                            shader_clock_ghz_under_load=round(launch.get("resident_cycles", 0.0) / max(launch["ms"] * 1e6, 1e-9), 3),
+                            avg_window_kcycles=round(launch.get("resident_cycles", 0.0) / max(launch["windows"], 1) / 1e3, 1),
                             algorithmic_per_launch=flops, trials_per_solve=trials / max(solves, 1),
                             launch_thread_ms=launch.get("service_ms"), timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2),
                             note="the resident grid is launched once and spans the timed region: duration = the region, work = the "

@@ -259,6 +259,9 @@ int mvo_debug_ba_service_times(int device, double* out5);
  * the last reset of mvo_ba_launch_stats (those windows count as one launch each there, `ms` = their solve times on the
  * device clock). */
 int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_starts);
+/* Shader-clock cycles the resident grid spent on those windows (sum over the windows, workgroup 0 of each, load to write-back;
+ * divided by their `ms` this is the clock the solver ran at under load). */
+int mvo_debug_ba_resident_cycles(int device, double* shader_cycles);
 /* Test hook: replays the resident solver service's demand estimate (see mvo_ba_set_mode) over n submission times (seconds,
  * ascending); decisions[i] = 1 if a window submitted at times[i] would go to the resident grid.  Returns the number of
  * changes of mind.  Touches no device. */

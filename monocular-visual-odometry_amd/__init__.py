@@ -467,9 +467,12 @@ class Context:
     def ba_launch_stats(self, reset=False):
         a, b, ms = C.c_longlong(), C.c_longlong(), C.c_double()
         rw, rs = C.c_longlong(), C.c_longlong()
+        rc = C.c_double()
         self.lib.mvo_debug_ba_resident_stats(self.device, C.byref(rw), C.byref(rs))   # (before a reset clears them)
+        self.lib.mvo_debug_ba_resident_cycles(self.device, C.byref(rc))
         self.lib.mvo_ba_launch_stats(self.device, C.byref(a), C.byref(b), C.byref(ms), int(reset))
-        return dict(launches=a.value, windows=b.value, ms=ms.value, resident_windows=rw.value, resident_grid_starts=rs.value)
+        return dict(launches=a.value, windows=b.value, ms=ms.value, resident_windows=rw.value, resident_grid_starts=rs.value,
+                    resident_cycles=rc.value)
 
     def ba_service_times(self):
         """Wall-clock of the BA launch thread's stages since the last stats reset (ms)."""

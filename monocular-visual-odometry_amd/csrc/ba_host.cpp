@@ -166,6 +166,7 @@ struct BaService {
     bool park_requested = false;    // mvo_synchronize: take an idle resident grid off the device now
     std::condition_variable cv_slot;
     long long resident_jobs = 0, resident_starts = 0;
+    double resident_cycles = 0;  // shader cycles of the windows the resident grid solved (sum; with `ms`: the clock under load)
     // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
     // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
     // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
@@ -417,6 +418,7 @@ bool BaService::reap_locked() {
         if (!j || __atomic_load_n(&mail[sl].done_seq, __ATOMIC_ACQUIRE) < j->seq) continue;
         const BaStatsDev* sd = (const BaStatsDev*)(j->ws->pin + j->ws->plan.m_stats);
         j->ms = (float)(sd->solve_ticks * 1e-5);  // 100 MHz ticks -> ms
+        resident_cycles += (double)sd->phase[14];
         j->batch = 1;
         j->done = true;
         slot_job[sl] = nullptr;
@@ -448,6 +450,8 @@ int BaService::start_resident() {
     a.arrived = d_cmd + 8 * BA_SERVICE_SLOTS;
     a.nslots = BA_SERVICE_SLOTS;
     a.wgs_per_slot = wgs_per_slot;
+    static const int env_map = std::getenv("MVO_BA_SLOT_MAP") ? std::atoi(std::getenv("MVO_BA_SLOT_MAP")) : 0;
+    a.slot_map = BA_SERVICE_SLOTS == 16 ? env_map : 0;
     ba_u64 init[9 * BA_SERVICE_SLOTS] = {0};
     for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) {
         a.first_seq[sl] = slot_seq[sl];
@@ -1244,9 +1248,10 @@ void ba_service_park(int device) {
     // wait (bounded) until the grid is gone or has work again
     sp->cv_done.wait_for(lk, std::chrono::milliseconds(50), [&] { return !sp->resident || sp->slots_busy > 0 || !sp->q.empty(); });
 }
-void ba_resident_stats(int device, long long* windows, long long* grid_starts) {
+void ba_resident_stats(int device, long long* windows, long long* grid_starts, double* cycles) {
     if (windows) *windows = 0;
     if (grid_starts) *grid_starts = 0;
+    if (cycles) *cycles = 0;
     if (device < 0 || device >= 16) return;
     BaService* sp;
     {
@@ -1257,6 +1262,7 @@ void ba_resident_stats(int device, long long* windows, long long* grid_starts) {
     std::lock_guard<std::mutex> lk(sp->m);
     if (windows) *windows = sp->resident_jobs;
     if (grid_starts) *grid_starts = sp->resident_starts;
+    if (cycles) *cycles = sp->resident_cycles;
 }
 void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
     if (launches) *launches = 0;
@@ -1279,6 +1285,7 @@ void ba_launch_stats(int device, long long* launches, long long* windows, double
         s.ms = 0;
         s.t_idle = s.t_batch = s.t_launch = s.t_sync = s.t_post = 0;
         s.resident_jobs = s.resident_starts = 0;
+        s.resident_cycles = 0;
     }
 }
 

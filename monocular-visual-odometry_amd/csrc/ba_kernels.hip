@@ -784,7 +784,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, terminated = 0, error = 0;
     long long ph[PROF ? BA_NPHASE : 1] = {0};
-    const long long ph_start = PROF ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const long long ph_start = (long long)__builtin_amdgcn_s_memtime();
     // ---- initial robust chi2: all-to-all through the chi2 slots (tag 1 of the B series)
     double currentChi;
     bool same_l2 = false;  // all workgroups of the window on one XCD (found out in the first exchange)
@@ -1689,6 +1689,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             ph[11] = (long long)__builtin_amdgcn_s_memtime() - ph_start;
             for (int i = 0; i < BA_NPHASE; ++i) st.phase[i] = ph[PROF ? i : 0];
         }
+        else st.phase[14] = (long long)__builtin_amdgcn_s_memtime() - ph_start;  // shader cycles of the solve (with solve_ticks: the clock it ran at)
         st.phase[15] = same_l2 ? 1 : 0;
         st.solve_ticks = (long long)(__builtin_amdgcn_s_memrealtime() - t_begin);
         if (PROF && B.trace)
@@ -1719,8 +1720,20 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
 // never outlive its host).
 template <int NR, int SLOTS>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
-    const int slot = blockIdx.x % a.nslots;
-    const int g = blockIdx.x / a.nslots;
+    int slot = blockIdx.x % a.nslots;
+    int g = blockIdx.x / a.nslots;
+    if (a.slot_map == 1) {
+        // neighbouring workgroups of an XCD (block b lands on XCD b % 8; q = its rank there) belong to the SAME window: two
+        // CUs share an instruction cache, and the solver's code (87 KB) does not fit it twice
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, W = a.wgs_per_slot, We = W & ~1;
+        if (q < 2 * We) {
+            slot = xcd + 8 * ((q >> 1) & 1);
+            g = ((q >> 2) << 1) | (q & 1);
+        } else {
+            slot = xcd + 8 * (q - 2 * We);
+            g = W - 1;
+        }
+    }
     __shared__ unsigned long long sJob[4];  // seq, desc, (tag0 | use_mfma << 32), stop
     volatile BaMail* mail = a.mail + slot;
     u64* cmd = a.cmd + 8 * (size_t)slot;    // device memory: {seq, desc, flags, stop} republished by workgroup 0

@@ -56,43 +56,41 @@ extern __shared__ __attribute__((aligned(16))) double ba_dyn_lds[];
 #endif
 
 // ------------------------------------------------------------------------------------------------ reduced solve
-// Solves the reduced (n x n, n <= 30) system with ONE wave.  SL (LDS, row pitch 33) holds row i = S[i][0..i] for i < n and
-// row 31 = the rhs g^T: the lower triangle of the symmetric matrix [[S, g], [g^T, .]], embedded into 31 rows (identity
-// rows behind n: exact no-ops).  Right-looking LDL^T without pivoting, canonical arithmetic per step j:
-//   r = 1 / d_j,  l_i = c_i r,  a_ik = fma(-l_i, c_k, a_ik)   (c = column j).
-// Lane (i = lane & 31, h = lane >> 5) keeps the entries k = 2 m + h of row i in registers (16 per lane: both halves of the
-// wave work on a row).  A single wave issues in order, and a step is bound by its instruction count and by three hand-offs;
-// the form below (round 4) keeps them off the path from one pivot to the next:
-//   * the pivot d_{j+1} and the entry c_{j+2} of the freshly finished column j + 1 that the NEXT step's first update needs
-//     travel as scalars (v_readlane): the chain pivot -> reciprocal -> l -> first update of the next column -> next pivot
-//     never waits for LDS;
-//   * a lane's c_i of the other half's column comes through v_permlane32_swap (vector ALU) instead of an LDS read-back;
-//   * the finished column still goes through LDS for the bulk of the next step's updates (15 .. 1 per lane), de-interleaved
-//     (even rows | odd rows) so that a lane's operands are consecutive and come two per read; they are fetched a whole
-//     step before they are used.
-// The rhs row comes out as z = D^-1 L^-1 g.  L is written transposed (row j = column j of L) over SL; x = L^-T z by a
-// column sweep with v_readlane broadcasts: x_j = fma(-l_ij, x_i, x_j) for i = n-1 .. j+1.  Returns 0 when a pivot is not
-// usable (g2o: LDLT "not positive" -> the step is rejected).  Same operations per entry, in the same order, as the
-// round-3 form (tests/sim and the bitwise GPU tests hold both to the blocked oracle).
+// Solves the reduced (n x n) system with ONE wave.  SL (LDS, row pitch NR + 1) holds row i = S[i][0..i] for i < n and
+// row n = the rhs g^T: the lower triangle of the symmetric matrix [[S, g], [g^T, .]].  Right-looking LDL^T without
+// pivoting, canonical arithmetic per step j: r = 1 / d_j, l_i = c_i r, a_ik = fma(-l_i, c_k, a_ik) (c = column j).
+// Lane i keeps row i in registers; the system is embedded into NR - 1 rows (identity rows behind n: exact no-ops) with
+// the rhs as row NR - 1, so that the whole elimination is straight-line code: at step j every lane first finishes
+// its entry of column j + 1, parks it in LDS and fetches the pivot with v_readlane -- the division of step j + 1 and
+// the LDS round trip of its column overlap with the remaining updates of step j.  The rhs row comes out as
+// z = D^-1 L^-1 g.  L is written transposed (row j = column j of L) over SL; x = L^-T z by a column sweep with
+// v_readlane broadcasts: x_j = fma(-l_ij, x_i, x_j) for i = n-1 .. j+1.  Returns 0 when a pivot is not positive
+// (g2o: LDLT "not positive" -> the step is rejected).
+// A step is bound by the ~45 instructions ONE wave has to issue for it (8999 cycles per solve = 290 per pivot,
+// tools/probes/solve_probe.hip).  Round 4 tried to take the LDS hand-off of the finished column off the path from one pivot to
+// the next -- pivot and next-column entry forwarded as scalars (three v_readlane pairs per step), the other half's c_i through
+// v_permlane32_swap -- : bit-identical and SLOWER (13016 cycles): the extra scalar moves and exec-masked updates cost more
+// issue slots than the hand-off costs latency.  That variant lives on in the probe for the record.
+// The 32-row flavour uses both halves of the wave: lane = (row i = lane & 31, half h = lane >> 5) keeps the columns
+// k = 2 m + h of its row (16 registers instead of 32), so that the prefetched column of the next step fits the register
+// file next to the one in use, and a step costs half the fused multiply-adds per lane.  Same arithmetic per entry.
 __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int lane) {
-    constexpr int R = 31, P = 33, H = 16;
+    constexpr int NR = 32, R = 31, P = 33, H = 16;
     double* SL = ba_dyn_lds + sl_off;
-    double* colbuf = ba_dyn_lds + cb_off;  // 2 buffers x 32: the finished column, rows (even | odd)
+    double* colbuf = ba_dyn_lds + cb_off;  // 2 buffers x (2 halves x 32 rows)
     double* xout = colbuf + 128;
     const int i = lane & 31, h = lane >> 5;
-    const int pos = (i & 1) * 16 + (i >> 1);  // where row i's entry of a column goes
     int ok = 1;
     double a[H];
 #pragma unroll
     for (int m = 0; m < H; ++m) a[m] = SL[i * P + 2 * m + h];
     double ck[2][H];
     // column 0 lives in half 0, register 0
+    colbuf[h * 32 + i] = a[0];
     double d = readlane_d(a[0], 0);
-    double sc = readlane_d(a[0], 1);  // c_1: row 1's entry of column 0
-    if (h == 0) colbuf[pos] = a[0];
-    double ci = half_bcast_d(a[0], 0);
+    double ci = colbuf[i];
 #pragma unroll
-    for (int m = 0; m < H; ++m) ck[0][m] = colbuf[h * 16 + m];
+    for (int m = 0; m < H; ++m) ck[0][m] = colbuf[2 * m + h];
     double r = ba_rcp_pivot(d);
     ok &= (d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX);
     double l = ci * r;
@@ -100,19 +98,16 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
     for (int j = 0; j < R; ++j) {
         const int cur = j & 1, nxt = cur ^ 1;
         const int jn = j + 1, hn = jn & 1, mn = jn >> 1;
-        double cin = 0, scn = 0;
-        // region A: finish column j + 1 (its entries live in half hn, register mn), send pivot and next entry ahead as
-        // scalars, hand the column to the other lanes
+        double cin = 0;
+        // region A: finish the entries of column j + 1, hand them to the other lanes, start fetching that column
         if (jn < R) {
-            if (h == hn) a[mn] = __builtin_fma(-l, sc, a[mn]);
+            a[mn] = __builtin_fma(-l, ck[cur][mn], a[mn]);  // (half hn: column j + 1; other half: column j or j + 2)
+            colbuf[nxt * 64 + h * 32 + i] = a[mn];
             d = readlane_d(a[mn], jn + 32 * hn);
-            scn = readlane_d(a[mn], jn + 1 + 32 * hn);  // c_{j+2}: row j + 2's entry of column j + 1
-            if (h == hn) colbuf[nxt * 32 + pos] = a[mn];
-            cin = half_bcast_d(a[mn], hn);
-            // operands of the next step: the other half's register mn' when it holds column j + 3, and everything behind
-            const int mq = (jn + 1) >> 1;  // = mn' of the next step
+            cin = colbuf[nxt * 64 + hn * 32 + i];
 #pragma unroll
-            for (int m = mq; m < H; ++m) ck[nxt][m] = colbuf[nxt * 32 + h * 16 + m];
+            for (int m = mn + 1; m < H; ++m) ck[nxt][m] = colbuf[nxt * 64 + hn * 32 + 2 * m + h];
+            if (mn + 1 < H || true) ck[nxt][mn] = colbuf[nxt * 64 + hn * 32 + ((2 * mn + h) & 31)];
         }
         __builtin_amdgcn_sched_barrier(0);
         // region B: the rest of step j; the division of step j + 1 rides along
@@ -121,8 +116,6 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
             rn = ba_rcp_pivot(d);
             ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (jn >= n);
         }
-        // (the half that does not hold column j + 1 in register mn holds column j -- finished -- or column j + 2 there)
-        if (hn == 0 && h == 1) a[mn] = __builtin_fma(-l, ck[cur][mn], a[mn]);
 #pragma unroll
         for (int m = mn + 1; m < H; ++m) a[m] = __builtin_fma(-l, ck[cur][m], a[m]);
         SL[j * P + i] = l;  // column j of L (entries of the rows <= j are never read)
@@ -130,11 +123,10 @@ __device__ __forceinline__ int solve_wave_32(int sl_off, int cb_off, int n, int 
         __builtin_amdgcn_sched_barrier(0);
         r = rn;
         l = ln;
-        sc = scn;
     }
-    // back-substitution: lane j (< 31) owns x_j  (intra-wave hand-off of L^T through LDS)
+    // back-substitution: lane j (< 31) owns x_j  (intra-wave hand-off of L^T through LDS, see solve_wave)
     __builtin_amdgcn_wave_barrier();
-    double cl[32];
+    double cl[NR];
     const int lj = i < R ? i : 0;
 #pragma unroll
     for (int q = 1; q < R; ++q) cl[q] = SL[lj * P + q];

@@ -130,6 +130,7 @@ struct BaServiceArgs {
     ba_u64* arrived;       // device memory: one counter per slot
     ba_u64 first_seq[BA_SERVICE_SLOTS];  // seq of every slot at launch
     int nslots, wgs_per_slot;
+    int slot_map;  // 0: slot = block % nslots; 1: pairs of neighbouring workgroups of an XCD share a slot (16 slots, 8 XCDs)
 };
 
 // ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner

@@ -107,6 +107,12 @@ int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_
     return MVO_OK;
 }
 
+int mvo_debug_ba_resident_cycles(int device, double* shader_cycles) {
+    if (!shader_cycles) return MVO_ERR_INVALID;
+    ba_resident_stats(device, nullptr, nullptr, shader_cycles);
+    return MVO_OK;
+}
+
 int mvo_ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
     if (device < 0 || device > 15) return MVO_ERR_INVALID;
     ba_launch_stats(device, launches, windows, ms, reset);

@@ -245,6 +245,6 @@ int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg
 void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset);
 void ba_service_times(int device, double* out5);
 void ba_service_park(int device);
-void ba_resident_stats(int device, long long* windows, long long* grid_starts);
+void ba_resident_stats(int device, long long* windows, long long* grid_starts, double* cycles = nullptr);
 
 #endif
