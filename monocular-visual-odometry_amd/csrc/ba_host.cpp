@@ -28,7 +28,7 @@
 int ba_kernel_set_lds_limit();
 hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr, int slots);
 int ba_solver_class(int n);
-hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream);
+hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream, int out_of_line);
 
 int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
@@ -462,7 +462,8 @@ int BaService::start_resident() {
     }
     if (hipMemcpyAsync(d_cmd, init, sizeof(init), hipMemcpyHostToDevice, resident_stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(resident_stream) != hipSuccess) return -1;
-    if (ba_service_launch(a, resident_stream) != hipSuccess) return -1;
+    static const int env_ool = std::getenv("MVO_BA_SERVICE_OOL") ? std::atoi(std::getenv("MVO_BA_SERVICE_OOL")) : 0;
+    if (ba_service_launch(a, resident_stream, env_ool) != hipSuccess) return -1;
     resident = true;
     ++resident_starts;
     return 0;

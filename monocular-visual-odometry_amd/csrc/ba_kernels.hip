@@ -681,7 +681,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     double* const sSol = sDx + 6 * B.F;           // 6 F (+ rhs slot)
     double* const sX = dyn + ba_pose_doubles(B.F);  // 2 G
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
-    __shared__ int sSliceLo[BA_MAX_POSES], sSliceHi[BA_MAX_POSES], sSliceOff[BA_MAX_POSES];  // pose-block chains: slices of a pass
+    __shared__ short sSlc[3][BA_HP_PASSES][BA_MAX_POSES];  // pose-block chains: slices of the staging passes (below)
     __shared__ int sFlag[4];
     __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
     if (threadIdx.x == 0) sFlag[2] = 0;
@@ -865,6 +865,56 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     if (nslot == 0)                                                          \
         for (int el0_ = tid; el0_ < Eg; el0_ += BA_THREADS) BA_EDGE_FROM_LDS(BODY, el0_)
 
+    // ---- pose-block chains: how the rows [A~ | e~] are staged (constant for the whole solve, made once).  Pass q of
+    // `hp_npass` holds slice q of EVERY pose: edges [s_p + q h_p, min(e_p, s_p + (q + 1) h_p)), h_p = ceil(n_p / npass) rounded up
+    // to even (a slice is whole MFMA steps), the slices of a pass packed back to back in the staging area.  sSlc[0 / 1 / 2][q][p] =
+    // first edge / one past the last edge / place in the area.
+    int hp_npass = 1;  // smallest number of passes whose slices fit the area together (uniform)
+    {
+        const int mcap = (int)(B.uarea / BA_MSTRIDE);
+        for (;; ++hp_npass) {
+            int tot = 0;
+            for (int p = 0; p < B.F; ++p) {
+                const int n_p = sPoseStart[p + 1] - sPoseStart[p];
+                tot += min(n_p, ((n_p + hp_npass - 1) / hp_npass + 1) & ~1);
+            }
+            if (tot <= mcap) break;
+            if (hp_npass > Eg) {
+                error = 1;
+                break;
+            }
+        }
+    }
+    const bool hp_tables = hp_npass <= BA_HP_PASSES;
+    auto hp_slice_row = [&](int q, int row) {
+        if (tid < B.F) {
+            int off = 0, lo = 0, hi = 0;
+            for (int pp = 0; pp <= tid; ++pp) {
+                const int s0 = sPoseStart[pp], n_p = sPoseStart[pp + 1] - s0;
+                const int h = ((n_p + hp_npass - 1) / hp_npass + 1) & ~1;
+                off += hi - lo;
+                lo = min(s0 + q * h, s0 + n_p);
+                hi = min(s0 + (q + 1) * h, s0 + n_p);
+            }
+            sSlc[0][row][tid] = (short)lo;
+            sSlc[1][row][tid] = (short)hi;
+            sSlc[2][row][tid] = (short)off;
+        }
+    };
+    if (hp_tables && !error)
+        for (int q = 0; q < hp_npass; ++q) hp_slice_row(q, q);
+    // pairs of free poses this wave chains (two rounds at most: F <= 20 -> <= 10 pairs on 8 waves)
+    int nfp = 0, hp_pa0 = -1, hp_pb0 = -1, hp_pa1 = -1, hp_pb1 = -1;
+    for (int p = 0; p < B.F; ++p) {
+        if (sSlot[p] < 0) continue;
+        if (nfp == 2 * wave) hp_pa0 = p;
+        if (nfp == 2 * wave + 1) hp_pb0 = p;
+        if (nfp == 2 * (wave + BA_WAVES)) hp_pa1 = p;
+        if (nfp == 2 * (wave + BA_WAVES) + 1) hp_pb1 = p;
+        ++nfp;
+    }
+    __syncthreads();
+
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus), kept in registers;
         // X~ and e~ also go to the staging area for the landmark blocks
@@ -972,120 +1022,84 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         const bool hp_local = hp_deferred || G == 1;  // results stay in this workgroup's hpl
         if (!hp_deferred) ++tagH;
         {
-            // The rows are staged in `npass` passes: pass q holds, for EVERY pose, the q-th slice of its rows (an even number of
-            // edges, so that a slice is whole MFMA steps), all slices of a pass packed back to back.  Every chain therefore runs
-            // in every pass -- side by side on different waves -- and carries its accumulator from pass to pass: the same fma
-            // chain over the pose's rows in storage order as with one pass.
+            // The rows are staged in `hp_npass` passes (tables made once per solve, above): pass q holds, for EVERY pose, the q-th
+            // slice of its rows, all slices of a pass packed back to back.  Every chain therefore runs in every pass -- side by
+            // side on different waves -- and carries its accumulator from pass to pass: the same fma chain over the pose's rows in
+            // storage order as with one pass.
             const int col = lane & 15;
-            const int mcap = (int)(B.uarea / BA_MSTRIDE);
-            int npass = 1;  // smallest number of passes whose slices fit the area together (uniform)
-            for (;; ++npass) {
-                int tot = 0;
-                for (int p = 0; p < B.F; ++p) {
-                    const int n_p = sPoseStart[p + 1] - sPoseStart[p];
-                    tot += min(n_p, ((n_p + npass - 1) / npass + 1) & ~1);
-                }
-                if (tot <= mcap) break;
-                if (npass > Eg) {
-                    error = 1;
-                    break;
-                }
-            }
-            // pair of free poses this wave chains (two rounds at most: F <= 20 -> <= 10 pairs on 8 waves)
-            int nfp = 0;
-            for (int p = 0; p < B.F; ++p) nfp += sSlot[p] >= 0;
             v4d accp0 = {0, 0, 0, 0}, accp1 = {0, 0, 0, 0};
-            for (int q = 0; q < npass && !error; ++q) {
-                // slice q of pose p: edges [s_p + q h_p, min(e_p, s_p + (q + 1) h_p)), h_p = ceil(n_p / npass) rounded up to even;
-                // its place in the staging area: behind the slices of the poses before it (tables in LDS, one thread per pose)
-                if (tid < B.F) {
-                    int off = 0, lo = 0, hi = 0;
-                    for (int pp = 0; pp <= tid; ++pp) {
-                        const int s0 = sPoseStart[pp], n_p = sPoseStart[pp + 1] - s0;
-                        const int h = ((n_p + npass - 1) / npass + 1) & ~1;
-                        off += hi - lo;
-                        lo = min(s0 + q * h, s0 + n_p);
-                        hi = min(s0 + (q + 1) * h, s0 + n_p);
-                    }
-                    sSliceLo[tid] = lo;
-                    sSliceHi[tid] = hi;
-                    sSliceOff[tid] = off;
+            for (int q = 0; q < hp_npass && !error; ++q) {
+                const int tq = hp_tables ? q : 0;
+                if (!hp_tables) {  // (more passes than the table holds: the pass's row is made now)
+                    hp_slice_row(q, 0);
+                    __syncthreads();
                 }
-                __syncthreads();
-                auto slice_of = [&](int p, int& lo, int& hi) {
-                    lo = sSliceLo[p];
-                    hi = sSliceHi[p];
-                };
-                auto slice_off = [&](int p) { return sSliceOff[p]; };
 #define BA_BODY_STAGE_M(el, r, l_, sl_, ee)                                   \
     const int p_ = W.epose[el];                                              \
-    int lo_, hi_;                                                            \
-    slice_of(p_, lo_, hi_);                                                  \
+    const int lo_ = sSlc[0][tq][p_], hi_ = sSlc[1][tq][p_];                  \
     if ((el) < lo_ || (el) >= hi_) break;                                    \
-    double* Mr = stage + BA_MSTRIDE * (slice_off(p_) + (el)-lo_);            \
+    double* Mr = stage + BA_MSTRIDE * (sSlc[2][tq][p_] + (el)-lo_);          \
     _Pragma("unroll") for (int c = 0; c < 6; ++c) {                          \
         Mr[c] = r.a0[c];                                                     \
         Mr[7 + c] = r.a1[c];                                                 \
     }                                                                        \
     Mr[6] = ee[0];                                                           \
     Mr[13] = ee[1];
-                if (!error) {
-                    BA_EDGES(BA_BODY_STAGE_M)
-                }
+                BA_EDGES(BA_BODY_STAGE_M)
                 __syncthreads();
-                const bool lastq = q == npass - 1;
-                if (batch.use_mfma && !error) {
+                const bool lastq = q == hp_npass - 1;
+                if (batch.use_mfma) {
                     // two free poses share a chain: columns 0..6 of the 16-wide operand are the rows [A~ | e~] of the first,
                     // columns 8..14 those of the second (zero rows once the shorter one has ended: exact no-ops), so the
                     // diagonal 7 x 7 blocks of the product are the two pose blocks, each its own fma chain over its rows
                     int ai = 0;
                     for (int pair = wave; 2 * pair < nfp; pair += BA_WAVES, ++ai) {
-                        int pa = -1, pb = -1, idx = 0;
-                        for (int p = 0; p < B.F; ++p) {
-                            if (sSlot[p] < 0) continue;
-                            if (idx == 2 * pair) pa = p;
-                            if (idx == 2 * pair + 1) pb = p;
-                            ++idx;
-                        }
+                        const int pa = ai == 0 ? hp_pa0 : hp_pa1, pb = ai == 0 ? hp_pb0 : hp_pb1;
                         const bool second = col >= 8;
                         const int pp = second ? pb : pa;
                         const int cc7 = col & 7;
                         const bool cv = cc7 < 7 && pp >= 0;
-                        int loA, hiA, loB = 0, hiB = 0;
-                        slice_of(pa, loA, hiA);
-                        if (pb >= 0) slice_of(pb, loB, hiB);
-                        const int sA = slice_off(pa), rowsA = 2 * (hiA - loA);
-                        const int sB = pb >= 0 ? slice_off(pb) : 0, rowsB = 2 * (hiB - loB);
-                        const int s = second ? sB : sA, rows = second ? rowsB : rowsA;
+                        const int rowsA = 2 * (sSlc[1][tq][pa] - sSlc[0][tq][pa]);
+                        const int rowsB = pb >= 0 ? 2 * (sSlc[1][tq][pb] - sSlc[0][tq][pb]) : 0;
+                        const int s = pp >= 0 ? sSlc[2][tq][pp] : 0, rows = second ? rowsB : rowsA;
                         const int rmax = max(rowsA, rowsB);
                         // row 4 st + k = (edge s + 2 st + (k >> 1), residual row k & 1); edge pitch BA_MSTRIDE, row offset 7
                         const double* pm = stage + BA_MSTRIDE * (s + (lane >> 5)) + 7 * ((lane >> 4) & 1) + (cv ? cc7 : 0);
                         const int kq = lane >> 4;
+                        const int myrows = cv ? rows - kq : 0;  // this lane supplies row 4 st + kq of its pose while 4 st < myrows
                         v4d acc = ai == 0 ? accp0 : accp1;
                         int st = 0;
-                        const int rmin = pb >= 0 ? min(rowsA, rowsB) : rowsA;
-                        for (; 4 * (st + 4) <= rmin; st += 4) {  // (both poses still have rows: no row predicate)
-                            const double v0 = pm[0], v1 = pm[2 * BA_MSTRIDE], v2 = pm[4 * BA_MSTRIDE], v3 = pm[6 * BA_MSTRIDE];
-                            const double w0 = cv ? v0 : 0.0, w1 = cv ? v1 : 0.0, w2 = cv ? v2 : 0.0, w3 = cv ? v3 : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, w0, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, w1, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w2, w2, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w3, w3, acc, 0, 0, 0);
-                            pm += 8 * BA_MSTRIDE;
+                        // four steps per group; the operands of the NEXT group are fetched right behind the first instruction of a
+                        // group (the wave stalls at every dependent MFMA anyway: 64 cycles in which the loads complete)
+#define BA_HP_LOAD4(V)                                                                   \
+    V##0 = 4 * st < myrows ? pm[0] : 0.0, V##1 = 4 * st + 4 < myrows ? pm[2 * BA_MSTRIDE] : 0.0, \
+    V##2 = 4 * st + 8 < myrows ? pm[4 * BA_MSTRIDE] : 0.0, V##3 = 4 * st + 12 < myrows ? pm[6 * BA_MSTRIDE] : 0.0; \
+    pm += 8 * BA_MSTRIDE;                                                                \
+    st += 4
+#define BA_HP_MFMA4_LOADNEXT(V, Wn, more)                                      \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(V##0, V##0, acc, 0, 0, 0);       \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    if (more) { BA_HP_LOAD4(Wn); }                                              \
+    __builtin_amdgcn_sched_barrier(0);                                          \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(V##1, V##1, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(V##2, V##2, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(V##3, V##3, acc, 0, 0, 0)
+                        if (4 * (st + 4) <= rmax) {
+                            double a0, a1, a2, a3, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                            BA_HP_LOAD4(a);
+                            for (;;) {
+                                const bool more1 = 4 * (st + 4) <= rmax;
+                                BA_HP_MFMA4_LOADNEXT(a, c, more1);
+                                if (!more1) break;
+                                const bool more2 = 4 * (st + 4) <= rmax;
+                                BA_HP_MFMA4_LOADNEXT(c, a, more2);
+                                if (!more2) break;
+                            }
                         }
-                        for (; 4 * (st + 4) <= rmax; st += 4) {  // (only one of the two poses still has rows)
-                            const double v0 = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
-                            const double v1 = (cv && 4 * st + 4 + kq < rows) ? pm[2 * BA_MSTRIDE] : 0.0;
-                            const double v2 = (cv && 4 * st + 8 + kq < rows) ? pm[4 * BA_MSTRIDE] : 0.0;
-                            const double v3 = (cv && 4 * st + 12 + kq < rows) ? pm[6 * BA_MSTRIDE] : 0.0;
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v2, v2, acc, 0, 0, 0);
-                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v3, v3, acc, 0, 0, 0);
-                            pm += 8 * BA_MSTRIDE;
-                        }
+#undef BA_HP_LOAD4
+#undef BA_HP_MFMA4_LOADNEXT
                         for (; 4 * st < rmax; ++st) {  // last steps, possibly with fewer than 4 rows
-                            const double v = (cv && 4 * st + kq < rows) ? pm[0] : 0.0;
+                            const double v = 4 * st < myrows ? pm[0] : 0.0;
                             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, acc, 0, 0, 0);
                             pm += 2 * BA_MSTRIDE;
                         }
@@ -1105,14 +1119,13 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                             }
                         }
                     }
-                } else if (!error) {
+                } else {
                     // validation path: the same fma chains on the vector ALU, running sums in hpl between the passes
                     for (int p = wave; p < B.F; p += BA_WAVES) {
                         const int sl = sSlot[p];
                         if (sl < 0 || lane >= BA_HP) continue;
-                        int lo, hi;
-                        slice_of(p, lo, hi);
-                        const int s = slice_off(p), e = s + hi - lo;
+                        const int lo = sSlc[0][tq][p], hi = sSlc[1][tq][p];
+                        const int s = sSlc[2][tq][p], e = s + hi - lo;
                         int i = 0;
                         while ((i + 1) * (i + 2) / 2 <= lane) ++i;
                         const int j = lane - i * (i + 1) / 2;
@@ -1719,6 +1732,11 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
 // the host posts `stop` or nothing has arrived for BA_SERVICE_IDLE_TICKS of the 100 MHz clock (safety net: the grid must
 // never outlive its host).
 template <int NR, int SLOTS>
+__device__ __attribute__((noinline)) void ba_window_call(const BaDev* desc, unsigned tag0, int use_mfma, int same_l2_ok, int g) {
+    BaRun run = {tag0, use_mfma, same_l2_ok};
+    ba_window<false, NR, SLOTS>(desc, run, g);
+}
+template <int NR, int SLOTS, bool OOL>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
     int slot = blockIdx.x % a.nslots;
     int g = blockIdx.x / a.nslots;
@@ -1776,9 +1794,13 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
         __syncthreads();
         if (stop) return;
         last = seq;
-        BaRun run = {(unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1)};
         const BaDev* D = reinterpret_cast<const BaDev*>(desc);
-        ba_window<false, NR, SLOTS>(D, run, g);
+        if (OOL) {
+            ba_window_call<NR, SLOTS>(D, (unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1), g);
+        } else {
+            BaRun run = {(unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1)};
+            ba_window<false, NR, SLOTS>(D, run, g);
+        }
         // ---- completion: every workgroup of the slot counts itself off once its results are on their way to the host (every
         // wave drains its own stores first); workgroup 0 waits for all of them and then posts the job's sequence number
         __threadfence_system();
@@ -1814,9 +1836,14 @@ int ba_kernel_set_lds_limit() {
                                            BA_LDS_BUDGET) != hipSuccess;
     return bad ? -1 : 0;
 }
-hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
-    hipLaunchKernelGGL((k_ba_service<32, 2>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
+hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream, int out_of_line) {
+    if (out_of_line) {
+        (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
+        hipLaunchKernelGGL((k_ba_service<32, 2, true>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
+        hipLaunchKernelGGL((k_ba_service<32, 2, false>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
+    }
     return hipGetLastError();
 }
 // solver class of a window with n unknowns (windows of one launch share it)

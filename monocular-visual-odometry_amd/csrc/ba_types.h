@@ -34,6 +34,7 @@ typedef unsigned long long ba_u64;
 #define BA_MAX_BATCH 16             // windows per launch (8 x 32 or 16 x 16 workgroups = one workgroup per CU)
 #define BA_NPHASE 16
 #define BA_TRACE_MAX 512            // LM trials recorded per solve (50 iterations x at most 10 trials)
+#define BA_HP_PASSES 6               // staging passes of the pose-block rows whose slice tables are kept for the whole solve
 #define BA_HP 28                    // packed lower triangle of the 7 x 7 pose block [H_pp | -b_p; . | e^T e]
 
 struct BaStatsDev {

@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 
 #include "mvo_internal.h"
 
@@ -57,6 +59,36 @@ void mvo_prof_collect(mvo_ctx* c) {
 }
 
 int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
+// ---- admission gate (mvo_internal.h)
+int g_extract_concurrency = std::getenv("MVO_EXTRACT_CONCURRENCY") ? std::atoi(std::getenv("MVO_EXTRACT_CONCURRENCY")) : 0;
+namespace {
+struct GateState {
+    std::mutex m;
+    std::condition_variable cv;
+    int in_flight = 0;
+};
+GateState* g_gates = new GateState[16];  // (never destroyed: contexts may outlive static destruction order)
+}  // namespace
+ExtractGate::ExtractGate(const mvo_ctx* ctx) {
+    const int cap = g_extract_concurrency;
+    if (!ctx || !ctx->ba_throughput_mode || cap <= 0) return;
+    device = ctx->device & 15;
+    GateState& g = g_gates[device];
+    std::unique_lock<std::mutex> lk(g.m);
+    g.cv.wait(lk, [&] { return g.in_flight < std::max(1, g_extract_concurrency); });
+    ++g.in_flight;
+}
+void ExtractGate::release() {
+    if (device < 0) return;
+    GateState& g = g_gates[device];
+    {
+        std::lock_guard<std::mutex> lk(g.m);
+        --g.in_flight;
+    }
+    g.cv.notify_one();
+    device = -1;
+}
+
 static int g_match_host_out = 1;  // measurement knob: 0 = k_knn2 delivers into HBM, a copy follows
 
 extern "C" {
@@ -318,6 +350,7 @@ static int knn2_common(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* 
     // the merge kernel writes the nq x (idx[2], dist[2]) block straight into the pinned staging buffer
     int r = mvo_ensure_pinned(ctx, (size_t)nq * 16);
     if (r) return r;
+    ExtractGate gate(ctx);
     if (g_match_host_out) {
         if ((r = match_launch_knn2(ctx, d_q, nq, d_t, nt, ctx->d_mout, reinterpret_cast<int32_t*>(ctx->h_pin)))) return r;
     } else {  // measurement knob: the kernel delivers into HBM and a copy follows (kernel time without the PCIe write tail)
@@ -325,6 +358,7 @@ static int knn2_common(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* 
         MVO_HIP(hipMemcpyAsync(ctx->h_pin, ctx->d_mout, (size_t)nq * 16, hipMemcpyDeviceToHost, ctx->stream));
     }
     MVO_HIP(hipStreamSynchronize(ctx->stream));
+    gate.release();
     if (ctx->prof) mvo_prof_collect(ctx);
     std::memcpy(idx, ctx->h_pin, (size_t)nq * 8);
     std::memcpy(dist, ctx->h_pin + (size_t)nq * 8, (size_t)nq * 8);
@@ -478,6 +512,10 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 // ---------------------------------------------------------------------------------------------- debug hooks
 int mvo_debug_set(const char* key, int value) {
     if (key && !std::strncmp(key, "ba_", 3)) return ba_debug_set(key, value);
+    if (key && !std::strcmp(key, "extract_concurrency")) {
+        g_extract_concurrency = value;
+        return MVO_OK;
+    }
     if (key && !std::strcmp(key, "match_host_out")) {
         g_match_host_out = value;
         return MVO_OK;

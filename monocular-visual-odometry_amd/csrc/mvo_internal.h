@@ -117,6 +117,21 @@ struct ProfEntry {
     double ms = 0;
 };
 
+// Admission gate of the extraction / matching launches of THROUGHPUT-mode contexts (many sequences share the GPU): at most
+// `g_extract_concurrency` such launch-and-wait sections are in flight per device (0 = no limit).  The kernels of a frame run on
+// the CUs the resident solver grid leaves free; their combined throughput DROPS when too many frames interleave there
+// (round 4: 14 frames at once -> 3400 frames/s of extraction, 8-9 at once -> 4600), so the excess waits at the door.
+extern int g_extract_concurrency;
+struct mvo_ctx;
+struct ExtractGate {
+    int device = -1;
+    explicit ExtractGate(const mvo_ctx* ctx);
+    ~ExtractGate() { release(); }
+    void release();
+    ExtractGate(const ExtractGate&) = delete;
+    ExtractGate& operator=(const ExtractGate&) = delete;
+};
+
 struct mvo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -288,9 +288,10 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     if (r) return r;
     const PyrInfo& P = ctx->pyr;
     ctx->pyr_valid = ctx->blur_valid = false;
+    if ((r = mvo_ensure_pinned(ctx, orb_detect_host_bytes(P.n_tiles)))) return r;
+    ExtractGate gate(ctx);
     if ((r = orb_launch_pyramid(ctx, d_img, stride, channels, P.nlevels))) return r;
     // the kernel delivers per-tile-row counts and ordered record lists into the pinned buffer itself
-    if ((r = mvo_ensure_pinned(ctx, orb_detect_host_bytes(P.n_tiles)))) return r;
     // a ctx in throughput mode (many sequences share the GPU) leaves the ordering of a tile row to this thread: the GPU time
     // of the ordering step (~8 us of kernel tail) is worth more there than ~75 us of a host thread that has company
     const bool ordered = !ctx->ba_throughput_mode;
@@ -298,6 +299,7 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
     ht.lap(0);
     MVO_HIP(hipEventSynchronize(ctx->ev));
+    gate.release();
     ht.lap(1);
     const int32_t* counts = (const int32_t*)ctx->h_pin;
     const DevCandidate* slots = (const DevCandidate*)(ctx->h_pin + orb_detect_counts_bytes(P.n_tiles));
@@ -419,9 +421,11 @@ int orb_describe_device(mvo_ctx* ctx, std::vector<mvo_keypoint>& kps, int w, int
     // buffer is not touched again before the synchronisation below
     uint8_t* hd = desc_host ? ctx->h_pin + (size_t)n * sizeof(DevDescKp) : nullptr;
     ht.lap(0);
+    ExtractGate gate(ctx);
     if ((r = orb_launch_brief(ctx, n, hk, hd))) return r;
     ht.lap(1);
     MVO_HIP(hipStreamSynchronize(ctx->stream));
+    gate.release();
     ht.lap(2);
     if (desc_host) std::memcpy(desc_host, hd, (size_t)n * 32);
     ht.lap(3);

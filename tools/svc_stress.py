@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, __graft_entry__ as g
 mvo = g.load_package()
 N = int(sys.argv[1]); reps = int(sys.argv[2]); with_extract = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+svc = int(sys.argv[4]) if len(sys.argv) > 4 else 2   # mvo_debug_set("ba_service"): 2 = always the resident grid, 0 = launch path
 pbs = [mvo.synth.ba_problem(5, 2000, 7 + k) for k in range(4)]
 img = mvo.synth.small_test_image(1, 640, 480)
 errs = []
 def work(k):
     try:
-        c = mvo.Context(0); c.ba_set_mode("throughput"); mvo.debug_set("ba_service", 2)
+        c = mvo.Context(0); c.ba_set_mode("throughput"); mvo.debug_set("ba_service", svc)
         ce = mvo.Context(0, max_keypoints=2000) if with_extract else None
         for r in range(reps):
             pb = pbs[(k + r) % len(pbs)]
@@ -26,4 +27,5 @@ for t in th: t.start()
 for t in th: t.join()
 dt = time.time() - t0
 c = mvo.Context(0)
-print("N %d reps %d extract %d: %.2fs -> %.0f solves/s errors %s stats %s" % (N, reps, with_extract, dt, N * reps / dt, errs[:2], c.ba_launch_stats()))
+st = c.ba_launch_stats()
+print("N %d reps %d extract %d: %.2fs -> %.0f solves/s errors %s | per window: %.3f ms, %.0f kcycles | %s" % (N, reps, with_extract, dt, N * reps / dt, errs[:2], st["ms"] / max(st["windows"], 1), st.get("resident_cycles", 0) / max(st["resident_windows"], 1) / 1e3, st))
