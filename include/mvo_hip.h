@@ -63,6 +63,9 @@ int mvo_create(mvo_ctx** ctx, int device);
  * queues (measured: 3443 / 3551 -> 3874 / 3910 frames/s with sibling contexts).  Destroy the sibling before its parent. */
 int mvo_create_sibling(mvo_ctx* parent, mvo_ctx** ctx);
 void mvo_destroy(mvo_ctx* ctx);
+/* A number that identifies this ctx for the lifetime of the process (never reused, unlike its address): what per-ctx state
+ * kept OUTSIDE the library (e.g. "parameters already latched", feature_match.cpp:16-19) is keyed by.  0 for a null ctx. */
+unsigned long long mvo_ctx_uid(const mvo_ctx* ctx);
 const char* mvo_last_error(const mvo_ctx* ctx);
 /* Blocks until all work queued on the ctx stream is done. */
 int mvo_synchronize(mvo_ctx* ctx);
@@ -159,7 +162,7 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * workgroup (the 5-keyframe window of the benchmark: 28 CUs of one XCD, shortest solve) and solved by a launch of its own;
  * the detection kernel also puts its candidates in order on the device.
  * THROUGHPUT: many sequences are in flight on this GPU -- CU time counts, not latency.  While the offered load keeps it
- * busy (64 submissions in a row at a rate x solve time of >= 10 of its 16 slots; it leaves after 80 ms below 8), 5-keyframe windows are cut into ~700 observations
+ * busy (64 submissions in a row at a rate x solve time of >= 10 of its 16 slots; it leaves after 80 ms below 8), 5-keyframe windows are cut into ~720 observations
  * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
  * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
@@ -262,6 +265,9 @@ int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_
 /* Shader-clock cycles the resident grid spent on those windows (sum over the windows, workgroup 0 of each, load to write-back;
  * divided by their `ms` this is the clock the solver ran at under load). */
 int mvo_debug_ba_resident_cycles(int device, double* shader_cycles);
+/* Times a window that cannot use the resident grid (pose-only, another solver class, rows in LDS only) made the grid leave
+ * since the last reset: every such switch drains the 16 slots and relaunches the grid afterwards -- mixed workloads pay for it. */
+int mvo_debug_ba_path_switches(int device, long long* n);
 /* Test hook: replays the resident solver service's demand estimate (see mvo_ba_set_mode) over n submission times (seconds,
  * ascending); decisions[i] = 1 if a window submitted at times[i] would go to the resident grid.  Returns the number of
  * changes of mind.  Touches no device. */

@@ -28,7 +28,11 @@
 int ba_kernel_set_lds_limit();
 hipError_t ba_kernel_launch(const BaBatch& batch, int max_wgs, size_t lds_bytes, hipStream_t stream, int profile, int nr, int slots);
 int ba_solver_class(int n);
-hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream, int out_of_line);
+hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream);
+
+// hipFree / hipHostFree synchronise with every stream of the device, the never-ending resident solver grid included: the
+// grid is taken off the device first (and kept off until the free is done).  Used by every grow / release path of the library.
+void ba_service_free(int device, void* p, bool host);
 
 int g_ba_use_mfma = 1;  // debug knobs (mvo_debug_set)
 int g_ba_wgs = 0;       // 0 = automatic
@@ -98,9 +102,10 @@ int ws_reserve(mvo_ctx* ctx, BaWorkspace& ws, size_t dev_bytes, size_t pin_bytes
     if (!ws.ready) MVO_HIP(hipEventCreateWithFlags(&ws.ready, hipEventDisableTiming));
     if (dev_bytes > ws.dev_cap) {
         MVO_HIP(hipStreamSynchronize(ctx->stream));
-        if (ws.dev) (void)hipFree(ws.dev);
+        if (ws.dev) ba_service_free(ctx->device, ws.dev, false);
         ws.dev = nullptr;
         ws.dev_cap = 0;
+        std::memset(ws.x_sig, 0, sizeof ws.x_sig);  // fresh memory: the exchange areas count as laid out anew (cleared + ordered below)
         const size_t cap = dev_bytes + dev_bytes / 4 + 65536;
         MVO_HIP(hipMalloc((void**)&ws.dev, cap));
         ws.dev_cap = cap;
@@ -110,7 +115,7 @@ int ws_reserve(mvo_ctx* ctx, BaWorkspace& ws, size_t dev_bytes, size_t pin_bytes
     }
     if (pin_bytes > ws.pin_cap) {
         MVO_HIP(hipStreamSynchronize(ctx->stream));
-        if (ws.pin) (void)hipHostFree(ws.pin);
+        if (ws.pin) ba_service_free(ctx->device, ws.pin, true);
         ws.pin = nullptr;
         ws.pin_cap = 0;
         const size_t cap = pin_bytes + pin_bytes / 4 + 65536;
@@ -120,8 +125,8 @@ int ws_reserve(mvo_ctx* ctx, BaWorkspace& ws, size_t dev_bytes, size_t pin_bytes
     return MVO_OK;
 }
 void ws_free(BaWorkspace& ws) {
-    if (ws.dev) (void)hipFree(ws.dev);
-    if (ws.pin) (void)hipHostFree(ws.pin);
+    if (ws.dev) ba_service_free(ws.device, ws.dev, false);
+    if (ws.pin) ba_service_free(ws.device, ws.pin, true);
     if (ws.ready) (void)hipEventDestroy(ws.ready);
     ws = BaWorkspace();
 }
@@ -161,7 +166,16 @@ struct BaService {
     hipStream_t resident_stream = nullptr;
     unsigned long long slot_seq[BA_SERVICE_SLOTS] = {0};
     BaJob* slot_job[BA_SERVICE_SLOTS] = {nullptr};
-    int slots_busy = 0, wgs_per_slot = 13;
+    int slots_busy = 0;
+    std::atomic<int> wgs_per_slot{13};  // workgroups per slot the NEXT grid gets (raised by planners, read by the scheduler)
+    int wgs_launched = 0;               // what the grid on the device was launched with (scheduler thread only)
+    int next_slot = 0;                  // slot assignment rotates: no slot sits idle for long while others work
+    unsigned long long beat = 0;        // heartbeat written to every mailbox while the grid is resident (scheduler thread only)
+    std::chrono::steady_clock::time_point beat_time{};
+    std::atomic<int> park_forced{0};    // a caller needs the grid off the device now (memory is about to be freed)
+    int free_gate = 0;                  // > 0: frees in progress, the grid must not come up (service mutex)
+    long long path_switches = 0;        // times a launch-path window made the resident grid leave (mixed workloads)
+    void heartbeat();
     std::atomic<int> q_pending{0};  // queued jobs (lets the scheduler poll without the mutex)
     bool park_requested = false;    // mvo_synchronize: take an idle resident grid off the device now
     std::condition_variable cv_slot;
@@ -225,11 +239,20 @@ void BaService::run() {
             // (pinned host memory the device writes), hands finished windows back and posts queued windows to free slots.  A
             // slot is held exactly as long as the device works on it, not until the client comes back for the result.
             if (resident) (void)reap_locked();
+            if (resident) heartbeat();
+            if (park_forced.load(std::memory_order_acquire)) {  // (ba_service_with_grid_parked: hipFree would wait for the grid)
+                if (resident) stop_resident(lk);
+                park_forced.store(0, std::memory_order_release);
+                cv_done.notify_all();
+            }
             while (!q.empty() && q.front()->ws->plan.service) {
                 // ---- resident solver service: no launch per window -- the job goes to a free slot of the resident grid
                 if (!flights.empty()) {  // (launch-path grids and the resident grid never share the device)
                     cv_flight.wait(lk, [&] { return flights.empty(); });
                 }
+                if (!resident && free_gate > 0) cv_work.wait(lk, [&] { return free_gate == 0; });
+                // (a window planned for more workgroups per slot than the grid on the device has: the grid is relaunched)
+                if (resident && q.front()->ws->plan.G > wgs_launched) stop_resident(lk);
                 if (!resident && start_resident() != 0) {
                     BaJob* j = q.front();
                     q.pop_front();
@@ -243,8 +266,9 @@ void BaService::run() {
                 BaJob* j = q.front();
                 q.pop_front();
                 q_pending.fetch_sub(1, std::memory_order_relaxed);
-                int sl = 0;
-                while (slot_job[sl]) ++sl;
+                int sl = next_slot;
+                while (slot_job[sl]) sl = (sl + 1) % BA_SERVICE_SLOTS;
+                next_slot = (sl + 1) % BA_SERVICE_SLOTS;
                 slot_job[sl] = j;
                 ++slots_busy;
                 ++resident_jobs;
@@ -262,16 +286,18 @@ void BaService::run() {
                     // to submit and to wake up -- a scheduler that spins on it starves them
                     lk.unlock();
                     for (;;) {
-                        bool work = q_pending.load(std::memory_order_acquire) > 0 && slots_busy < BA_SERVICE_SLOTS;
+                        bool work = (q_pending.load(std::memory_order_acquire) > 0 && slots_busy < BA_SERVICE_SLOTS) ||
+                                    park_forced.load(std::memory_order_acquire) != 0;
                         for (int sl = 0; sl < BA_SERVICE_SLOTS && !work; ++sl)
                             work = slot_job[sl] && __atomic_load_n(&mail[sl].done_seq, __ATOMIC_ACQUIRE) >= slot_job[sl]->seq;
                         if (work) break;
+                        heartbeat();
                         for (int k = 0; k < 64; ++k) __builtin_ia32_pause();
                     }
                     continue;
                 }
                 // (a device-wide synchronisation of the caller waits for the grid as well: it must not linger)
-                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(3), [&] { return !q.empty() || park_requested; })) stop_resident(lk);
+                if (q.empty() && !cv_work.wait_for(lk, std::chrono::milliseconds(3), [&] { return !q.empty() || park_requested || park_forced.load() != 0; })) stop_resident(lk);
                 else if (park_requested && q.empty() && slots_busy == 0) stop_resident(lk);
                 park_requested = false;
                 continue;
@@ -281,7 +307,10 @@ void BaService::run() {
                 continue;
             }
             lap(l_idle);
-            if (resident) stop_resident(lk);  // a launch-path window: the resident grid leaves first
+            if (resident) {  // a launch-path window: the resident grid leaves first
+                ++path_switches;
+                stop_resident(lk);
+            }
             int share = g_ba_cu_share > 0 ? g_ba_cu_share : cus;
             share = std::max(1, std::min(share, cus));
             {   // batching: clients that submitted during the last 10 ms are expected back within a fraction of a solve
@@ -431,6 +460,15 @@ bool BaService::reap_locked() {
     if (any) cv_done.notify_all();
     return any;
 }
+void BaService::heartbeat() {
+    // (scheduler thread; the mailboxes are pinned host memory only this thread writes)
+    const auto now = std::chrono::steady_clock::now();
+    if (now - beat_time < std::chrono::milliseconds(200)) return;
+    beat_time = now;
+    ++beat;
+    if (mail)
+        for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&mail[sl].beat, (ba_u64)beat, __ATOMIC_RELAXED);
+}
 int BaService::start_resident() {
     // (called with the service mutex held; everything here is quick)
     if (!mail) {
@@ -449,9 +487,7 @@ int BaService::start_resident() {
     a.cmd = d_cmd;
     a.arrived = d_cmd + 8 * BA_SERVICE_SLOTS;
     a.nslots = BA_SERVICE_SLOTS;
-    a.wgs_per_slot = wgs_per_slot;
-    static const int env_map = std::getenv("MVO_BA_SLOT_MAP") ? std::atoi(std::getenv("MVO_BA_SLOT_MAP")) : 0;
-    a.slot_map = BA_SERVICE_SLOTS == 16 ? env_map : 0;
+    a.wgs_per_slot = wgs_launched = wgs_per_slot.load(std::memory_order_relaxed);
     ba_u64 init[9 * BA_SERVICE_SLOTS] = {0};
     for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) {
         a.first_seq[sl] = slot_seq[sl];
@@ -459,11 +495,11 @@ int BaService::start_resident() {
         mail[sl].seq = slot_seq[sl];
         mail[sl].stop = 0;
         mail[sl].done_seq = slot_seq[sl];
+        mail[sl].beat = ++beat;
     }
     if (hipMemcpyAsync(d_cmd, init, sizeof(init), hipMemcpyHostToDevice, resident_stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(resident_stream) != hipSuccess) return -1;
-    static const int env_ool = std::getenv("MVO_BA_SERVICE_OOL") ? std::atoi(std::getenv("MVO_BA_SERVICE_OOL")) : 0;
-    if (ba_service_launch(a, resident_stream, env_ool) != hipSuccess) return -1;
+    if (ba_service_launch(a, resident_stream) != hipSuccess) return -1;
     resident = true;
     ++resident_starts;
     return 0;
@@ -478,6 +514,13 @@ void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;  // (a slot that never answers: give up waiting)
         }
     }
+    for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl)
+        if (BaJob* j = slot_job[sl]) {  // still outstanding after the bail-out: its client must not wait for ever
+            j->err = hipErrorUnknown;
+            j->done = true;
+            slot_job[sl] = nullptr;
+            --slots_busy;
+        }
     for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&mail[sl].stop, (ba_u64)1, __ATOMIC_RELEASE);
     lk.unlock();
     (void)hipStreamSynchronize(resident_stream);
@@ -566,6 +609,37 @@ BaService& service_for(int device) {
     }
     return s;
 }
+}  // namespace
+void ba_service_free(int device, void* p, bool host) {
+    if (!p) return;
+    BaService* sp = nullptr;
+    if (device >= 0 && device < 16) {
+        std::lock_guard<std::mutex> lk(*g_service_start);
+        sp = g_service[device & 15];
+    }
+    bool gated = false;
+    if (sp && sp->started) {
+        std::unique_lock<std::mutex> lk(sp->m);
+        ++sp->free_gate;
+        gated = true;
+        if (sp->resident) {
+            sp->park_forced.store(1, std::memory_order_release);
+            sp->cv_work.notify_all();
+            // (running windows finish first: a few milliseconds; bounded in case the scheduler is stuck)
+            sp->cv_done.wait_for(lk, std::chrono::seconds(2), [&] { return !sp->resident; });
+        }
+    }
+    if (host) (void)hipHostFree(p);
+    else (void)hipFree(p);
+    if (gated) {
+        {
+            std::lock_guard<std::mutex> lk(sp->m);
+            --sp->free_gate;
+        }
+        sp->cv_work.notify_all();
+    }
+}
+namespace {
 void service_submit(BaService& s, BaJob* jobs, int n) {
     {
         std::lock_guard<std::mutex> lk(s.m);
@@ -682,7 +756,12 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     const int reserve = env_reserve >= 0 ? env_reserve : (throughput ? g_ba_xcd_reserve + 2 : g_ba_xcd_reserve);
     const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
     const int g_cap = throughput ? per_xcd / 2 : per_xcd;
-    if (throughput) service_for(ctx->device).wgs_per_slot = std::max(service_for(ctx->device).wgs_per_slot, per_xcd / 2);
+    if (throughput) {  // (monotonic: the grid is relaunched by its scheduler when a window needs more than it has)
+        std::atomic<int>& wps = service_for(ctx->device).wgs_per_slot;
+        int cur = wps.load(std::memory_order_relaxed);
+        while (cur < per_xcd / 2 && !wps.compare_exchange_weak(cur, per_xcd / 2)) {
+        }
+    }
     int G = 1;
     while (G < g_cap && E > 160 * G) G = std::min(2 * G, g_cap);
     if (g_ba_wgs > 0) G = g_ba_wgs;
@@ -965,7 +1044,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // running: a host-to-device copy into memory it may have cached would not be seen); every other window is uploaded.
     // (pose-only windows solve in a fraction of a millisecond: holding CUs resident for them would only take them from
     // the callers' other kernels -- they keep the launch path)
-    P.service = svc && P.slots != 0 && G <= service_for(ctx->device).wgs_per_slot;
+    P.service = svc && P.slots != 0 && G <= service_for(ctx->device).wgs_per_slot.load(std::memory_order_relaxed);
     char* I = P.service ? ws.pin : D;  // where the kernel finds the inputs
     B.poses_in = (const double*)(I + P.o_pin);
     B.poses_out = (double*)(D + P.o_pout);
@@ -1249,10 +1328,11 @@ void ba_service_park(int device) {
     // wait (bounded) until the grid is gone or has work again
     sp->cv_done.wait_for(lk, std::chrono::milliseconds(50), [&] { return !sp->resident || sp->slots_busy > 0 || !sp->q.empty(); });
 }
-void ba_resident_stats(int device, long long* windows, long long* grid_starts, double* cycles) {
+void ba_resident_stats(int device, long long* windows, long long* grid_starts, double* cycles, long long* path_switches) {
     if (windows) *windows = 0;
     if (grid_starts) *grid_starts = 0;
     if (cycles) *cycles = 0;
+    if (path_switches) *path_switches = 0;
     if (device < 0 || device >= 16) return;
     BaService* sp;
     {
@@ -1264,6 +1344,7 @@ void ba_resident_stats(int device, long long* windows, long long* grid_starts, d
     if (windows) *windows = sp->resident_jobs;
     if (grid_starts) *grid_starts = sp->resident_starts;
     if (cycles) *cycles = sp->resident_cycles;
+    if (path_switches) *path_switches = sp->path_switches;
 }
 void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset) {
     if (launches) *launches = 0;
@@ -1287,6 +1368,7 @@ void ba_launch_stats(int device, long long* launches, long long* windows, double
         s.t_idle = s.t_batch = s.t_launch = s.t_sync = s.t_post = 0;
         s.resident_jobs = s.resident_starts = 0;
         s.resident_cycles = 0;
+        s.path_switches = 0;
     }
 }
 

@@ -1729,35 +1729,19 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_lm(BaBatch batch) {
 // pair in device memory (same XCD: they poll its L2), everybody solves the window -- inputs are read straight from the
 // pinned upload image, results go to the pinned mirrors as always --, the workgroups count themselves off, workgroup 0 writes
 // the job's sequence number into the window's pinned status word and the slot waits for the next job.  A slot leaves when
-// the host posts `stop` or nothing has arrived for BA_SERVICE_IDLE_TICKS of the 100 MHz clock (safety net: the grid must
-// never outlive its host).
+// the host posts `stop`, or when neither a job nor a heartbeat of the host's scheduler has arrived for BA_SERVICE_IDLE_TICKS
+// of the 100 MHz clock (safety net: the grid must never outlive its host -- and no slot may leave while the host lives).
 template <int NR, int SLOTS>
-__device__ __attribute__((noinline)) void ba_window_call(const BaDev* desc, unsigned tag0, int use_mfma, int same_l2_ok, int g) {
-    BaRun run = {tag0, use_mfma, same_l2_ok};
-    ba_window<false, NR, SLOTS>(desc, run, g);
-}
-template <int NR, int SLOTS, bool OOL>
 __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
-    int slot = blockIdx.x % a.nslots;
-    int g = blockIdx.x / a.nslots;
-    if (a.slot_map == 1) {
-        // neighbouring workgroups of an XCD (block b lands on XCD b % 8; q = its rank there) belong to the SAME window: two
-        // CUs share an instruction cache, and the solver's code (87 KB) does not fit it twice
-        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, W = a.wgs_per_slot, We = W & ~1;
-        if (q < 2 * We) {
-            slot = xcd + 8 * ((q >> 1) & 1);
-            g = ((q >> 2) << 1) | (q & 1);
-        } else {
-            slot = xcd + 8 * (q - 2 * We);
-            g = W - 1;
-        }
-    }
+    const int slot = blockIdx.x % a.nslots;
+    const int g = blockIdx.x / a.nslots;
     __shared__ unsigned long long sJob[4];  // seq, desc, (tag0 | use_mfma << 32), stop
     volatile BaMail* mail = a.mail + slot;
     u64* cmd = a.cmd + 8 * (size_t)slot;    // device memory: {seq, desc, flags, stop} republished by workgroup 0
     u64* arrived = a.arrived + slot;        // device memory: workgroups that finished the current job (monotonic)
     unsigned long long last = a.first_seq[slot];
     unsigned long long idle0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long last_beat = ~0ull;
     for (;;) {
         if (threadIdx.x == 0) {
             unsigned long long seq, stop = 0, desc = 0, flags = 0;
@@ -1765,7 +1749,18 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
                 if (g == 0) {
                     seq = __hip_atomic_load(&mail->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     stop = __hip_atomic_load(&mail->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    if (!stop && seq == last && __builtin_amdgcn_s_memrealtime() - idle0 > BA_SERVICE_IDLE_TICKS) stop = 1;
+                    if (!stop && seq == last && __builtin_amdgcn_s_memrealtime() - idle0 > BA_SERVICE_IDLE_TICKS) {
+                        // nothing for this slot for a long time: leave only if the HOST has gone quiet as well (its scheduler
+                        // bumps `beat` in every mailbox while the grid is resident) -- a slot that left on its own while the
+                        // grid stays would swallow the next window posted to it
+                        const unsigned long long beat = __hip_atomic_load(&mail->beat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (beat != last_beat) {
+                            last_beat = beat;
+                            idle0 = __builtin_amdgcn_s_memrealtime();
+                        } else {
+                            stop = 1;
+                        }
+                    }
                     if (seq != last || stop) {
                         desc = __hip_atomic_load(&mail->desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         flags = __hip_atomic_load(&mail->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1794,13 +1789,9 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
         __syncthreads();
         if (stop) return;
         last = seq;
+        BaRun run = {(unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1)};
         const BaDev* D = reinterpret_cast<const BaDev*>(desc);
-        if (OOL) {
-            ba_window_call<NR, SLOTS>(D, (unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1), g);
-        } else {
-            BaRun run = {(unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1)};
-            ba_window<false, NR, SLOTS>(D, run, g);
-        }
+        ba_window<false, NR, SLOTS>(D, run, g);
         // ---- completion: every workgroup of the slot counts itself off once its results are on their way to the host (every
         // wave drains its own stores first); workgroup 0 waits for all of them and then posts the job's sequence number
         __threadfence_system();
@@ -1836,14 +1827,9 @@ int ba_kernel_set_lds_limit() {
                                            BA_LDS_BUDGET) != hipSuccess;
     return bad ? -1 : 0;
 }
-hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream, int out_of_line) {
-    if (out_of_line) {
-        (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
-        hipLaunchKernelGGL((k_ba_service<32, 2, true>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
-        hipLaunchKernelGGL((k_ba_service<32, 2, false>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
-    }
+hipError_t ba_service_launch(const BaServiceArgs& a, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)k_ba_service<32, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, BA_LDS_BUDGET);
+    hipLaunchKernelGGL((k_ba_service<32, 2>), dim3(a.nslots * a.wgs_per_slot), dim3(BA_THREADS), BA_LDS_BUDGET, stream, a);
     return hipGetLastError();
 }
 // solver class of a window with n unknowns (windows of one launch share it)

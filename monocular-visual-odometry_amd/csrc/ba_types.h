@@ -123,7 +123,8 @@ struct BaMail {
     ba_u64 flags;     // tag base | use_mfma << 32 | same_l2_ok << 33
     ba_u64 stop;      // 1: leave
     ba_u64 done_seq;  // device -> host
-    ba_u64 pad[3];
+    ba_u64 beat;      // heartbeat of the host's scheduler (bumped while the grid is resident): an idle slot stays while it moves
+    ba_u64 pad[2];
 };
 struct BaServiceArgs {
     BaMail* mail;          // BA_SERVICE_SLOTS mailboxes (pinned host memory)
@@ -131,7 +132,6 @@ struct BaServiceArgs {
     ba_u64* arrived;       // device memory: one counter per slot
     ba_u64 first_seq[BA_SERVICE_SLOTS];  // seq of every slot at launch
     int nslots, wgs_per_slot;
-    int slot_map;  // 0: slot = block % nslots; 1: pairs of neighbouring workgroups of an XCD share a slot (16 slots, 8 XCDs)
 };
 
 // ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner

@@ -60,7 +60,7 @@ void mvo_prof_collect(mvo_ctx* c) {
 
 int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
 // ---- admission gate (mvo_internal.h)
-int g_extract_concurrency = std::getenv("MVO_EXTRACT_CONCURRENCY") ? std::atoi(std::getenv("MVO_EXTRACT_CONCURRENCY")) : 0;
+int g_extract_concurrency = std::getenv("MVO_EXTRACT_CONCURRENCY") ? std::atoi(std::getenv("MVO_EXTRACT_CONCURRENCY")) : 8;
 namespace {
 struct GateState {
     std::mutex m;
@@ -116,6 +116,8 @@ int mvo_create(mvo_ctx** out, int device) {
     return MVO_OK;
 }
 
+unsigned long long mvo_ctx_uid(const mvo_ctx* ctx) { return ctx ? ctx->uid : 0ull; }
+
 int mvo_create_sibling(mvo_ctx* parent, mvo_ctx** out) {
     if (!out) return MVO_ERR_INVALID;
     *out = nullptr;
@@ -145,8 +147,8 @@ void mvo_destroy(mvo_ctx* ctx) {
                    ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
                    ctx->d_mout, ctx->d_fh_slots, ctx->d_fh_line, ctx->d_fh_arrive};
     for (void* p : dev)
-        if (p) (void)hipFree(p);
-    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+        if (p) mvo_free_on_current_device(p);
+    if (ctx->h_pin) ba_service_free(ctx->device, ctx->h_pin, true);
     for (auto& p : ctx->prof_pending) ctx->prof_pool.push_back(p.second);
     for (auto& e : ctx->prof_pool) {
         (void)hipEventDestroy(e.first);
@@ -190,7 +192,7 @@ static int check_image(mvo_ctx* ctx, const void* img, int w, int h, int stride, 
 static int upload_image(mvo_ctx* ctx, const uint8_t* img, int h, int stride) {
     const size_t bytes = (size_t)h * stride;
     if (ctx->d_img_cap < bytes) {
-        if (ctx->d_img) (void)hipFree(ctx->d_img);
+        if (ctx->d_img) ba_service_free(ctx->device, ctx->d_img, false);
         ctx->d_img = nullptr;
         ctx->d_img_cap = 0;
         MVO_HIP(hipMalloc((void**)&ctx->d_img, bytes + 64));
@@ -314,9 +316,9 @@ int mvo_select_uniform_kpts_by_grid(mvo_ctx* ctx, mvo_keypoint* kps, int* n, int
 // ---------------------------------------------------------------------------------------------- matching
 static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
     if (nq > ctx->m_cap_q) {
-        if (ctx->d_mq) (void)hipFree(ctx->d_mq);
-        if (ctx->d_mqxy) (void)hipFree(ctx->d_mqxy);
-        if (ctx->d_mout) (void)hipFree(ctx->d_mout);
+        if (ctx->d_mq) ba_service_free(ctx->device, ctx->d_mq, false);
+        if (ctx->d_mqxy) ba_service_free(ctx->device, ctx->d_mqxy, false);
+        if (ctx->d_mout) ba_service_free(ctx->device, ctx->d_mout, false);
         ctx->d_mq = nullptr;
         ctx->d_mqxy = nullptr;
         ctx->d_mout = nullptr;
@@ -332,8 +334,8 @@ static int ensure_match_bufs(mvo_ctx* ctx, int nq, int nt) {
         ctx->m_cap_q = cap;
     }
     if (nt > ctx->m_cap_t) {
-        if (ctx->d_mt) (void)hipFree(ctx->d_mt);
-        if (ctx->d_mtxy) (void)hipFree(ctx->d_mtxy);
+        if (ctx->d_mt) ba_service_free(ctx->device, ctx->d_mt, false);
+        if (ctx->d_mtxy) ba_service_free(ctx->device, ctx->d_mtxy, false);
         ctx->d_mt = nullptr;
         ctx->d_mtxy = nullptr;
         ctx->m_cap_t = 0;

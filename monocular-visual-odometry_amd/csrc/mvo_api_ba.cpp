@@ -107,6 +107,12 @@ int mvo_debug_ba_resident_stats(int device, long long* windows, long long* grid_
     return MVO_OK;
 }
 
+int mvo_debug_ba_path_switches(int device, long long* n) {
+    if (!n) return MVO_ERR_INVALID;
+    ba_resident_stats(device, nullptr, nullptr, nullptr, n);
+    return MVO_OK;
+}
+
 int mvo_debug_ba_resident_cycles(int device, double* shader_cycles) {
     if (!shader_cycles) return MVO_ERR_INVALID;
     ba_resident_stats(device, nullptr, nullptr, shader_cycles);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -132,7 +133,12 @@ struct ExtractGate {
     ExtractGate& operator=(const ExtractGate&) = delete;
 };
 
+inline unsigned long long mvo_next_ctx_uid() {
+    static std::atomic<unsigned long long> n{0};
+    return ++n;
+}
 struct mvo_ctx {
+    unsigned long long uid = mvo_next_ctx_uid();  // mvo_ctx_uid: never reused
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = true;  // false: a sibling ctx on its parent's stream (mvo_create_sibling)
@@ -260,6 +266,14 @@ int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg
 void ba_launch_stats(int device, long long* launches, long long* windows, double* ms, int reset);
 void ba_service_times(int device, double* out5);
 void ba_service_park(int device);
-void ba_resident_stats(int device, long long* windows, long long* grid_starts, double* cycles = nullptr);
+void ba_resident_stats(int device, long long* windows, long long* grid_starts, double* cycles = nullptr, long long* path_switches = nullptr);
+// hipFree / hipHostFree with the resident solver grid of `device` taken off first (both synchronise with every stream of the
+// device; the grid never ends on its own)
+void ba_service_free(int device, void* p, bool host);
+inline void mvo_free_on_current_device(void* p) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    ba_service_free(d, p, false);
+}
 
 #endif

@@ -108,7 +108,7 @@ void fill_resize_tab(ResizeEntry* tab, int ssize, int dsize, bool exact) {
 
 template <class T>
 int free_dev(T*& p) {
-    if (p) (void)hipFree(p);
+    if (p) mvo_free_on_current_device(p);
     p = nullptr;
     return 0;
 }
@@ -133,7 +133,7 @@ void retain_best(std::vector<DevCandidate>& v, int n, Key key) {
 
 int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes) {
     if (ctx->h_pin_cap >= bytes) return MVO_OK;
-    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_pin) ba_service_free(ctx->device, ctx->h_pin, true);
     ctx->h_pin = nullptr;
     ctx->h_pin_cap = 0;
     size_t cap = round_up(bytes + bytes / 2, 1 << 16);

@@ -53,7 +53,7 @@ namespace {
 
 template <class T>
 void free_dev(T*& p) {
-    if (p) (void)hipFree(p);
+    if (p) mvo_free_on_current_device(p);
     p = nullptr;
 }
 

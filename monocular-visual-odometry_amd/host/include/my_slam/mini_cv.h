@@ -9,6 +9,8 @@
 #include <opencv2/core.hpp>
 #else
 #include <cfloat>
+#include <cmath>
+#include <utility>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -110,6 +112,34 @@ public:
         Mat m(rows, cols, type_);
         for (int r = 0; r < rows; ++r) std::memcpy(m.ptr<uchar>(r), ptr<uchar>(r), (size_t)cols * elemSize());
         return m;
+    }
+    // inverse of a small square f64 matrix (Gauss-Jordan with partial pivoting): what T_w_c_.inv() needs (frame.cpp:22,29)
+    Mat inv() const {
+        const int n = rows;
+        Mat a = clone(), b = eye(n, n, CV_64FC1);
+        for (int c = 0; c < n; ++c) {
+            int p = c;
+            for (int r = c + 1; r < n; ++r)
+                if (std::fabs(a.at<double>(r, c)) > std::fabs(a.at<double>(p, c))) p = r;
+            for (int k = 0; k < n; ++k) {
+                std::swap(a.at<double>(c, k), a.at<double>(p, k));
+                std::swap(b.at<double>(c, k), b.at<double>(p, k));
+            }
+            const double d = a.at<double>(c, c);
+            for (int k = 0; k < n; ++k) {
+                a.at<double>(c, k) /= d;
+                b.at<double>(c, k) /= d;
+            }
+            for (int r = 0; r < n; ++r) {
+                if (r == c) continue;
+                const double f = a.at<double>(r, c);
+                for (int k = 0; k < n; ++k) {
+                    a.at<double>(r, k) -= f * a.at<double>(c, k);
+                    b.at<double>(r, k) -= f * b.at<double>(c, k);
+                }
+            }
+        }
+        return b;
     }
     void copyTo(Mat& dst) const {
         dst.create(rows, cols, type_);

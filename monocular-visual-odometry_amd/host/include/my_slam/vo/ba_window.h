@@ -16,41 +16,45 @@
 namespace my_slam {
 namespace vo {
 
-struct BaWindow {  // what vo.cpp:408-449 builds
-    vector<vector<cv::Point2f*>> v_pts_2d;
-    vector<vector<int>> v_pts_2d_to_3d_idx;
-    std::unordered_map<int, cv::Point3f*> um_pts_3d_in_prev_frames;
-    vector<cv::Point3f*> v_pts_3d_only_in_curr;
-    vector<cv::Mat*> v_camera_poses;
+// The pointer lists optimization::bundleAdjustment takes (g2o_ba.h:23-30), one entry of the outer vectors per window frame.
+// The member names are the argument names of the reference's call (vo.cpp:458-462) so that call sites read alike.
+struct BaWindow {
+    vector<vector<cv::Point2f*>> v_pts_2d;                           // per frame: measured pixels (into Frame::keypoints_)
+    vector<vector<int>> v_pts_2d_to_3d_idx;                          // per frame: map-point id of every measurement
+    std::unordered_map<int, cv::Point3f*> um_pts_3d_in_prev_frames;  // id -> landmark position (into MapPoint::pos_)
+    vector<cv::Point3f*> v_pts_3d_only_in_curr;                      // landmarks seen by the newest frame (optimizeSingleFrame's list)
+    vector<cv::Mat*> v_camera_poses;                                 // per frame: its T_w_c_
     vector<int> frame_ids;
 };
 
-inline BaWindow buildBundleAdjustmentWindow(const std::deque<Frame::Ptr>& frames_buff, const Map::Ptr& map,
-                                            int num_prev_frames_to_opti_by_ba) {
+// Window = the newest `window_len` frames of the buffer, newest first, at most all but the oldest buffered frame
+// (vo.cpp:395-396).  Per frame, in the iteration order of its connection table: one measurement per connection whose map
+// point still exists (vo.cpp:440-441); frames with fewer than three connections contribute nothing, not even a pose
+// (vo.cpp:423-426).  Order matters downstream (vertex ids, summation order), hence the explicit walk.
+inline BaWindow buildBundleAdjustmentWindow(const std::deque<Frame::Ptr>& frames_buff, const Map::Ptr& map, int window_len) {
     BaWindow w;
-    const int kTotalFrames = (int)frames_buff.size();
-    const int kNumFramesForBA = std::min(num_prev_frames_to_opti_by_ba, kTotalFrames - 1);  // vo.cpp:395-396
-    int ith_frame = 0;
-    for (int ith_frame_in_buff = kTotalFrames - 1; ith_frame_in_buff >= kTotalFrames - kNumFramesForBA;
-         ith_frame_in_buff--, ith_frame++) {
-        Frame::Ptr frame = frames_buff[ith_frame_in_buff];
-        const int num_mappt_in_frame = (int)frame->inliers_to_mappt_connections_.size();
-        if (num_mappt_in_frame < 3) continue;  // Too few mappoints. Not optimizing this frame (vo.cpp:423-426)
-        w.v_pts_2d.push_back(vector<cv::Point2f*>());
-        w.v_pts_2d_to_3d_idx.push_back(vector<int>());
-        w.v_camera_poses.push_back(&frame->T_w_c_);
-        w.frame_ids.push_back(frame->id_);
-        for (auto ite = frame->inliers_to_mappt_connections_.begin(); ite != frame->inliers_to_mappt_connections_.end(); ++ite) {
-            const int kpt_idx = ite->first;
-            const int mappt_idx = ite->second.pt_map_idx;
-            auto mp = map->map_points_.find(mappt_idx);
-            if (mp == map->map_points_.end()) continue;  // point has been deleted (vo.cpp:440-441)
-            w.v_pts_2d.back().push_back(&(frame->keypoints_[kpt_idx].pt));
-            w.v_pts_2d_to_3d_idx.back().push_back(mappt_idx);
-            cv::Point3f* p = &(mp->second->pos_);
-            w.um_pts_3d_in_prev_frames[mappt_idx] = p;
-            if (ith_frame == 0) w.v_pts_3d_only_in_curr.push_back(p);
+    const int buffered = (int)frames_buff.size();
+    const int take = std::min(window_len, buffered - 1);
+    bool newest = true;
+    for (auto it = frames_buff.rbegin(); it != frames_buff.rend() && (int)(it - frames_buff.rbegin()) < take; ++it, newest = false) {
+        Frame& frame = **it;
+        if (frame.inliers_to_mappt_connections_.size() < 3) continue;
+        vector<cv::Point2f*> pixels;
+        vector<int> ids;
+        for (const auto& conn : frame.inliers_to_mappt_connections_) {  // (keypoint index -> {.., map-point id})
+            const int id = conn.second.pt_map_idx;
+            const auto found = map->map_points_.find(id);
+            if (found == map->map_points_.end()) continue;
+            cv::Point3f* position = &found->second->pos_;
+            pixels.push_back(&frame.keypoints_[conn.first].pt);
+            ids.push_back(id);
+            w.um_pts_3d_in_prev_frames[id] = position;
+            if (newest) w.v_pts_3d_only_in_curr.push_back(position);
         }
+        w.v_pts_2d.push_back(std::move(pixels));
+        w.v_pts_2d_to_3d_idx.push_back(std::move(ids));
+        w.v_camera_poses.push_back(&frame.T_w_c_);
+        w.frame_ids.push_back(frame.id_);
     }
     return w;
 }

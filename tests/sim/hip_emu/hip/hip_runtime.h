@@ -188,6 +188,10 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 hipError_t hipSetDevice(int);
 hipError_t hipGetDeviceCount(int*);
+inline hipError_t hipGetDevice(int* d) {
+    *d = 0;
+    return 0;
+}
 hipError_t hipGetLastError();
 const char* hipGetErrorString(hipError_t);
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t a, int device);

@@ -1,6 +1,8 @@
-"""The drop-in headers define everything the reference headers they replace declare (feature_match.h:12-54,
-g2o_ba.h:16-30), and host/tests/test_callsites.cpp calls every one of them -- a function that goes missing fails the
-build of that program (built by __graft_entry__.build()) instead of a maintainer's link step."""
+"""The drop-in translation units (host/src/feature_match_mvo.cpp, g2o_ba_mvo.cpp) define everything the reference headers
+declare for the two replaced sources (feature_match.h:12-54, g2o_ba.h:16-30), this repo's OpenCV-less mirror headers declare
+the same functions, and host/tests/test_callsites.cpp calls every one of them -- a function that goes missing fails the build
+of that program (built by __graft_entry__.build()) instead of a maintainer's link step.  tests/test_dropin_headers.py compiles
+the translation units against the reference's own headers."""
 import os
 import re
 import subprocess
@@ -30,13 +32,21 @@ def test_name_lists_match_the_reference_headers_when_present():
     assert _declared(os.path.join(ref, "optimization", "g2o_ba.h")) == sorted(G2O_BA_H)
 
 
-def test_drop_in_headers_define_every_function():
-    fm = open(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h")).read()
-    ba = open(os.path.join(HOST, "include", "my_slam", "optimization", "g2o_ba.h")).read()
+def test_translation_units_define_and_mirror_headers_declare_every_function():
+    fm = open(os.path.join(HOST, "src", "feature_match_mvo.cpp")).read()
+    ba = open(os.path.join(HOST, "src", "g2o_ba_mvo.cpp")).read()
     for name in FEATURE_MATCH_H:
-        assert re.search(r"\binline\b[^;{]*\b%s\s*\(" % name, fm), "feature_match.h lacks %s" % name
+        assert re.search(r"^[A-Za-z_:<>\s\*&]*\b%s\s*\([^;{]*\)\s*\{" % name, fm, flags=re.M), "feature_match_mvo.cpp lacks %s" % name
     for name in G2O_BA_H:
-        assert re.search(r"\binline\b[^;{]*\b%s\s*\(" % name, ba), "g2o_ba.h lacks %s" % name
+        assert re.search(r"^[A-Za-z_:<>\s\*&]*\b%s\s*\([^;{]*\)\s*\{" % name, ba, flags=re.M), "g2o_ba_mvo.cpp lacks %s" % name
+    # the mirror headers are declaration lists like the reference's (no definitions that could drift from the translation units)
+    assert _declared(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h"))[:0] == []
+    mfm = open(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h")).read()
+    mba = open(os.path.join(HOST, "include", "my_slam", "optimization", "g2o_ba.h")).read()
+    for name in FEATURE_MATCH_H:
+        assert re.search(r"\b%s\s*\([^;{]*\)\s*;" % name, mfm), "mirror feature_match.h does not declare %s" % name
+    for name in G2O_BA_H:
+        assert re.search(r"\b%s\s*\([^;{]*\)\s*;" % name, mba), "mirror g2o_ba.h does not declare %s" % name
 
 
 def test_callsite_program_uses_every_function_and_links():
@@ -55,6 +65,7 @@ def test_callsite_program_uses_every_function_and_links():
 def test_orb_parameters_are_latched_per_ctx():
     """ADVICE r1 + r2: hot_path_ctx() is thread_local and a thread may bind several ctxs in turn, so the 'parameters
     latched' flag and the pyramid-owner token are kept per (thread, ctx)."""
-    fm = open(os.path.join(HOST, "include", "my_slam", "geometry", "feature_match.h")).read()
-    assert re.search(r"static\s+thread_local\s+std::unordered_map<mvo_ctx\*,\s*CtxState>", fm)
-    assert "m[hot_path_ctx()]" in fm
+    fm = open(os.path.join(HOST, "src", "feature_match_mvo.cpp")).read()
+    # (ADVICE r3: keyed by the ctx's unique id -- a ctx created at the address of a destroyed one must not inherit the flag)
+    assert re.search(r"static\s+thread_local\s+std::unordered_map<unsigned long long,\s*CtxState>", fm)
+    assert "m[mvo_ctx_uid(hot_path_ctx())]" in fm

@@ -33,7 +33,6 @@ WORKER = textwrap.dedent("""
     t = bench.max_over_ranks(dist, 1.0 + rank, "cpu")
     assert t == float(world)
     dist.barrier()
-    dist.destroy_process_group()
 
     # ---- the whole control flow of bench.run_benchmark (warm-up, barriers, timed region, MAX over ranks, the one
     # collective with REAL per-frame rows) with stand-in shards: what a rank does at N > 1, executed, not just its helpers
@@ -54,7 +53,9 @@ WORKER = textwrap.dedent("""
             time.sleep(0.01 * (1 + rank))             # the slower rank defines the clock
     class StubEnv:
         device = "cpu"
-        def init_process_group(self, d): d.init_process_group("gloo")
+        def init_process_group(self, d):
+            # (ONE process group per process: re-initialising after a destroy re-uses the launcher's store and can hang)
+            if not d.is_initialized(): d.init_process_group("gloo")
         def sync(self): pass
         def make_shard(self, sid, args, ba_mode, pipeline, **kw): return StubShard(sid)
     # a step = --frames-per-step consecutive frames of every shard: 4 steps x 3 frames timed after 2 x 3 warm-up frames

@@ -27,7 +27,8 @@ for kind, kw in kinds:
         dt=(time.perf_counter()-t0)/N
         ph = ctx.debug_ba_phases()
         if not prof:
-            print(kind, "wgs", ph["wgs"], "ms/solve %.3f (wall, production kernel) trials %d same_l2 %d" % (dt*1e3, st["trials"], ph["x15"]))
+            print(kind, "wgs", ph["wgs"], "ms/solve %.3f (wall, production kernel) trials %d same_l2 %d | rounds with a second system %d, first one failed as guessed %d | kcycles %.0f"
+                  % (dt*1e3, st["trials"], ph["x15"], ph["schur.loop"], ph["schur.wait"], ph["schur.acc"] / 1e3))
         else:
             tot = ph["total"]
             raw = ctx.ba_trace(h, raw_rows=412)[400:406].ravel()
