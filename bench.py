@@ -377,6 +377,63 @@ def pmc_mfma_busy(kernel):
     return best
 
 
+def rank_cpu_slice(cpus, local_rank, local_world, gpu_numa=None, cpu_numa=None):
+    """CPUs the threads of local rank `local_rank` are confined to when `local_world` ranks share one host (one
+    rank per GPU, each with ~26 threads -- 24 sequence shards, the solver's scheduler, its completion thread).  Without it the
+    8 x 26 threads of a node wander over all cores: a shard thread is woken on the far socket, the pinned mailboxes the
+    resident solver grid polls end up on whatever NUMA node the allocating thread happened to run on.
+    `cpus`: the CPUs this process may use (sorted).  With NUMA information -- `gpu_numa[r]` = node of rank r's GPU,
+    `cpu_numa[c]` = node of CPU c -- a rank gets an equal share of ITS GPU's node (split among the ranks of that node);
+    otherwise the CPU list is cut into `local_world` contiguous slices.  Pure function (tested on CPU)."""
+    cpus = sorted(cpus)
+    if local_world <= 1 or not cpus:
+        return cpus
+    if gpu_numa is not None and cpu_numa is not None and len(gpu_numa) >= local_world:
+        node = gpu_numa[local_rank]
+        mine = [c for c in cpus if cpu_numa.get(c) == node]
+        peers = [r for r in range(local_world) if gpu_numa[r] == node]
+        if mine and len(mine) >= len(peers):
+            k = peers.index(local_rank)
+            per = len(mine) // len(peers)
+            return mine[k * per:(k + 1) * per] if k < len(peers) - 1 else mine[k * per:]
+    per = max(1, len(cpus) // local_world)
+    lo = min(local_rank * per, len(cpus) - 1)
+    return cpus[lo:lo + per] if local_rank < local_world - 1 else cpus[lo:]
+
+
+def host_numa_maps(local_world):
+    """(gpu_numa, cpu_numa) from sysfs, or (None, None): node of every local GPU (by the PCI address torch reports) and of
+    every CPU."""
+    try:
+        import torch
+        cpu_numa = {}
+        for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+            node = int(os.path.basename(d)[4:])
+            for part in open(os.path.join(d, "cpulist")).read().strip().split(","):
+                a, _, b = part.partition("-")
+                for c in range(int(a), int(b or a) + 1):
+                    cpu_numa[c] = node
+        gpu_numa = []
+        for r in range(local_world):
+            pr = torch.cuda.get_device_properties(r)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+            gpu_numa.append(max(node, 0))
+        return (gpu_numa, cpu_numa) if cpu_numa else (None, None)
+    except Exception:  # noqa: BLE001  (no sysfs, no such attribute: fall back to contiguous slices)
+        return None, None
+
+
+def confine_rank_to_its_cpus(local_rank, local_world, numa=(None, None)):
+    """Applied before any context, stream, thread or pinned buffer of the rank exists (all of them inherit it)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = rank_cpu_slice(os.sched_getaffinity(0), local_rank, local_world, *numa)
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return cpus
+
+
 class GpuEnv:
     """What main() needs from the machine: the process group, the device, barriers and shards.  tests/ substitute a CPU
     stand-in (gloo, stub shards) to execute the N > 1 control flow without a GPU."""
@@ -388,9 +445,16 @@ class GpuEnv:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+        # N > 1 ranks on one host: every rank keeps to its own CPUs (those of its GPU's NUMA node when sysfs tells), and waits
+        # for the device by yielding instead of spinning when its threads outnumber its CPUs -- unmeasured on hardware
+        # (the driver runs the multi-GPU bench), exercised on CPU by tests/test_distributed_gloo.py
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        self.cpus = confine_rank_to_its_cpus(self.local, local_world, host_numa_maps(local_world) if local_world > 1 else (None, None))
         torch.cuda.set_device(self.local)
         self.device = "cuda"
         self.mvo = graft.load_package()
+        if self.cpus is not None and len(self.cpus) < args.streams + 4:
+            self.mvo.set_wait_policy(self.local, "yield")
 
     def init_process_group(self, dist):
         dist.init_process_group(self.backend, device_id=self.torch.device("cuda", self.local))

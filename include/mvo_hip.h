@@ -69,6 +69,15 @@ unsigned long long mvo_ctx_uid(const mvo_ctx* ctx);
 const char* mvo_last_error(const mvo_ctx* ctx);
 /* Blocks until all work queued on the ctx stream is done. */
 int mvo_synchronize(mvo_ctx* ctx);
+/* How the host threads of this process wait for `device` (hipSetDeviceFlags): 0 auto (the runtime's choice: spinning while
+ * there are enough cores), 1 spin, 2 yield, 3 block on an interrupt.  A process whose waiting threads outnumber its CPUs
+ * (one rank of a multi-GPU node confined to its share of the cores, 24 sequence threads each) should yield or block.  No
+ * reference counterpart (OpenCV / g2o do not wait for a device). */
+#define MVO_WAIT_AUTO 0
+#define MVO_WAIT_SPIN 1
+#define MVO_WAIT_YIELD 2
+#define MVO_WAIT_BLOCK 3
+int mvo_set_wait_policy(int device, int policy);
 /* Replaces basics::Config::get<...> latching in feature_match.cpp:16-19,42-45,56-59.  Also resets the
  * latched grid dimensions (feature_match.cpp:59-62 latches rows/cols from the FIRST image). */
 int mvo_orb_configure(mvo_ctx* ctx, const mvo_orb_params* params);

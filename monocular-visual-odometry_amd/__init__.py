@@ -503,6 +503,13 @@ class Context:
         return out[:n.value].copy()
 
 
+def set_wait_policy(device, policy):
+    """How host threads wait for `device`: "spin" | "yield" | "block" | "auto" (mvo_set_wait_policy)."""
+    r = load_library().mvo_set_wait_policy(int(device), {"auto": 0, "spin": 1, "yield": 2, "block": 3}[policy])
+    if r != MVO_OK:
+        raise MvoError(r, "mvo_set_wait_policy")
+
+
 def debug_set(key, value):
     r = load_library().mvo_debug_set(key.encode(), int(value))
     if r != MVO_OK:

@@ -118,6 +118,20 @@ int mvo_create(mvo_ctx** out, int device) {
 
 unsigned long long mvo_ctx_uid(const mvo_ctx* ctx) { return ctx ? ctx->uid : 0ull; }
 
+int mvo_set_wait_policy(int device, int policy) {
+    if (policy < MVO_WAIT_AUTO || policy > MVO_WAIT_BLOCK) return MVO_ERR_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MVO_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return MVO_ERR_NO_DEVICE;
+    static const unsigned flags[4] = {hipDeviceScheduleAuto, hipDeviceScheduleSpin, hipDeviceScheduleYield, hipDeviceScheduleBlockingSync};
+    const hipError_t e = hipSetDeviceFlags(flags[policy]);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return MVO_ERR_HIP;
+    }
+    return MVO_OK;
+}
+
 int mvo_create_sibling(mvo_ctx* parent, mvo_ctx** out) {
     if (!out) return MVO_ERR_INVALID;
     *out = nullptr;

@@ -8,7 +8,10 @@ make_golden.py's fixtures, produced by the library calls the reference makes:
                               (feature_match.cpp:42-48)
   reference_match_150x170.npz cv::BFMatcher(NORM_HAMMING).knnMatch k = 2 (the exact answer) and the reference's
                               FlannBasedMatcher(LshIndexParams(5, 10, 2)) (feature_match.cpp:140, 161, 182) side by side
-  reference_ba_3x40.npz       only if a g2o Python binding is importable (g2opy); otherwise not written
+  reference_ba_3x40.npz       through a g2o Python binding (g2opy) if one is importable -- or WITHOUT one: `--export-ba-text`
+                              writes tests/golden/ba_3x40.txt, tests/golden/reference_ba_driver.cpp (linked with the
+                              reference's own src/optimization/g2o_ba.cpp: build line in its header) turns it into
+                              reference_ba_3x40.txt, `--import-ba-text reference_ba_3x40.txt` makes the .npz
 
 None of this can run in the authoring container (no cv2, no network), so no reference_*.npz is committed yet and
 the oracle stays "parity unpinned" (DESIGN.md section 2).  tests/test_reference_golden.py is the pinned-parity check: it
@@ -47,7 +50,45 @@ def grid_select(kps, rows, cols, grid_size=16, per_cell=8, max_keypoints=300):
     return out
 
 
+def export_ba_text(path=None):
+    """ba_3x40.npz -> the plain-text window tests/golden/reference_ba_driver.cpp reads (points and pixels as float: the
+    reference stores them as cv::Point3f / cv::Point2f)."""
+    b = np.load(os.path.join(HERE, "ba_3x40.npz"))
+    path = path or os.path.join(HERE, "ba_3x40.txt")
+    f, cx, cy = [float(v) for v in b["intr"]]
+    with open(path, "w") as o:
+        o.write("%d %d %d %.17g %.17g %.17g 1 0 0 1 0 1\n" % (len(b["poses0"]), len(b["points0"]), len(b["edge_pose"]), f, cx, cy))
+        for T in b["poses0"]:
+            o.write(" ".join("%.17g" % v for v in T.ravel()) + "\n")
+        for X in b["points0"].astype(np.float32):
+            o.write("%.9g %.9g %.9g\n" % tuple(X))
+        for p, l, uv in zip(b["edge_pose"], b["edge_point"], b["edge_uv"].astype(np.float32)):
+            o.write("%d %d %.9g %.9g\n" % (p, l, uv[0], uv[1]))
+    print("wrote", path)
+    return 0
+
+
+def import_ba_text(path):
+    """The driver's output (F lines of 16 doubles, L lines of 3 floats) -> reference_ba_3x40.npz."""
+    b = np.load(os.path.join(HERE, "ba_3x40.npz"))
+    rows = [np.array(line.split(), np.float64) for line in open(path) if line.strip()]
+    F, L = len(b["poses0"]), len(b["points0"])
+    assert len(rows) == F + L, (len(rows), F, L)
+    poses = np.stack(rows[:F]).reshape(F, 4, 4)
+    pts = np.stack(rows[F:])
+    np.savez_compressed(os.path.join(HERE, "reference_ba_3x40.npz"), poses0=b["poses0"],
+                        points0=b["points0"].astype(np.float32).astype(np.float64), edge_pose=b["edge_pose"],
+                        edge_point=b["edge_point"], edge_uv=b["edge_uv"].astype(np.float32).astype(np.float64), intr=b["intr"],
+                        full50_poses=poses, full50_points=pts)
+    print("wrote reference_ba_3x40.npz from", path)
+    return 0
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--export-ba-text":
+        return export_ba_text(sys.argv[2] if len(sys.argv) > 2 else None)
+    if len(sys.argv) > 2 and sys.argv[1] == "--import-ba-text":
+        return import_ba_text(sys.argv[2])
     try:
         import cv2
     except ImportError:
@@ -90,9 +131,10 @@ def main():
 
 
 def write_ba(g2o):
-    """src/optimization/g2o_ba.cpp:127-246 through g2opy: VertexSE3Expmap / VertexSBAPointXYZ (marginalized) /
-    EdgeProjectXYZ2UV + RobustKernelHuber(sqrt 5.991), OptimizationAlgorithmLevenberg over BlockSolver_6_3 with the
-    dense linear solver, 50 iterations."""
+    """src/optimization/g2o_ba.cpp:193-289 through g2opy: VertexSE3Expmap / VertexSBAPointXYZ (marginalized) /
+    EdgeProjectXYZ2UV + RobustKernelHuber() (default delta 1, g2o_ba.cpp:268), OptimizationAlgorithmLevenberg over
+    BlockSolver_6_3 with the dense linear solver, 50 iterations.  Poses go in as world -> camera (g2o_ba.cpp:185-190
+    inverts T_w_c) and come back inverted again (:298-306)."""
     b = np.load(os.path.join(HERE, "ba_3x40.npz"))
     f, cx, cy = [float(v) for v in b["intr"]]
     opt = g2o.SparseOptimizer()
@@ -104,7 +146,8 @@ def write_ba(g2o):
     for i, T in enumerate(b["poses0"]):
         v = g2o.VertexSE3Expmap()
         v.set_id(i)
-        v.set_estimate(g2o.SE3Quat(T[:3, :3], T[:3, 3]))
+        Tcw = np.linalg.inv(T)
+        v.set_estimate(g2o.SE3Quat(Tcw[:3, :3], Tcw[:3, 3]))
         opt.add_vertex(v)
     for j, X in enumerate(b["points0"]):
         v = g2o.VertexSBAPointXYZ()
@@ -119,12 +162,12 @@ def write_ba(g2o):
         e.set_measurement(uv)
         e.set_parameter_id(0, 0)
         e.set_information(np.eye(2))
-        e.set_robust_kernel(g2o.RobustKernelHuber(np.sqrt(5.991)))
+        e.set_robust_kernel(g2o.RobustKernelHuber())
         opt.add_edge(e)
     opt.initialize_optimization()
     opt.optimize(50)
-    poses = np.stack([np.vstack([np.hstack([opt.vertex(i).estimate().rotation().matrix(),
-                                            opt.vertex(i).estimate().translation().reshape(3, 1)]), [0, 0, 0, 1]])
+    poses = np.stack([np.linalg.inv(np.vstack([np.hstack([opt.vertex(i).estimate().rotation().matrix(),
+                                                          opt.vertex(i).estimate().translation().reshape(3, 1)]), [0, 0, 0, 1]]))
                       for i in range(F)])
     pts = np.stack([opt.vertex(F + j).estimate() for j in range(L)])
     np.savez_compressed(os.path.join(HERE, "reference_ba_3x40.npz"), poses0=b["poses0"], points0=b["points0"],

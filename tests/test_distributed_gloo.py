@@ -75,6 +75,97 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
+WORKER8 = textwrap.dedent("""
+    import os, sys, threading, time, types
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, %r)
+    import bench
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local, local_world = int(os.environ["LOCAL_RANK"]), int(os.environ["LOCAL_WORLD_SIZE"])
+    allowed = sorted(os.sched_getaffinity(0))
+    mine = bench.confine_rank_to_its_cpus(local, local_world)
+    assert mine and set(mine) <= set(allowed) and sorted(os.sched_getaffinity(0)) == mine
+    dist.init_process_group("gloo")
+    slices = [None] * world
+    dist.all_gather_object(slices, mine)
+    if len(allowed) >= world:                       # disjoint cover of the host's CPUs
+        flat = sum(slices, [])
+        assert sorted(flat) == allowed, (flat, allowed)
+    together = threading.Barrier(24)     # a shard's run() returns only when all 24 sequence threads of the rank are in theirs
+    class StubCtx:
+        def ba_launch_stats(self, reset=False): return dict(launches=1, windows=1, ms=1.0)
+        def ba_service_times(self): return {}
+        def synchronize(self): pass
+    class StubShard:
+        def __init__(self, sid):
+            self.id, self.traj, self.ctx, self.frame = sid, [], StubCtx(), 0
+        def state(self):
+            return types.SimpleNamespace(ba_trials=10 * self.frame, ba_solves=self.frame, ba_edges=100 * self.frame, frame_no=self.frame)
+        def run(self, n):
+            together.wait(timeout=120)
+            assert set(os.sched_getaffinity(0)) == set(mine)          # shard threads inherit the rank's slice
+            for _ in range(n):
+                self.traj.append(np.full(12, 1000.0 * self.id + self.frame))
+                self.frame += 1
+            time.sleep(0.002)
+    class StubEnv:
+        device = "cpu"
+        def init_process_group(self, d):
+            if not d.is_initialized(): d.init_process_group("gloo")
+        def sync(self): pass
+        def make_shard(self, sid, args, ba_mode, pipeline, **kw): return StubShard(sid)
+    args = bench.parse(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--streams", "24", "--frames-per-step", "2"])
+    R = bench.run_benchmark(args, StubEnv())
+    assert R["world"] == world and R["traj_all"].shape == (world, 24, 6, 12)
+    for r in range(world):
+        for s_ in range(24):
+            assert np.array_equal(R["traj_all"][r, s_, :, 0], 1000.0 * (r * 24 + s_) + np.arange(2, 8))
+    assert abs(R["value"] - world * 24 * 6 / R["elapsed"]) < 1e-9
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_rank_cpu_slices_partition_the_host():
+    """bench.rank_cpu_slice: N ranks of one host get disjoint CPU sets that cover what the process may use -- contiguous
+    slices without NUMA information, the GPU's own node split among the ranks of that node with it (the
+    driver's 8-GPU node: 256 CPUs, 2 nodes, 4 GPUs each)."""
+    import bench
+    cpus = list(range(256))
+    plain = [bench.rank_cpu_slice(cpus, r, 8) for r in range(8)]
+    assert sorted(sum(plain, [])) == cpus and all(len(p) == 32 for p in plain)
+    assert plain[3] == list(range(96, 128))
+    cpu_numa = {c: (0 if c < 64 or 128 <= c < 192 else 1) for c in cpus}      # (SMT siblings share a node)
+    gpu_numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    numa = [bench.rank_cpu_slice(cpus, r, 8, gpu_numa, cpu_numa) for r in range(8)]
+    assert sorted(sum(numa, [])) == cpus
+    for r in range(8):
+        assert len(numa[r]) == 32 and {cpu_numa[c] for c in numa[r]} == {gpu_numa[r]}
+    # uneven cases: 3 ranks on 8 CPUs (this container), more ranks than CPUs of a node, a single rank
+    odd = [bench.rank_cpu_slice(range(8), r, 3) for r in range(3)]
+    assert sorted(sum(odd, [])) == list(range(8)) and all(odd)
+    few = [bench.rank_cpu_slice(range(4), r, 8) for r in range(8)]
+    assert all(len(f) >= 1 for f in few)
+    assert bench.rank_cpu_slice(range(8), 0, 1) == list(range(8))
+    starved = [bench.rank_cpu_slice(cpus, r, 8, [0] * 8, {c: (0 if c < 4 else 1) for c in cpus}) for r in range(8)]
+    assert sorted(sum(starved, [])) == cpus                                       # (node too small: contiguous slices instead)
+
+
+def test_world_size_8_gloo_with_the_real_thread_counts(tmp_path):
+    """The driver's largest run: 8 ranks x 24 sequence threads on one host, every rank confined to its CPU slice, the
+    barriers / MAX-over-ranks clock / one all_gather of bench.run_benchmark -- with stand-in shards (no GPU here)."""
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 8
+
+
 def test_world_size_2_gloo(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
