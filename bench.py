@@ -49,7 +49,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=24, help="sequence shards in flight per GPU")
+    ap.add_argument("--streams", type=int, default=32, help="sequence shards in flight per GPU (32: the solver slots stay full on hosts whose per-frame host work is slower; 24 suffices on fast ones)")
     ap.add_argument("--frames-per-step", type=int, default=10,
                     help="consecutive frames every shard advances in one step (a step = one batch: streams x this many frames)")
     ap.add_argument("--ba", default="full", choices=["full", "pose_only"],

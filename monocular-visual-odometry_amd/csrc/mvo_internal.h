@@ -152,6 +152,7 @@ struct mvo_ctx {
     std::vector<int> quota;
     bool pyr_valid = false, blur_valid = false;
     bool pyr_group_tiled[MVO_MAX_LEVELS] = {false};  // per level group: every tile's regions fit the LDS pool
+    int pyr_group_lds[MVO_MAX_LEVELS] = {0};         // ... and the bytes of it the hungriest tile of the group needs
     int pyr_levels_built = 0;
     uint8_t* d_img = nullptr;
     size_t d_img_cap = 0;

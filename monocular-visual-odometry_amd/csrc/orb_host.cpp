@@ -206,6 +206,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     };
     for (int l0 = 0; l0 < p.nlevels; l0 += 4) {
         bool fits = true;
+        int need = 0;
         const int base = l0 == 0 ? 0 : l0 - 1;
         for (int l = std::max(l0, 1); l < std::min(l0 + 4, p.nlevels) && fits; ++l) {
             const LevelInfo& L = P.lv[l];
@@ -222,10 +223,13 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
                     }
                     PyrRegion reg[8];
                     int off[8];
-                    fits = pyr_regions(P, tabs.data(), l, l - base, xlo, xhi, ylo, yhi, reg, off) <= PYR_LDS_BYTES;
+                    const int used = pyr_regions(P, tabs.data(), l, l - base, xlo, xhi, ylo, yhi, reg, off);
+                    need = std::max(need, used);
+                    fits = used <= PYR_LDS_BYTES;
                 }
         }
         ctx->pyr_group_tiled[l0 / 4] = fits;
+        ctx->pyr_group_lds[l0 / 4] = std::min(PYR_LDS_BYTES, (need + 255) & ~255);  // (dynamic LDS of the group's launch)
     }
     ctx->pyr = P;
     ctx->pyr_bytes = bytes;

@@ -130,7 +130,9 @@ __device__ __forceinline__ int pyr_sample(const uint8_t* __restrict__ S, const P
 
 __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
                                                  const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
-    __shared__ uint8_t lds[PYR_LDS_BYTES];
+    // region pool: dynamic LDS sized by the host for the hungriest tile of THIS launch (orb_setup_geometry: ~9 KB for the
+    // 4-level 640 x 480 pyramid; the fixed 32 KB pool of round 3 let only four workgroups share a CU)
+    extern __shared__ uint8_t lds[];
     __shared__ int sbox[4];
     const int tid = threadIdx.x;
     int l = l0;
@@ -641,12 +643,16 @@ struct __attribute__((aligned(16))) BriefLds {
     uint16_t hb[BW_RAW_ROWS * BW_STRIDE];
     uint32_t out[BW_ROWS * (BW_STRIDE / 4)];
 };
-__global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ rawpyr, const DevDescKp* __restrict__ kps,
-                                               uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host, PyrInfo P,
-                                               int n) {
-    __shared__ BriefLds lds[4];
+// WAVES keypoints per workgroup (one wave each, 8.7 KB of LDS each).  WAVES = 1 (round 4): the waves of a workgroup share
+// nothing, and small workgroups let a CU hold as many of them as its wave slots allow instead of four 35-KB ones -- next to the
+// resident solver grid the extraction kernels live on 6 CUs per XCD, where occupancy is throughput.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_brief(const uint8_t* __restrict__ rawpyr, const DevDescKp* __restrict__ kps,
+                                                      uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host, PyrInfo P,
+                                                      int n) {
+    __shared__ BriefLds lds[WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int ki = blockIdx.x * 4 + wave;
+    const int ki = blockIdx.x * WAVES + wave;
     if (ki >= n) return;
     const DevDescKp kp = kps[ki];
     const LevelInfo L = P.lv[__builtin_amdgcn_readfirstlane(kp.level)];  // (wave-uniform: scalar loads)
@@ -741,6 +747,8 @@ __global__ __launch_bounds__(256) void k_brief(const uint8_t* __restrict__ rawpy
 // ================================================================================================ launchers
 static bool g_tables_ready[16] = {false};
 int g_pyr_force_chain = 0;  // test hook: the per-pixel chain kernel instead of the LDS-tiled one
+int g_pyr_full_pool = std::getenv("MVO_PYR_FULL_POOL") ? std::atoi(std::getenv("MVO_PYR_FULL_POOL")) : 0;  // A/B: the fixed 32-KB pool
+int g_brief_waves = std::getenv("MVO_BRIEF_WAVES") ? std::atoi(std::getenv("MVO_BRIEF_WAVES")) : 4;        // A/B: 1 = one keypoint per workgroup (measured: no gain under load, 3 us slower alone)
 
 static int upload_constant_tables(mvo_ctx* ctx) {
     if (ctx->device < 16 && g_tables_ready[ctx->device]) return MVO_OK;
@@ -786,7 +794,8 @@ int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int chann
         const bool tiled = ctx->pyr_group_tiled[l0 / PYR_GROUP] && !g_pyr_force_chain;
         ProfScope ps(ctx, tiled ? "k_pyramid" : "k_pyramid_chain");
         if (tiled)
-            hipLaunchKernelGGL(k_pyramid, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
+            hipLaunchKernelGGL(k_pyramid, dim3(nblk), dim3(256), g_pyr_full_pool ? PYR_LDS_BYTES : ctx->pyr_group_lds[l0 / PYR_GROUP],
+                               ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
         else
             hipLaunchKernelGGL(k_pyramid_chain, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
     }
@@ -824,8 +833,10 @@ int orb_launch_blur(mvo_ctx* ctx, int nlevels) {
 int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps, uint8_t* desc_host) {
     if (n <= 0) return MVO_OK;
     ProfScope ps(ctx, "k_brief");
-    hipLaunchKernelGGL(k_brief, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_raw, kps, ctx->d_desc, desc_host,
-                       ctx->pyr, n);
+    if (g_brief_waves == 4)
+        hipLaunchKernelGGL((k_brief<4>), dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_raw, kps, ctx->d_desc, desc_host, ctx->pyr, n);
+    else
+        hipLaunchKernelGGL((k_brief<1>), dim3(n), dim3(64), 0, ctx->stream, ctx->d_raw, kps, ctx->d_desc, desc_host, ctx->pyr, n);
     MVO_HIP(hipGetLastError());
     return MVO_OK;
 }
