@@ -687,8 +687,19 @@ struct StageTimes {
 };
 static thread_local StageTimes g_stage_times;
 
+// Working vectors of ba_stage, kept per host thread: a BA5 window needs ~0.5 MB of them per call, and the larger ones
+// (150 KB of sorted measurements) sit above malloc's mmap threshold -- fresh pages every frame otherwise.
+struct StageScratch {
+    std::vector<int> pose_slot, slot_pose, act, deg, wg_edge, owner, wg_pose, cnt, e_pose, e_point, ptstart, ptlist, cur, cur2;
+    std::vector<double> e_uv;
+    std::vector<short> eof, dup, seen, pkt;
+    int pkt_n = -1;
+};
+static thread_local StageScratch g_stage_scratch;
+
 int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_trace) {
     g_stage_times.start();
+    StageScratch& SC = g_stage_scratch;
     BaPlan& P = ws.plan;
     P = BaPlan();
     const int F = p->n_poses, L = p->n_points;
@@ -698,7 +709,9 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     if (!(a > 0) || std::fabs(b - c) > 1e-12 * (std::fabs(a) + std::fabs(d)) || !(a * d - b * b > 0))
         return mvo_set_err(ctx, MVO_ERR_INVALID, "information matrix must be symmetric positive definite", hipSuccess);
     const double lc00 = std::sqrt(a), lc01 = b / lc00, lc11 = std::sqrt(d - lc01 * lc01);
-    std::vector<int> pose_slot(F, -1), slot_pose;
+    std::vector<int>&pose_slot = SC.pose_slot, &slot_pose = SC.slot_pose;
+    pose_slot.assign(F, -1);
+    slot_pose.clear();
     for (int i = 0; i < F; ++i)
         if (!(p->pose_fixed && p->pose_fixed[i])) {
             pose_slot[i] = (int)slot_pose.size();
@@ -706,9 +719,10 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         }
     const int nfree = (int)slot_pose.size();
     // active edges: SparseOptimizer::initializeOptimization drops edges whose vertices are all fixed
-    std::vector<int> act;
+    std::vector<int>&act = SC.act, &deg = SC.deg;
+    act.clear();
     act.reserve(p->n_edges);
-    std::vector<int> deg(L, 0);
+    deg.assign(L, 0);
     for (int e = 0; e < p->n_edges; ++e) {
         if (pose_slot[p->edge_pose[e]] < 0 && p->fix_points) continue;
         act.push_back(e);
@@ -770,7 +784,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     int env_nsplit = 0;
     if (const char* env = std::getenv("MVO_BA_NSPLIT")) env_nsplit = std::max(1, std::atoi(env));
     std::vector<int>& wg_pt = P.wg_pt;
-    std::vector<int> wg_edge, owner(L, 0), wg_pose;
+    std::vector<int>&wg_edge = SC.wg_edge, &owner = SC.owner, &wg_pose = SC.wg_pose;
+    owner.assign(L, 0);
     int maxEg = 0, maxLg = 0, maxEpose = 0, nsplit = 1, npar = 1, nseq = 1;
     size_t uarea = 0;
     for (;;) {
@@ -795,7 +810,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
             for (int ll = wg_pt[g]; ll < wg_pt[g + 1]; ++ll) owner[ll] = g;
         wg_pose.assign((size_t)G * (F + 1), 0);
         {
-            std::vector<int> cnt((size_t)G * std::max(F, 1), 0);
+            std::vector<int>& cnt = SC.cnt;
+            cnt.assign((size_t)G * std::max(F, 1), 0);
             for (int e : act) cnt[(size_t)owner[p->edge_point[e]] * F + p->edge_pose[e]]++;
             int acc = 0;
             maxEpose = 0;
@@ -881,10 +897,16 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.maxLg = maxLg;
     P.slice = (nlow + G - 1) / G;
     // ---- edges sorted by (owner workgroup, pose); adjacency tables
-    std::vector<int> e_pose(E), e_point(E), ptstart(L + 1, 0), ptlist(E);
-    std::vector<double> e_uv(2 * (size_t)E);
+    std::vector<int>&e_pose = SC.e_pose, &e_point = SC.e_point, &ptstart = SC.ptstart, &ptlist = SC.ptlist;
+    std::vector<double>& e_uv = SC.e_uv;
+    e_pose.resize(E);
+    e_point.resize(E);
+    ptstart.assign(L + 1, 0);
+    ptlist.resize(E);
+    e_uv.resize(2 * (size_t)E);
     {
-        std::vector<int> cur((size_t)G * std::max(F, 1));
+        std::vector<int>& cur = SC.cur;
+        cur.resize((size_t)G * std::max(F, 1));
         for (int g = 0; g < G; ++g)
             for (int q = 0; q < F; ++q) cur[(size_t)g * F + q] = wg_pose[(size_t)g * (F + 1) + q];
         for (int e : act) {
@@ -898,15 +920,19 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     for (int k = 0; k < E; ++k) ptstart[e_point[k] + 1]++;
     for (int i = 0; i < L; ++i) ptstart[i + 1] += ptstart[i];
     {
-        std::vector<int> cur(ptstart.begin(), ptstart.end() - 1);
+        std::vector<int>& cur = SC.cur2;
+        cur.assign(ptstart.begin(), ptstart.end() - 1);
         for (int k = 0; k < E; ++k) ptlist[cur[e_point[k]]++] = k;
     }
     // first observation of every (landmark, pose slot) pair and the rank of every edge among the observations of its pair
     // (ascending edge order: the order in which the oracle adds them)
-    std::vector<short> eof((size_t)std::max(L, 1) * std::max(nfree, 1), -1), dup(std::max(E, 1), 0);
+    std::vector<short>&eof = SC.eof, &dup = SC.dup;
+    eof.assign((size_t)std::max(L, 1) * std::max(nfree, 1), -1);
+    dup.assign(std::max(E, 1), 0);
     int max_dup = 0;
     {
-        std::vector<short> seen((size_t)std::max(L, 1) * std::max(nfree, 1), 0);
+        std::vector<short>& seen = SC.seen;
+        seen.assign((size_t)std::max(L, 1) * std::max(nfree, 1), 0);
         for (int k = 0; k < E; ++k) {
             const int sl = pose_slot[e_pose[k]];
             if (sl < 0) continue;
@@ -918,8 +944,10 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     }
     P.max_dup = max_dup;
     // ---- packed order of the reduced system and its place inside the 16 x 16 tile pairs
-    std::vector<short> pkt((size_t)npair * 256, -1);
-    {
+    std::vector<short>& pkt = SC.pkt;  // (depends on n only: kept from the last window of this thread)
+    if (SC.pkt_n != n) {
+        SC.pkt_n = n;
+        pkt.assign((size_t)npair * 256, -1);
         int pr = 0;
         for (int ti = 0; ti < NT; ++ti)
             for (int tj = ti; tj < NT; ++tj, ++pr)

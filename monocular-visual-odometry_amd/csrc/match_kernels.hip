@@ -15,12 +15,18 @@
 #include "mvo_internal.h"
 
 #include <climits>
+#include <cstdlib>
+#include <algorithm>
 
 typedef unsigned long long u64;
 
 #define MK_WAVES 16
 
 int g_match_mfma = 1;  // test hook: 0 = the vector-ALU kernel k_knn2 for every call
+// trains per slice of k_knn2_mfma in THROUGHPUT-mode contexts (latency mode: MM_TS = 256): a slice's LDS image (272 B per
+// train) decides how many workgroups share a CU -- 256 trains = 68 KB = two workgroups (8 waves) per CU, fine for a lone
+// frame on an empty chip, a waste of the few CUs the resident solver grid leaves to the extraction
+int g_match_slice_throughput = std::getenv("MVO_MATCH_SLICE") ? std::atoi(std::getenv("MVO_MATCH_SLICE")) : 256;
 
 struct Top2 {
     int d0, i0, d1, i1;
@@ -298,7 +304,8 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
     ProfScope ps(ctx, "k_knn2");
     if (g_match_mfma && nt > 0 && nt < 65536) {
         // slices of <= MM_TS trains, at most 64 of them (the partial area holds 64 x nq x 16 B)
-        int nsl = (nt + MM_TS - 1) / MM_TS;
+        const int ts = ctx->ba_throughput_mode ? std::max(16, std::min(MM_TS, g_match_slice_throughput & ~15)) : MM_TS;
+        int nsl = (nt + ts - 1) / ts;
         if (nsl > 64) nsl = 64;
         int slice = ((nt + nsl - 1) / nsl + 15) & ~15;
         if (slice <= MM_TS) {

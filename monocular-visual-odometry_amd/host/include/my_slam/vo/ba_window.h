@@ -33,6 +33,8 @@ struct BaWindow {
 // (vo.cpp:423-426).  Order matters downstream (vertex ids, summation order), hence the explicit walk.
 inline BaWindow buildBundleAdjustmentWindow(const std::deque<Frame::Ptr>& frames_buff, const Map::Ptr& map, int window_len) {
     BaWindow w;
+    // (no reserve() on the id -> landmark table: its iteration order becomes the landmark order of the graph, g2o_ba.cpp:225-243,
+    // and must be what the reference's default-constructed table of vo.cpp:404 would yield)
     const int buffered = (int)frames_buff.size();
     const int take = std::min(window_len, buffered - 1);
     bool newest = true;
@@ -41,6 +43,8 @@ inline BaWindow buildBundleAdjustmentWindow(const std::deque<Frame::Ptr>& frames
         if (frame.inliers_to_mappt_connections_.size() < 3) continue;
         vector<cv::Point2f*> pixels;
         vector<int> ids;
+        pixels.reserve(frame.inliers_to_mappt_connections_.size());
+        ids.reserve(frame.inliers_to_mappt_connections_.size());
         for (const auto& conn : frame.inliers_to_mappt_connections_) {  // (keypoint index -> {.., map-point id})
             const int id = conn.second.pt_map_idx;
             const auto found = map->map_points_.find(id);

@@ -4,6 +4,7 @@
 // real OpenCV and against the mirror's mini_cv.h alike.
 #ifndef MVO_FLAT_BUNDLE_H
 #define MVO_FLAT_BUNDLE_H
+#include <stdexcept>
 #include <unordered_map>
 #include <vector>
 
@@ -18,6 +19,7 @@ using std::vector;
 struct FlatBundle {
     vector<double> poses, pts, uv;
     vector<int> ep, el, slot2id;
+    vector<int> table_;  // (id -> slot, when the ids are dense)
     mvo_ba_problem pr{};
 
     void flatten(const vector<vector<cv::Point2f*>>& v_pts_2d, const vector<vector<int>>& v_pts_2d_to_3d_idx, const cv::Mat& K,
@@ -28,24 +30,47 @@ struct FlatBundle {
         for (int i = 0; i < num_frames; ++i)
             for (int r = 0; r < 4; ++r)
                 for (int c = 0; c < 4; ++c) poses[16 * i + 4 * r + c] = v_camera_g2o_poses[i]->at<double>(r, c);
+        // landmark id -> position in the flat list.  Map-point ids are small non-negative integers handed out by a counter
+        // (mappoint.cpp:11): a direct table when they are dense enough, a hash map otherwise (9.4 k look-ups per BA5 window)
+        const size_t npts = pts_3d.size();
+        int max_id = -1, min_id = 0;
+        for (const auto& kv : pts_3d) {
+            max_id = kv.first > max_id ? kv.first : max_id;
+            min_id = kv.first < min_id ? kv.first : min_id;
+        }
+        const bool direct = min_id >= 0 && (size_t)max_id < 8 * npts + 4096;
         std::unordered_map<int, int> id2slot;
-        id2slot.reserve(pts_3d.size());
+        if (direct) table_.assign((size_t)max_id + 1, -1);
+        else id2slot.reserve(npts);
         slot2id.clear();
+        slot2id.reserve(npts);
         pts.clear();
+        pts.reserve(3 * npts);
         for (auto it = pts_3d.begin(); it != pts_3d.end(); ++it) {
-            id2slot[it->first] = (int)slot2id.size();
+            if (direct) table_[(size_t)it->first] = (int)slot2id.size();
+            else id2slot[it->first] = (int)slot2id.size();
             slot2id.push_back(it->first);
             pts.push_back(it->second->x);
             pts.push_back(it->second->y);
             pts.push_back(it->second->z);
         }
+        size_t nobs = 0;
+        for (int f = 0; f < num_frames; ++f) nobs += v_pts_2d[f].size();
         ep.clear();
         el.clear();
         uv.clear();
+        ep.reserve(nobs);
+        el.reserve(nobs);
+        uv.reserve(2 * nobs);
         for (int f = 0; f < num_frames; ++f)
             for (size_t j = 0; j < v_pts_2d[f].size(); ++j) {
+                const int id = v_pts_2d_to_3d_idx[f][j];
+                int slot = -1;
+                if (direct) slot = (id >= 0 && id <= max_id) ? table_[(size_t)id] : -1;
+                else slot = id2slot.at(id);
+                if (slot < 0) throw std::out_of_range("bundleAdjustment: an observation refers to a landmark that is not in pts_3d");
                 ep.push_back(f);
-                el.push_back(id2slot.at(v_pts_2d_to_3d_idx[f][j]));
+                el.push_back(slot);
                 uv.push_back(v_pts_2d[f][j]->x);
                 uv.push_back(v_pts_2d[f][j]->y);
             }
