@@ -49,7 +49,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--streams", type=int, default=32, help="sequence shards in flight per GPU (32: the solver slots stay full on hosts whose per-frame host work is slower; 24 suffices on fast ones)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="sequence shards in flight per GPU; default 32 (the solver slots stay full also on hosts whose per-frame host "
+                         "work is slower; 24 suffices on fast ones), 24 with --track (its PnP kernels hold a CU per workgroup: more "
+                         "shards only queue)")
     ap.add_argument("--frames-per-step", type=int, default=10,
                     help="consecutive frames every shard advances in one step (a step = one batch: streams x this many frames)")
     ap.add_argument("--ba", default="full", choices=["full", "pose_only"],
@@ -81,7 +84,10 @@ def parse(argv=None):
     ap.add_argument("--max-kp", type=int, default=2000)
     ap.add_argument("--ba-poses", type=int, default=5)
     ap.add_argument("--ba-points", type=int, default=2000)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.streams is None:
+        args.streams = 24 if args.track else 32
+    return args
 
 
 class FrameLoopCfg(C.Structure):  # host/driver/frame_loop.cpp: struct frame_loop_cfg
@@ -566,9 +572,11 @@ def main(argv=None, env=None):
             roof["resources"] = kernel_resources("k_ba_service<32,2>" if resident else "k_ba_lm<false,32,1>")
             mb = pmc_mfma_busy("k_ba_lm")
             if mb:
-                wgs = 28  # the profiled single-window launch: latency cut, one workgroup per CU, 4 SIMDs each
-                roof["mfma_busy"] = round(mb[0] / max(mb[1] * wgs * 4, 1.0), 4)
-                roof["mfma_busy_source"] = mb[2] + " (single-window launch, %d CUs)" % wgs
+                # the profiled single-window launch: latency cut, 28 workgroups = 28 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over
+                # the 8 XCDs (the launch's duration in cycles = a eighth of it)
+                wgs = 28
+                roof["mfma_busy"] = round(mb[0] / max(mb[1] / 8.0 * wgs * 4, 1.0), 4)
+                roof["mfma_busy_source"] = mb[2] + " (single-window launch, %d CUs: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x %d SIMDs))" % (wgs, wgs * 4)
             per_kernel["k_ba_lm"] = (launch.get("elapsed_ms", 0.0) if resident else launch["ms"]) / max(R["nframes"] * args.streams, 1)
         else:
             roof = None
