@@ -1,5 +1,6 @@
 #!/bin/bash
-# round 4, GPU call F: same-box A/B of three builds (round-3 final, call-B build, working tree)
+# round 4, GPU call F: same-box A/B of three builds (round-3 final, call-B build, working tree).  Needs the two older trees built
+# next to this one first: git worktree add _wt/r03 bc83609; git worktree add _wt/callb 5d79eb4; (cd _wt/<tree> && python -c "import __graft_entry__ as g; g.build()")
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 ROOT=$PWD

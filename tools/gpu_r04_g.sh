@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs _wt/callb like gpu_r04_f.sh)
 # round 4, GPU call G: is the slow equilibrium of the working tree the service policy (demand estimate) or the device?
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp

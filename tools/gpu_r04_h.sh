@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs _wt/callb like gpu_r04_f.sh)
 # round 4, GPU call H: host stage times of the extraction under the 24-shard load, working tree vs call-B build
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
