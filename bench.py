@@ -459,8 +459,13 @@ class GpuEnv:
         torch.cuda.set_device(self.local)
         self.device = "cuda"
         self.mvo = graft.load_package()
+        self.wait_policy = "auto"
         if self.cpus is not None and len(self.cpus) < args.streams + 4:
-            self.mvo.set_wait_policy(self.local, "yield")
+            try:
+                self.mvo.set_wait_policy(self.local, "yield")
+                self.wait_policy = "yield"
+            except Exception as e:  # noqa: BLE001  (a runtime that refuses the flag on an active device: keep its default)
+                print("[bench] wait policy left at the runtime's default: %s" % e, file=sys.stderr)
 
     def init_process_group(self, dist):
         dist.init_process_group(self.backend, device_id=self.torch.device("cuda", self.local))
