@@ -451,19 +451,21 @@ class GpuEnv:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-        # N > 1 ranks on one host: every rank keeps to its own CPUs (those of its GPU's NUMA node when sysfs tells), and waits
-        # for the device by yielding instead of spinning when its threads outnumber its CPUs -- unmeasured on hardware
-        # (the driver runs the multi-GPU bench), exercised on CPU by tests/test_distributed_gloo.py
+        # N > 1 ranks on one host: every rank keeps to its own CPUs (those of its GPU's NUMA node when sysfs tells), and blocks
+        # on an interrupt instead of spinning when its threads outnumber its CPUs.  Measured for ONE rank confined like a rank of
+        # an 8-GPU node (32 of 256 CPUs, tools/gpu_r04_s.sh): block 5029, yield 4955, spin 4904 frames/s vs 5054 unconfined; the
+        # N > 1 run itself is the driver's; the control flow is exercised on CPU by tests/test_distributed_gloo.py
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
         self.cpus = confine_rank_to_its_cpus(self.local, local_world, host_numa_maps(local_world) if local_world > 1 else (None, None))
         torch.cuda.set_device(self.local)
         self.device = "cuda"
         self.mvo = graft.load_package()
         self.wait_policy = "auto"
-        if self.cpus is not None and len(self.cpus) < args.streams + 4:
+        want = os.environ.get("MVO_BENCH_WAIT_POLICY") or ("block" if self.cpus is not None and len(self.cpus) < args.streams + 4 else "auto")
+        if want != "auto":
             try:
-                self.mvo.set_wait_policy(self.local, "yield")
-                self.wait_policy = "yield"
+                self.mvo.set_wait_policy(self.local, want)
+                self.wait_policy = want
             except Exception as e:  # noqa: BLE001  (a runtime that refuses the flag on an active device: keep its default)
                 print("[bench] wait policy left at the runtime's default: %s" % e, file=sys.stderr)
 
