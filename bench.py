@@ -189,7 +189,8 @@ class Shard:
             self._pinned = [self.torch.from_numpy(f).pin_memory() for f in self.host_frames]
             self._hf = (C.c_void_p * len(self._pinned))(*[t.data_ptr() for t in self._pinned])
             c.h_frames = C.cast(self._hf, C.POINTER(C.c_void_p))
-        c.ba_throughput = 1 if self.ba_cut == "throughput" else 0
+        # (tracking rows / the PnP chain in the loop: the frames wait for those stages, not for the solver -> SHARED mode)
+        c.ba_throughput = (2 if (self.track is not None or self.chain) else 1) if self.ba_cut == "throughput" else 0
         c.track = 1 if self.track is not None else 0
         c.keyframe_every = a.keyframe_every
         for i, k in enumerate(("fx", "fy", "cx", "cy")):

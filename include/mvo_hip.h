@@ -177,9 +177,15 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
  * calling thread (~75 us of host time per frame instead of ~8 us of kernel time).
  * The summation order of a solve (hence the last bits of its result) follows the cut; every cut is deterministic and is what
- * mvo_debug_get_ba_plan reports.  Results of the extraction do not depend on the mode. */
+ * mvo_debug_get_ba_plan reports.  Results of the extraction do not depend on the mode.
+ * SHARED: many sequences are in flight, but the bundle adjustment is not what their frames mostly wait for (tracking rows --
+ * map points in view, solvePnPRansac -- or other stages in the loop: ~2500 windows/s on this GPU instead of ~5000).  Windows keep the
+ * THROUGHPUT cut but always take the launch path (1...16 windows per grid): a resident grid would hold 208 CUs for slots that
+ * are half empty (tracking rows in the loop: 1800 frames/s with the grid, 2470 without).  The caller knows its loop; the library's
+ * load estimate only sees submission times and cannot tell a saturated launch path from a loop that is busy elsewhere. */
 #define MVO_BA_MODE_LATENCY 0
 #define MVO_BA_MODE_THROUGHPUT 1
+#define MVO_BA_MODE_SHARED 2
 int mvo_ba_set_mode(mvo_ctx* ctx, int mode);
 
 /* The same call in two halves, so that the host thread can do other work (e.g. extract the next frame on another

@@ -333,8 +333,9 @@ class Context:
                 for i, k in enumerate(keeps)]
 
     def ba_set_mode(self, mode):
-        """mvo_ba_set_mode: "latency" (default, ~300 observations per workgroup) or "throughput" (~600)."""
-        self._chk(self.lib.mvo_ba_set_mode(self.h, {"latency": 0, "throughput": 1}[mode]))
+        """mvo_ba_set_mode: "latency" (default, ~300 observations per workgroup), "throughput" (~720, resident grid under load) or
+        "shared" (the throughput cut on the launch path only)."""
+        self._chk(self.lib.mvo_ba_set_mode(self.h, {"latency": 0, "throughput": 1, "shared": 2}[mode]))
 
     def ba_trace_enable(self, on=True):
         self._chk(self.lib.mvo_debug_ba_trace_enable(self.h, int(on)))

@@ -765,8 +765,8 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // latency cut (BaService::wanted).  Other windows of the mode keep the throughput cut on the launch path.
     bool throughput = ctx->ba_throughput_mode != 0;
     const bool svc_class = throughput && !p->fix_points && !g_ba_profile && !g_ba_block_solver && P.runnable && ba_solver_class(n) == 32;
-    const bool svc = svc_class && service_for(ctx->device).wanted();
-    if (svc_class && !svc && g_ba_service == 1) throughput = false;
+    const bool svc = svc_class && !ctx->ba_never_resident && service_for(ctx->device).wanted();
+    if (svc_class && !svc && g_ba_service == 1 && !ctx->ba_never_resident) throughput = false;
     const int reserve = env_reserve >= 0 ? env_reserve : (throughput ? g_ba_xcd_reserve + 2 : g_ba_xcd_reserve);
     const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
     const int g_cap = throughput ? per_xcd / 2 : per_xcd;

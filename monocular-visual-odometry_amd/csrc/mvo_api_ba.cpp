@@ -41,8 +41,10 @@ static int ba_check(mvo_ctx* ctx, const mvo_ba_problem* p) {
     return MVO_OK;
 }
 int mvo_ba_set_mode(mvo_ctx* ctx, int mode) {
-    if (!ctx || (mode != MVO_BA_MODE_LATENCY && mode != MVO_BA_MODE_THROUGHPUT)) return mvo_set_err(ctx, MVO_ERR_INVALID, "bad BA mode", hipSuccess);
-    ctx->ba_throughput_mode = mode == MVO_BA_MODE_THROUGHPUT;
+    if (!ctx || (mode != MVO_BA_MODE_LATENCY && mode != MVO_BA_MODE_THROUGHPUT && mode != MVO_BA_MODE_SHARED))
+        return mvo_set_err(ctx, MVO_ERR_INVALID, "bad BA mode", hipSuccess);
+    ctx->ba_throughput_mode = mode != MVO_BA_MODE_LATENCY;
+    ctx->ba_never_resident = mode == MVO_BA_MODE_SHARED;
     return MVO_OK;
 }
 int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* p, mvo_ba_stats* st) {

@@ -185,6 +185,7 @@ struct mvo_ctx {
     long long ba_phase[16] = {0};
     int ba_wgs = 0, ba_trials = 0;
     int ba_throughput_mode = 0;  // mvo_ba_set_mode: 0 = latency (default), 1 = throughput (fewer, fuller workgroups per window)
+    bool ba_never_resident = false;  // MVO_BA_MODE_SHARED: throughput cut, launch path only
     struct mvo_ba_pool* ba_pool = nullptr;  // pooled BA workspaces (ba_host.cpp)
     // --- profiling
     bool prof = false;

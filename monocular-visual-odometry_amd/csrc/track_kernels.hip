@@ -10,6 +10,8 @@
 // The arithmetic lives in pnp_wave.h (wave-level SPMD code); this file binds it to threads and LDS.
 #include "mvo_internal.h"
 
+#include <cstdlib>
+
 #define PW_FN __device__ __forceinline__
 #define PW_LANES(l, NL) for (int l = (int)threadIdx.x, pw_once_ = 1; pw_once_; pw_once_ = 0)
 #define PW_WAVES(w, NW) for (int w = (int)(threadIdx.x >> 6), pw_once_ = 1; pw_once_; pw_once_ = 0)
@@ -82,12 +84,11 @@ int track_launch_map_in_view(mvo_ctx* ctx, const float* d_pos, const uint8_t* d_
 }
 
 // ------------------------------------------------------------------------------------------------ PnP RANSAC
-__global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* __restrict__ p3, const float* __restrict__ p2, int n,
+__device__ __forceinline__ void pnp_hypothesis_body(const float* __restrict__ p3, const float* __restrict__ p2, int n,
                                                         const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
                                                         double* __restrict__ models, int32_t* __restrict__ counts,
                                                         uint8_t* __restrict__ masks, double* __restrict__ h_models,
-                                                        int32_t* __restrict__ h_counts) {
-    __shared__ pw::HypLds lds;
+                                                        int32_t* __restrict__ h_counts, pw::HypLds& lds) {
     const int h = blockIdx.x;
     const pw::Camera c{cam.fx, cam.fy, cam.cx, cam.cy};
     double R[3][3], t[3];
@@ -109,6 +110,25 @@ __global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* _
         for (int i = 0; i < 12; ++i) hm[i] = m[i];
         h_counts[h] = good;
     }
+}
+
+// Two builds of the same body: the compiler's free choice (256 VGPR + 52 AGPR = ONE wave per SIMD: fastest for a lone frame on an
+// empty chip, 200 us) and a build held to two waves per SIMD (40 registers spilled to scratch): next to the resident solver grid
+// the 100 hypotheses of a frame share a few CUs, where a workgroup that holds a CU to itself is what limits the frame rate.
+__global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* __restrict__ p3, const float* __restrict__ p2, int n,
+                                                        const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
+                                                        double* __restrict__ models, int32_t* __restrict__ counts,
+                                                        uint8_t* __restrict__ masks, double* __restrict__ h_models,
+                                                        int32_t* __restrict__ h_counts) {
+    __shared__ pw::HypLds lds;
+    pnp_hypothesis_body(p3, p2, n, subsets, cam, thr2, models, counts, masks, h_models, h_counts, lds);
+}
+__global__ __launch_bounds__(pw::kHypLanes) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pnp_hypotheses_occ2(
+    const float* __restrict__ p3, const float* __restrict__ p2, int n, const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
+    double* __restrict__ models, int32_t* __restrict__ counts, uint8_t* __restrict__ masks, double* __restrict__ h_models,
+    int32_t* __restrict__ h_counts) {
+    __shared__ pw::HypLds lds;
+    pnp_hypothesis_body(p3, p2, n, subsets, cam, thr2, models, counts, masks, h_models, h_counts, lds);
 }
 
 // Picks the best hypothesis (the RANSAC loop's bookkeeping replayed over the counts, or `forced_best` >= 0), keeps
@@ -238,7 +258,9 @@ int track_launch_pnp_hypotheses(mvo_ctx* ctx, const float* d_p3, const float* d_
                                 int n_hyp, const TrackCamera& cam, float thr2, double* d_models, int32_t* d_counts,
                                 uint8_t* d_masks, double* h_models, int32_t* h_counts) {
     ProfScope ps(ctx, "k_pnp_hypotheses");
-    hipLaunchKernelGGL(k_pnp_hypotheses, dim3(n_hyp), dim3(pw::kHypLanes), 0, ctx->stream, d_p3, d_p2, n, d_subsets, cam, thr2,
+    static const int env_occ = std::getenv("MVO_PNP_OCC") ? std::atoi(std::getenv("MVO_PNP_OCC")) : 0;  // 0: by mode, 1 / 2: forced
+    const bool occ2 = env_occ ? env_occ == 2 : ctx->ba_throughput_mode != 0;
+    hipLaunchKernelGGL(occ2 ? k_pnp_hypotheses_occ2 : k_pnp_hypotheses, dim3(n_hyp), dim3(pw::kHypLanes), 0, ctx->stream, d_p3, d_p2, n, d_subsets, cam, thr2,
                        d_models, d_counts, d_masks, h_models, h_counts);
     MVO_HIP(hipGetLastError());
     return MVO_OK;

@@ -45,7 +45,8 @@ struct frame_loop_cfg {
     const float *kf_ref, *kf_cur; // keyframe matches
     int32_t kf_n;
     const double *kf_T_curr_to_prev, *kf_T_w_cur, *kf_T_w_ref;  // 16 each
-    int32_t ba_throughput;        // 1: mvo_ba_set_mode(ctx_ba, MVO_BA_MODE_THROUGHPUT) (many sequences per GPU)
+    int32_t ba_throughput;        // 1: mvo_ba_set_mode(ctx_ba, MVO_BA_MODE_THROUGHPUT) (many sequences per GPU); 2: MVO_BA_MODE_SHARED
+                                  // (many sequences, and stages other than the bundle adjustment dominate a frame)
     const void* const* h_frames;  // optional: the same frames in (pinned) host memory; when set, every frame is handed to
                                   // mvo_calc_keypoints as a HOST image like run_vo.cpp:114 does (H2D inside the loop)
     int32_t chain;                // 1: the newest frame of every window takes its pose and its map-point connections from
@@ -157,8 +158,9 @@ void* frame_loop_create(const frame_loop_cfg* cfg) {
     L->c = *cfg;
     if (!L->c.ctx_ba) L->c.ctx_ba = L->c.ctx;
     // (both contexts of the sequence: the mode also tells the detection who restores the candidate order)
-    (void)mvo_ba_set_mode(L->c.ctx_ba, cfg->ba_throughput ? MVO_BA_MODE_THROUGHPUT : MVO_BA_MODE_LATENCY);
-    (void)mvo_ba_set_mode(L->c.ctx, cfg->ba_throughput ? MVO_BA_MODE_THROUGHPUT : MVO_BA_MODE_LATENCY);
+    const int ba_mode = cfg->ba_throughput == 2 ? MVO_BA_MODE_SHARED : (cfg->ba_throughput ? MVO_BA_MODE_THROUGHPUT : MVO_BA_MODE_LATENCY);
+    (void)mvo_ba_set_mode(L->c.ctx_ba, ba_mode);
+    (void)mvo_ba_set_mode(L->c.ctx, ba_mode);
     L->kps.resize((size_t)cfg->max_kp + 16);
     L->matches.resize((size_t)cfg->max_kp + 16);
     if (cfg->track) {
