@@ -46,6 +46,7 @@ int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or 
 int g_ba_uv_global = 1;     // 0 = measurements always in LDS (the form before the second half of round 3)
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
+int g_ba_alias_sl = std::getenv("MVO_BA_ALIAS_SL") ? std::atoi(std::getenv("MVO_BA_ALIAS_SL")) : 1;  // 0 = the reduced system always has LDS of its own (A/B)
 
 // The demand estimate of the resident solver service (a plain state machine over submission times, so that it can be
 // replayed by the tests: mvo_debug_ba_demand_replay).
@@ -70,7 +71,8 @@ struct Carver {
 // Everything the host computes for one window; offsets are relative to the start of the device block.
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
-        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0, uv_global = 0;
+        ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0, uv_global = 0,
+        alias_sl = 0;
     bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
@@ -864,7 +866,10 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 // twice per trial from L2, and 16 bytes per edge of LDS go to the U chunks instead (BA5 on 13 workgroups: two
                 // chunks where three were needed)
                 P.uv_global = (!all_lds && maxEg > BA_THREADS && g_ba_uv_global) ? 1 : 0;
-                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel, P.uv_global);
+                // one column piece per chunk (no split tiles while U is live): the reduced system can live in the U area
+                P.alias_sl = (do_schur && npar == 1 && g_ba_alias_sl && uarea >= ba_solver_matrix_doubles(n, nlow + nhp, G, npair, npar)) ? 1 : 0;
+                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel, P.uv_global,
+                                     P.alias_sl);
                 fits = P.lds <= BA_LDS_BUDGET;
                 if (plan_trace)
                     std::fprintf(stderr, "[mvo plan] G %d rows_in_lds %d chunks %d pieces %d pt_passes %d maxEg %d maxLg %d uarea %zu B lds %zu B (budget %d) %s\n",
@@ -1055,6 +1060,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.uarea = (int)uarea;
     B.e2_edges = P.e2_edges;
     B.uv_global = P.uv_global;
+    B.alias_sl = P.alias_sl;
     B.uv_dev = (double*)(D + P.o_uvd);
     B.npt = P.npt;
     B.panel = P.panel;

@@ -699,7 +699,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     {
         double* d = dyn + ba_pose_doubles(B.F) + 2 * (size_t)G + 8;
         W.SL = d;
-        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar, B.panel) - 3 * 64 - (B.panel ? BA_PANEL_DOUBLES : 0);
+        d += ba_solver_doubles(n, nlow + B.nhp, G, B.npair, B.npar, B.panel, B.alias_sl) - 3 * 64 - (B.panel ? BA_PANEL_DOUBLES : 0);
         W.colbuf = d;
         d += 3 * 64;
         W.pan = d;
@@ -727,6 +727,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         d += full * B.maxLg * 3;
         W.U = d;
         stage = d;
+        if (B.alias_sl) W.SL = d;  // (the matrix shares the U area: alive only between the last chain and the back-substitution)
         d += B.uarea;
         W.E2 = d;
         d += (size_t)B.e2_edges * BA_E2S;

@@ -66,6 +66,7 @@ struct BaDev {
     int npt;     // passes of the landmark-block phase: pass h stages [X~ | e~] of the edges of the h-th slice of a range's landmarks
     int panel;   // 1: the solver area has the panel of the block LDL^T behind it
     int e2_edges;  // edges per range whose Jacobian rows live in LDS (all of them, or those behind the first 512)
+    int alias_sl;   // 1: the reduced system (SL) lives in the U area (ba_solver_doubles)
     int uv_global;  // 1: the measurements (u, v) of a range stay in device memory (read once per trial) instead of LDS
     double* uv_dev;  // their device copy (E x 2; a window of the resident service has its inputs in pinned host memory)
     int slots;   // kernel flavour the plan was made for: 0 = all rows in LDS, 1 / 2 = first 512 edges in registers
@@ -135,15 +136,22 @@ struct BaServiceArgs {
 };
 
 // ---- LDS carve-up of one workgroup (doubles unless noted); shared by the kernel and the planner
-__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int npar, int panel) {
-    // the solver area also stages the split-chain tiles and the slice reduction (never live together)
-    // register solvers: the system is embedded into 32 / 64 rows (ba_kernels.hip: solve_wave)
+// the matrix part of the solver area: the reduced system (embedded into 32 / 64 rows for the register / block solvers), which also
+// stages the split-chain tiles and the slice reduction (never live together)
+__host__ __device__ inline size_t ba_solver_matrix_doubles(int n, int nlow, int G, int npair, int npar) {
     size_t a = n + 1 <= 32 ? 32 * 33 : (n + 1 <= 64 ? 64 * 65 : (size_t)(n + 1) * (size_t)(n + 2));
     const size_t sp = (size_t)npair * (size_t)(npar > 1 ? npar - 1 : 0) * 256;
     const size_t sl = (size_t)((nlow + G - 1) / (G > 0 ? G : 1)) * (size_t)G;
     if (sp > a) a = sp;
     if (sl > a) a = sl;
-    return a + 3 * 64 + (panel ? BA_PANEL_DOUBLES : 0);  // + two column-broadcast buffers + scratch (+ the panel of the block solver)
+    return a;
+}
+// `alias`: the matrix part lives in the U area (windows whose Schur chains have ONE column piece per chunk -- no split tiles while
+// U is live --: the matrix, the slice staging and L are only ever needed between the last chain and the back-substitution, when
+// the U area is dead; the 64-row class saves 33 KB that way: two chunks of U instead of three for the BA10 window)
+__host__ __device__ inline size_t ba_solver_doubles(int n, int nlow, int G, int npair, int npar, int panel, int alias = 0) {
+    return (alias ? 0 : ba_solver_matrix_doubles(n, nlow, G, npair, npar)) + 3 * 64 +
+           (panel ? BA_PANEL_DOUBLES : 0);  // + two column-broadcast buffers + scratch (+ the panel of the block solver)
 }
 // per-pose state: q t (8) + backup (8), R (9), t (3), H_pp (36), b_p (6), dx (6), solution (6)
 __host__ __device__ inline size_t ba_pose_doubles(int F) { return (size_t)(F > 0 ? F : 1) * 82; }
@@ -165,8 +173,9 @@ __host__ __device__ inline size_t ba_uarea_doubles(int ucols, int ldu, int max_p
     return a;
 }
 __host__ __device__ inline size_t ba_lds_bytes(int F, int n, int nlow, int nhp, int G, int npair, int npar, int nfree, int maxEg,
-                                               int maxLg, int fix_points, size_t uarea, int e2_edges, int panel, int uv_global = 0) {
-    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar, panel) + (size_t)nlow + 2 * (size_t)nhp + 17 +
+                                               int maxLg, int fix_points, size_t uarea, int e2_edges, int panel, int uv_global = 0,
+                                               int alias_sl = 0) {
+    size_t d = ba_solver_doubles(n, nlow + nhp, G, npair, npar, panel, alias_sl) + (size_t)nlow + 2 * (size_t)nhp + 17 +
                (uv_global ? 0 : (size_t)maxEg * 2) + (size_t)maxLg * 3;
     d += ba_pose_doubles(F) + 2 * (size_t)G + 8;  // pose state, per-workgroup exchange values
     if (!fix_points) d += (size_t)maxLg * (3 + BA_XS + 3 + BA_XS + 3);
