@@ -23,7 +23,6 @@
 #include "ba_types.h"
 #include "mvo_internal.h"
 
-typedef double v4d __attribute__((ext_vector_type(4)));
 typedef ba_u64 u64;
 
 // per-phase cycle counters: only in the instrumented instantiation of the kernel (debug knob "ba_profile"); the
@@ -338,106 +337,8 @@ __device__ __forceinline__ unsigned ba_xcc_id() {
 #endif
 }
 
-#include "ba_solve.h"  // readlane_d, ba_rcp_pivot, the one-wave solver of the 5-pose class (solve_wave_32)
+#include "ba_solve.h"  // readlane_d, ba_rcp_pivot, the one-wave solver of the 5-pose class (solve_wave_32), the block solver (solve_block)
 
-// The same factorisation as a BLOCK algorithm run by the whole workgroup, matrix in LDS (SL, NR rows at pitch NR + 1,
-// embedded as above: identity rows behind n, the rhs as row NR - 1).  Per block of 4 columns j0 .. j0 + 3:
-//   panel   (wave 0, lane = row): the four pivots one after the other -- pivot and the three sub-diagonal entries of the
-//           diagonal block by v_readlane, r = 1 / d, l = c r, the remaining panel columns updated in registers; the rows
-//           [-l] and [c] of the panel go to LDS in MFMA operand order, the l into the matrix;
-//   update  (all waves, one 16 x 16 tile each): S_tile += (-L_panel) C_panel^T by ONE v_mfma_f64_16x16x4_f64 -- the four
-//           columns of the panel are the four k slots, added as fused multiply-adds in column order, which is exactly
-//           the canonical a_ik = fma(-l_ij, c_kj, a_ik), j ascending; only entries below the panel columns and inside
-//           the lower triangle are written back.
-// Same bits as the scalar right-looking LDL^T (every entry receives the same fma's in the same order); 63 pivots cost 16
-// panel + update rounds instead of 63 single-wave steps with the whole matrix in one wave's registers (the 64-row
-// register solver used every VGPR of the kernel and spilled).  `pan`: 8 NR doubles of scratch.  Returns 0 when a pivot
-// is not usable; leaves x in xout[0 .. n).
-template <int NR>
-__device__ __forceinline__ int solve_block(int sl_off, int pan_off, int xout_off, int n, int tid) {
-    constexpr int R = NR - 1, P = NR + 1, NB = NR / 4, NTL = NR / 16;
-    double* SL = ba_dyn_lds + sl_off;
-    double* LP = ba_dyn_lds + pan_off;  // NR x 4: -l_i,j0+k
-    double* CP = LP + NR * 4;           // NR x 4:  c_i,j0+k
-    double* xout = ba_dyn_lds + xout_off;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int ok = 1;
-    for (int b = 0; b < NB; ++b) {
-        const int j0 = 4 * b;
-        if (wave == 0) {
-            const int i = lane < NR ? lane : R;
-            double p[4], l[4], c[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) p[k] = SL[i * P + j0 + k];  // (column R of the last block: never a pivot)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int j = j0 + jj;
-                double d = readlane_d(p[jj], j < NR ? j : 0);
-                if (j >= R) d = 1.0;
-                ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (j >= n);
-                const double r = ba_rcp_pivot(d);
-                c[jj] = p[jj];
-                l[jj] = p[jj] * r;
-#pragma unroll
-                for (int kk = jj + 1; kk < 4; ++kk) {
-                    const double ckj = readlane_d(p[jj], j0 + kk < NR ? j0 + kk : 0);  // S[j0 + kk][j] before the scaling
-                    p[kk] = __builtin_fma(-l[jj], ckj, p[kk]);
-                }
-            }
-            if (lane < NR) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    LP[i * 4 + k] = -l[k];
-                    CP[i * 4 + k] = c[k];
-                    if (i > j0 + k && j0 + k < R) SL[i * P + j0 + k] = l[k];
-                }
-            }
-        }
-        __syncthreads();
-        // trailing update: tiles (ti >= tj) that reach below / right of the panel
-        {
-            const int t0 = (j0 + 4) / 16;  // first tile row / column with an entry behind the panel
-            const int q = lane >> 4, cidx = lane & 15;
-            int t = 0;
-            for (int tj = t0; tj < NTL; ++tj)
-                for (int ti = tj; ti < NTL; ++ti, ++t) {
-                    if ((t & (BA_WAVES - 1)) != wave) continue;
-                    v4d acc;
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) acc[rr] = SL[(16 * ti + 4 * rr + q) * P + 16 * tj + cidx];
-                    const double a = LP[(16 * ti + cidx) * 4 + q], bb = CP[(16 * tj + cidx) * 4 + q];
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc, 0, 0, 0);
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int row = 16 * ti + 4 * rr + q, col = 16 * tj + cidx;
-                        if (row > j0 + 3 && col > j0 + 3 && col <= row && col < R) SL[row * P + col] = acc[rr];
-                    }
-                }
-        }
-        __syncthreads();
-    }
-    // back-substitution x = L^-T z by wave 0: lane j owns x_j (z = the rhs row of L); row i of L is read in LDS order
-    if (wave == 0) {
-        const int j = lane < R ? lane : 0;
-        double x = SL[R * P + j];
-        for (int i0 = R - 1; i0 >= 1; i0 -= 8) {
-            double li[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) li[u] = i0 - u >= 1 ? SL[(i0 - u) * P + j] : 0.0;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 - u;
-                if (i < 1) break;
-                const double xi = readlane_d(x, i);
-                const double t = __builtin_fma(-li[u], xi, x);
-                x = lane < i ? t : x;
-            }
-        }
-        if (lane < n) xout[lane] = x;
-    }
-    return __builtin_amdgcn_readfirstlane(ok);
-}
 // the same arithmetic for more than 63 unknowns (> 10 free poses): one wave, matrix in LDS (row pitch n + 2)
 __device__ __attribute__((noinline)) int solve_lds(int sl_off, int cb_off, int n, int lane) {
     double* S = ba_dyn_lds + sl_off;

@@ -27,7 +27,7 @@ typedef unsigned long long ba_u64;
 #define BA_SXS 9                    // doubles per edge in the staged [X~ (6) | e~ (2)] rows of the landmark-block phase (odd)
 #define BA_EDGE_SLOTS 2             // edges per thread: the first one keeps its Jacobian rows in registers, the second one (ranges
 //                                  with more than 512 edges) in LDS; a range holds <= 1024 edges
-#define BA_PANEL_DOUBLES 512         // block LDL^T: rows [-l] and [c] of a 4-column panel, 64 rows each
+#define BA_PANEL_DOUBLES 1040        // block LDL^T: rows [-l] and [c] of a 4-column panel, 64 rows each, two buffers; the 4 x 4 diagonal block
 #define BA_E2S 21                   // doubles per edge in that LDS area: a0 (6) | a1 (6) | x (6) | e~ (2), odd pitch
 #define BA_LDS_BUDGET (157 * 1024)  // dynamic part; the static part (descriptor, flags: < 1.5 KB) comes on top (160 KB per CU)
 #define BA_MAX_WGS 256
