@@ -311,7 +311,9 @@ int mvo_debug_set(const char* key, int value);
 int mvo_debug_ba_trace_enable(mvo_ctx* ctx, int on);
 int mvo_debug_get_ba_trace(mvo_ctx* ctx, mvo_ba_handle* handle, double* rows, int cap, int* n);
 /* Summation plan of that window: number of landmark ranges (workgroups), column splits of a Schur chain, and the
- * first landmark of every range (wgs + 1 entries) -- what the oracle needs to restate the device sums bit for bit. */
+ * first landmark of every range (wgs + 1 entries) -- what the oracle needs to restate the device sums bit for bit.
+ * nsplit: bits 0..15 = the column splits; bits 16.. = K when the window's Schur exchange is grouped (windows of more than
+ * 32 workgroups add the partials of the workgroups g = k mod K first -- one XCD each --, then the K group sums), else 0. */
 int mvo_debug_get_ba_plan(mvo_ctx* ctx, mvo_ba_handle* handle, int* wgs, int* nsplit, int32_t* wg_pt_start, int cap);
 /* Shader-clock cycles the last fetched BA solve spent per phase (ids in csrc/ba_kernels.hip), and the number
  * of workgroups it ran on. */

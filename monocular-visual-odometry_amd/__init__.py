@@ -349,11 +349,11 @@ class Context:
         return out[:n.value].copy()
 
     def ba_plan(self, handle=None):
-        """Summation plan of the last window: dict(wgs, nsplit, wg_pt_start)."""
+        """Summation plan of the last window: dict(wgs, nsplit, groups, wg_pt_start)."""
         g, ns = C.c_int(), C.c_int()
         pt = np.zeros(257, np.int32)
         self._chk(self.lib.mvo_debug_get_ba_plan(self.h, handle[0] if handle else None, C.byref(g), C.byref(ns), _p(pt), 257))
-        return dict(wgs=g.value, nsplit=ns.value, wg_pt_start=pt[:g.value + 1].copy())
+        return dict(wgs=g.value, nsplit=ns.value & 0xffff, groups=max(1, ns.value >> 16), wg_pt_start=pt[:g.value + 1].copy())
 
     # ---- tracking rows (vo.cpp:16-49, 270-357)
     def map_create(self):

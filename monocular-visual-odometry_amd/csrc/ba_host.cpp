@@ -46,6 +46,7 @@ int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or 
 int g_ba_uv_global = 1;     // 0 = measurements always in LDS (the form before the second half of round 3)
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
+int g_ba_groups = std::getenv("MVO_BA_GROUPS") ? std::atoi(std::getenv("MVO_BA_GROUPS")) : 1;  // 0 = one flat Schur exchange whatever the window's size (A/B)
 int g_ba_alias_sl = std::getenv("MVO_BA_ALIAS_SL") ? std::atoi(std::getenv("MVO_BA_ALIAS_SL")) : 1;  // 0 = the reduced system always has LDS of its own (A/B)
 
 // The demand estimate of the resident solver service (a plain state machine over submission times, so that it can be
@@ -72,7 +73,7 @@ struct Carver {
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
         ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0, uv_global = 0,
-        alias_sl = 0;
+        alias_sl = 0, groups = 1;
     bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
@@ -356,11 +357,12 @@ void BaService::run() {
         const int nj = fl->nj;
         BaBatch b{};
         b.nwin = nj;
-        int maxG = 1, slots = 0;
+        int maxG = 1, maxK = 1, slots = 0;
         size_t lds = 16;
         for (int i = 0; i < nj; ++i) {
             BaWorkspace* ws = fl->jobs[i]->ws;
             slots = ws->plan.slots;
+            maxK = std::max(maxK, ws->plan.groups);
             (void)hipStreamWaitEvent(stream, ws->ready, 0);  // the window's upload (queued on its ctx stream)
             b.win[i] = (const BaDev*)(ws->dev + ws->plan.o_desc);
             b.tag_base[i] = ws->seq << 12;
@@ -370,6 +372,7 @@ void BaService::run() {
         // window = block % stride: with the dispatcher's round-robin (block b on XCD b % 8) a stride of 8 or 16 keeps
         // every window's workgroups on ONE XCD (a window of > 32 workgroups does not fit an XCD's 32 CUs anyway)
         b.stride = cus >= 256 && maxG <= 16 ? 16 : (cus >= 256 && maxG <= 32 ? 8 : nj);
+        if (cus >= 256 && maxK > 1) b.stride = (nj + 8 / maxK - 1) / (8 / maxK) * (8 / maxK);  // workgroup w of a window on XCD (w stride + window) mod 8: w mod K decides
         if (b.stride < nj) b.stride = nj;
         b.use_mfma = fl->jobs[0]->use_mfma;
         b.same_l2_ok = g_ba_same_l2;
@@ -900,7 +903,16 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.G = G;
     P.maxEg = maxEg;
     P.maxLg = maxLg;
-    P.slice = (nlow + G - 1) / G;
+    // A window of more than one XCD's worth of workgroups sums its Schur partials per XCD first (group k = the workgroups
+    // g = k mod K, placed on one XCD by the launch: stride 8 / K), then the K group sums: the bulk of the exchange stays in
+    // an L2.  The grouping is part of the summation plan (ba_get_plan), never a matter of where the workgroups ended up.
+    P.groups = 1;
+    if (G > 32 && g_ba_groups) {
+        int K = 2;
+        while (G / K > 32 && K < 8) K *= 2;
+        if (G % K == 0 && G / K <= 32 && uarea >= (size_t)K * (size_t)(nlow + nhp)) P.groups = K;
+    }
+    P.slice = (nlow + G / P.groups - 1) / (G / P.groups);
     // ---- edges sorted by (owner workgroup, pose); adjacency tables
     std::vector<int>&e_pose = SC.e_pose, &e_point = SC.e_point, &ptstart = SC.ptstart, &ptlist = SC.ptlist;
     std::vector<double>& e_uv = SC.e_uv;
@@ -970,7 +982,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // (below): bytes that once held ordinary data must never be taken for a published value.
     Carver cv;
     P.o_xp = cv.take((size_t)G * npk * 16);
-    P.o_xr = cv.take((size_t)npk * 16);
+    P.o_xr = cv.take((size_t)npk * 16 * (P.groups > 1 ? 2 * P.groups : 1));
     P.o_xh = cv.take((size_t)G * nhp * 16);
     P.o_xc = cv.take((size_t)2 * G * 4 * 8);
     P.x_end = cv.off;
@@ -1061,6 +1073,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.e2_edges = P.e2_edges;
     B.uv_global = P.uv_global;
     B.alias_sl = P.alias_sl;
+    B.groups = P.groups;
     B.uv_dev = (double*)(D + P.o_uvd);
     B.npt = P.npt;
     B.panel = P.panel;
@@ -1325,7 +1338,7 @@ int ba_get_plan(mvo_ctx* ctx, mvo_ba_handle* H, int* G, int* nsplit, int32_t* wg
     BaWorkspace* ws = H ? &H->ws : (ctx->ba_pool && !ctx->ba_pool->ws.empty() ? ctx->ba_pool->ws[0] : nullptr);
     if (!ws) return mvo_set_err(ctx, MVO_ERR_STATE, "no bundle adjustment has been planned", hipSuccess);
     if (G) *G = ws->plan.G;
-    if (nsplit) *nsplit = ws->plan.nsplit;
+    if (nsplit) *nsplit = ws->plan.nsplit | (ws->plan.groups > 1 ? ws->plan.groups << 16 : 0);  // (bits 16 ..: the groups of the Schur exchange when there are several)
     if (wg_pt)
         for (int i = 0; i <= ws->plan.G && i < cap; ++i) wg_pt[i] = ws->plan.wg_pt[i];
     return MVO_OK;

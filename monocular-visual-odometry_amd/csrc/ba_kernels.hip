@@ -690,6 +690,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     // ---- initial robust chi2: all-to-all through the chi2 slots (tag 1 of the B series)
     double currentChi;
     bool same_l2 = false;  // all workgroups of the window on one XCD (found out in the first exchange)
+    bool grp_l2 = false;   // every group g mod K of the window on one XCD of its own (K = 1: the same thing)
+    const int K = B.groups > 1 ? B.groups : 1;
     {
         double c = robust_chi2_local(B, W, Eg, sR, sT, sScr);
         if (G > 1) {
@@ -704,12 +706,14 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             __syncthreads();
             if (sFlag[2]) error = 1;
             c = 0;
-            bool one = true;
+            bool one = true, grp = true;
             for (int w = 0; w < G; ++w) {
                 c += sX[2 * w];
                 one = one && sX[2 * w + 1] == sX[1];
+                grp = grp && sX[2 * w + 1] == sX[2 * (w % K) + 1];
             }
             same_l2 = one && batch.same_l2_ok;
+            grp_l2 = grp && batch.same_l2_ok;
             __syncthreads();
         }
         currentChi = c;
@@ -1228,7 +1232,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                                         const int rr = (lane >> 4) + 4 * j, c = lane & 15;
                                         const int pk = a == wave ? pk4[j] : pkt_g[pr * 256 + rr * 16 + c];
                                         if (pk >= 0) {
-                                            if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], same_l2);
+                                            if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], grp_l2);
                                             else W.Rl[pk] = r[j];
                                         }
                                     }
@@ -1250,7 +1254,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                                 tot = (ch == 0 && sp == 0) ? acc : tot + acc;
                             }
                             W.Rl[pk] = tot;
-                            if (last && G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, tot, same_l2);
+                            if (last && G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, tot, grp_l2);
                         }
                     }
                     if (!last) __syncthreads();  // (the chunk and the split tiles are consumed)
@@ -1260,15 +1264,22 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 if (G > 1) {
                     __syncthreads();
                     STAMP(6);
-                    // stage 1: this workgroup reduces its SLICE of the packed entries over all G partials, in workgroup
-                    // order, and republishes the slice
+                    // stage 1: this workgroup reduces its SLICE of the packed entries over the partials of its group (the
+                    // workgroups w = g mod K; K = 1: all of them), in workgroup order, and republishes the slice.  A window
+                    // of more than one XCD's worth of workgroups is planned with one group per XCD (the launch places
+                    // workgroup w on XCD w mod K): the G partials -- the bulk of the exchange -- then stay inside their XCD's
+                    // L2, and only the K group sums cross the fabric.
+                    const int Gk = G / K, gk = g % K, gj = g / K;
+                    // (K > 1: the group sums alternate between two buffers -- a trial that ends at the failed factorisation
+                    // has no all-to-all behind it, and a slice owner only knows that its OWN group has left the last trial)
+                    u64* xR = B.xR + (K > 1 ? 2 * (size_t)(tagA & 1) * K * npk : 0);
                     const int nhpx = hp_pending ? B.nhp - 1 : 0, nlowx = nlow + nhpx;
-                    const int slicex = hp_pending ? (nlowx + G - 1) / G : slice;
-                    for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(B.xP + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], same_l2);
-                    const int sl0 = g * slicex, sln = max(0, min(slicex, nlowx - sl0));
+                    const int slicex = hp_pending ? (nlowx + Gk - 1) / Gk : slice;
+                    for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(B.xP + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], grp_l2);
+                    const int sl0 = gj * slicex, sln = max(0, min(slicex, nlowx - sl0));
                     if (sln > 0) {
-                        // item q = (w, el): partial of workgroup w, entry sl0 + el
-                        if (!gather_tagged(B.xP + 2 * (size_t)sl0, sln * G, sln, npk, tag0 + tagA, W.SL, PROF ? &ph[PROF ? 12 : 0] : nullptr)) sFlag[2] = 1;
+                        // item q = (w, el): partial of the group's workgroup w (= workgroup w K + gk), entry sl0 + el
+                        if (!gather_tagged(B.xP + 2 * ((size_t)gk * npk + sl0), sln * Gk, sln, (size_t)K * npk, tag0 + tagA, W.SL, PROF ? &ph[PROF ? 12 : 0] : nullptr)) sFlag[2] = 1;
                     }
                     STAMP(7);
                     __syncthreads();
@@ -1278,7 +1289,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                         // compiler every add waits for its own LDS read: 32 round trips)
                         double sum = 0;
                         int w = 0;
-                        for (; w + 8 <= G; w += 8) {
+                        for (; w + 8 <= Gk; w += 8) {
                             double t8[8];
 #pragma unroll
                             for (int k = 0; k < 8; ++k) t8[k] = W.SL[(w + k) * sln + el];
@@ -1286,12 +1297,23 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
 #pragma unroll
                             for (int k = 0; k < 8; ++k) sum += t8[k];
                         }
-                        for (; w < G; ++w) sum += W.SL[w * sln + el];
-                        gstore_d(B.xR + 2 * (size_t)(sl0 + el), tag0 + tagA, sum, same_l2);
+                        for (; w < Gk; ++w) sum += W.SL[w * sln + el];
+                        gstore_d(xR + 2 * ((size_t)gk * npk + sl0 + el), tag0 + tagA, sum, same_l2);
                     }
                     STAMP(9);
-                    // stage 2: everybody reads the summed entries
-                    if (!gather_tagged(B.xR, nlowx, nlowx, 0, tag0 + tagA, W.Rl, PROF ? &ph[PROF ? 13 : 0] : nullptr)) sFlag[2] = 1;
+                    // stage 2: everybody reads the summed entries (K > 1: the K group sums, added in group order)
+                    if (K == 1) {
+                        if (!gather_tagged(xR, nlowx, nlowx, 0, tag0 + tagA, W.Rl, PROF ? &ph[PROF ? 13 : 0] : nullptr)) sFlag[2] = 1;
+                    } else {
+                        __syncthreads();  // (the staging of stage 1 may share the U area with this one)
+                        if (!gather_tagged(xR, K * nlowx, nlowx, (size_t)npk, tag0 + tagA, stage, PROF ? &ph[PROF ? 13 : 0] : nullptr)) sFlag[2] = 1;
+                        __syncthreads();
+                        for (int idx = tid; idx < nlowx; idx += BA_THREADS) {
+                            double t = 0;
+                            for (int k = 0; k < K; ++k) t += stage[k * nlowx + idx];
+                            W.Rl[idx] = t;
+                        }
+                    }
                     STAMP(10);
                     if (hp_pending) {  // the summed pose blocks of this iteration: [H_pp | -b_p] of every free pose
                         __syncthreads();

@@ -59,6 +59,7 @@ struct BaDev {
     int nlow;    // packed entries of the reduced system: lower triangle (i >= j, i < n) then the rhs row (n, j)
     int npk;     // nlow rounded up to 16: row pitch of the partial exchange
     int slice;   // packed entries every workgroup reduces in stage 1
+    int groups;  // K: the Schur exchange sums the partials of the workgroups g = k mod K first (one XCD each), then the K group sums
     int nsplit;  // consecutive column pieces of a Schur chain (results added in piece order) = nseq x npar
     int npar;    // pieces that run side by side on different waves (one chunk of the U area holds npar pieces)
     int nseq;    // chunks of the U area that are built and consumed one after the other

@@ -191,7 +191,7 @@ struct Range {  // one landmark range ("workgroup") of the plan
 
 struct Blocked {
     // problem
-    int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, nsplit = 1;
+    int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, nsplit = 1, groups = 1;
     bool fix_points = false;
     double f = 0, cx = 0, cy = 0, delta = 1, lc00 = 1, lc01 = 0, lc11 = 1;
     std::vector<int> pose_slot, slot_pose;
@@ -263,7 +263,9 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
     B.F = in->n_poses;
     B.L = in->n_points;
     B.G = G;
-    B.nsplit = nsplit < 1 ? 1 : nsplit;
+    B.nsplit = (nsplit & 0xffff) < 1 ? 1 : (nsplit & 0xffff);
+    B.groups = (nsplit >> 16) > 1 ? (nsplit >> 16) : 1;  // (bits 16 .. of `nsplit`: groups of the Schur exchange, see oracle.h)
+    if (G % B.groups != 0) return -2;
     B.fix_points = in->fix_points != 0;
     B.f = in->focal;
     B.cx = in->cx;
@@ -409,16 +411,23 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
             const int p = B.slot_pose[sl];
             for (int i = 0; i < 7; ++i)
                 for (int j = 0; j <= i; ++j) {
+                    // (the device's first iteration adds the ranges' chains in range order; from the second one on the pose
+                    // blocks ride along with the Schur exchange and are added the way that one adds: per group, then the groups)
+                    const int Kp = (B.groups > 1 && do_schur && it > 0) ? B.groups : 1;
                     double tot = 0;
-                    for (int g = 0; g < G; ++g) {
-                        const Range& r = B.rg[g];
-                        double acc = 0;
-                        for (int el = r.pose_start[p]; el < r.pose_start[p + 1]; ++el) {
-                            const double* Mr = &B.M[14 * (size_t)(r.e_lo + el)];
-                            acc = std::fma(Mr[i], Mr[j], acc);
-                            acc = std::fma(Mr[7 + i], Mr[7 + j], acc);
+                    for (int k = 0; k < Kp; ++k) {
+                        double gs = 0;
+                        for (int g = k; g < G; g += Kp) {
+                            const Range& r = B.rg[g];
+                            double acc = 0;
+                            for (int el = r.pose_start[p]; el < r.pose_start[p + 1]; ++el) {
+                                const double* Mr = &B.M[14 * (size_t)(r.e_lo + el)];
+                                acc = std::fma(Mr[i], Mr[j], acc);
+                                acc = std::fma(Mr[7 + i], Mr[7 + j], acc);
+                            }
+                            gs = G == 1 ? acc : gs + acc;
                         }
-                        tot = G == 1 ? acc : tot + acc;
+                        tot = Kp == 1 ? gs : tot + gs;
                     }
                     if (i < 6) {
                         B.Hpp[36 * p + 6 * i + j] = tot;
@@ -524,21 +533,27 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                         i = n;
                         j = idx - n * (n + 1) / 2;
                     }
-                    double sum = 0;
-                    for (int g = 0; g < G; ++g) {
-                        const Range& r = B.rg[g];
-                        const double* Ug = &U[u_off[g]];
-                        const int ncol = 3 * r.Lg, msteps = (ncol + 3) / 4, msplit = (msteps + B.nsplit - 1) / B.nsplit;
-                        double tot = 0;
-                        for (int sp = 0; sp < B.nsplit; ++sp) {
-                            double acc = 0;
-                            const int c0 = std::min(4 * sp * msplit, ncol), c1 = std::min(4 * (sp + 1) * msplit, ncol);
-                            for (int col = c0; col < c1; ++col) acc = std::fma(Ug[(size_t)col * nrow + j], Ug[(size_t)col * nrow + i], acc);
-                            tot = sp == 0 ? acc : tot + acc;
+                    // ranges in order within a group (the ranges g = k mod K), then the K group sums in order (K = 1: all ranges)
+                    const int K = B.groups;
+                    double total = 0;
+                    for (int k = 0; k < K; ++k) {
+                        double sum = 0;
+                        for (int g = k; g < G; g += K) {
+                            const Range& r = B.rg[g];
+                            const double* Ug = &U[u_off[g]];
+                            const int ncol = 3 * r.Lg, msteps = (ncol + 3) / 4, msplit = (msteps + B.nsplit - 1) / B.nsplit;
+                            double tot = 0;
+                            for (int sp = 0; sp < B.nsplit; ++sp) {
+                                double acc = 0;
+                                const int c0 = std::min(4 * sp * msplit, ncol), c1 = std::min(4 * (sp + 1) * msplit, ncol);
+                                for (int col = c0; col < c1; ++col) acc = std::fma(Ug[(size_t)col * nrow + j], Ug[(size_t)col * nrow + i], acc);
+                                tot = sp == 0 ? acc : tot + acc;
+                            }
+                            sum = G == 1 ? tot : sum + tot;
                         }
-                        sum = G == 1 ? tot : sum + tot;
+                        total = K == 1 ? sum : total + sum;
                     }
-                    Gsum[idx] = sum;
+                    Gsum[idx] = total;
                 }
             }
             // ---- reduced system (lower triangle + rhs row n), right-looking LDL^T, back-substitution

@@ -137,7 +137,8 @@ typedef struct {
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317). */
 int orc_bundle_adjustment(orc_ba_problem* prob, orc_ba_stats* stats);
 /* The same algorithm with the BLOCKED summation order the device declares (ba_blocked_oracle.cpp): G landmark ranges
- * (wg_pt_start: G + 1 entries), nsplit column pieces per Schur chain.  trace (may be NULL): rows {lambda, chi2, rho,
+ * (wg_pt_start: G + 1 entries), nsplit column pieces per Schur chain (bits 0..15 of `nsplit`; bits 16..: K > 1 = the Schur
+ * exchange adds the ranges g = k mod K per group k first, then the K group sums).  trace (may be NULL): rows {lambda, chi2, rho,
  * accepted} per LM trial.  Used to check the MI355X solve bit for bit. */
 int orc_bundle_adjustment_blocked(orc_ba_problem* prob, int G, const int32_t* wg_pt_start, int nsplit, orc_ba_stats* stats,
                                   double* trace, int trace_cap, int* trace_n);

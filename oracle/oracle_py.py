@@ -254,7 +254,7 @@ def bundle_adjustment(poses, points, edge_pose, edge_point, edge_uv, focal, cx, 
 
 def bundle_adjustment_blocked(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, plan, info=(1, 0, 0, 1),
                               huber_delta=1.0, fix_points=False, pose_fixed=None, max_iterations=50):
-    """The same LM solve with the blocked summation order of `plan` = dict(wgs, nsplit, wg_pt_start) (what
+    """The same LM solve with the blocked summation order of `plan` = dict(wgs, nsplit, wg_pt_start[, groups]) (what
     mvo_debug_get_ba_plan reports).  Returns (poses, points, stats, trace [trials, 4] = lambda, chi2, rho, accepted)."""
     pr, keep = _ba_problem(poses, points, edge_pose, edge_point, edge_uv, focal, cx, cy, info, huber_delta,
                            fix_points, pose_fixed, max_iterations)
@@ -262,7 +262,8 @@ def bundle_adjustment_blocked(poses, points, edge_pose, edge_point, edge_uv, foc
     wg = np.ascontiguousarray(plan["wg_pt_start"], np.int32)
     trace = np.zeros((512, 4))
     nt = C.c_int()
-    r = lib().orc_bundle_adjustment_blocked(C.byref(pr), int(plan["wgs"]), wg.ctypes.data_as(C.c_void_p), int(plan["nsplit"]),
+    r = lib().orc_bundle_adjustment_blocked(C.byref(pr), int(plan["wgs"]), wg.ctypes.data_as(C.c_void_p),
+                                            int(plan["nsplit"]) | ((int(plan.get("groups", 1)) << 16) if int(plan.get("groups", 1)) > 1 else 0),
                                             C.byref(st), trace.ctypes.data_as(C.c_void_p), 512, C.byref(nt))
     if r != 0:
         raise RuntimeError("oracle BA (blocked order) failed: %d" % r)

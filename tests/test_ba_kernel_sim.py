@@ -114,6 +114,24 @@ def test_throughput_mode_cuts_the_window_into_fewer_workgroups(mvo, O, simctx, s
     assert plan["wgs"] == 28
 
 
+@pytest.mark.parametrize("wgs,groups", [(40, 2), (72, 4)])
+def test_windows_of_more_than_one_xcd_sum_their_schur_partials_per_group(mvo, O, simctx, simlib, wgs, groups, monkeypatch):
+    """More than 32 workgroups (forced here on the benchmarked window): the partials of the workgroups g = k mod K are added
+    first (the launch places a group on one XCD; the emulator's XCC id is blockIdx & 7 like the dispatcher's round-robin),
+    then the K group sums -- the pose blocks that ride along from the second iteration on included; the trials that end at the
+    failed factorisation (no all-to-all behind them) alternate between the two buffers of the group sums.  Still the oracle's
+    bits, whatever order the emulated threads run in."""
+    simlib.mvo_debug_set(b"ba_wgs", wgs)
+    try:
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=30)
+        assert plan["wgs"] == wgs and plan["groups"] == groups and st["trials"] > st["iterations"]
+        monkeypatch.setenv("EMU_ORDER", "shuffle")
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 9), fix_points=False, max_iterations=5, pose_fixed=_fix(5, 1))
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True, max_iterations=4)
+    finally:
+        simlib.mvo_debug_set(b"ba_wgs", 0)
+
+
 @pytest.mark.parametrize("block", [0, 1])
 def test_six_to_ten_pose_windows_use_the_block_solver(mvo, O, simctx, simlib, block):
     """n + 1 in 33..64 (6..10 free poses): workgroup-wide block LDL^T (panel on one wave, MFMA tile updates on all); with
@@ -126,7 +144,7 @@ def test_six_to_ten_pose_windows_use_the_block_solver(mvo, O, simctx, simlib, bl
         if block == 0:
             pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)
             st, plan = _bitwise(mvo, O, simctx, pb, fix_points=False, max_iterations=3)
-            assert plan["wgs"] <= 64
+            assert plan["wgs"] <= 64 and plan["groups"] == 2  # (more than one XCD's worth of workgroups: grouped Schur exchange)
     finally:
         simlib.mvo_debug_set(b"ba_block_solver", 0)
 
