@@ -171,7 +171,7 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * workgroup (the 5-keyframe window of the benchmark: 28 CUs of one XCD, shortest solve) and solved by a launch of its own;
  * the detection kernel also puts its candidates in order on the device.
  * THROUGHPUT: many sequences are in flight on this GPU -- CU time counts, not latency.  While the offered load keeps it
- * busy (64 submissions in a row at a rate x solve time of >= 10 of its 16 slots; it leaves after 80 ms below 8), 5-keyframe windows are cut into ~720 observations
+ * busy (64 submissions in a row at a rate x solve time of >= 8 of its 16 slots; it leaves after 80 ms below 5), 5-keyframe windows are cut into ~720 observations
  * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
  * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the

@@ -399,10 +399,10 @@ bool BaDemand::submit(double now) {
         // the callers paused (a barrier, a synchronisation, the end of a run): not low demand -- the decision stands, the
         // averages start over from where the decision would put them
         n = 0;
-        rate_avg = on ? 0.65 * BA_SERVICE_SLOTS / kSolve : 0.0;
+        rate_avg = on ? 0.5 * BA_SERVICE_SLOTS / kSolve : 0.0;
         low_since = -1;
     } else {
-        if (dt > 0.01) n = 0;  // (the 64-submission window restarts after a gap; the average bridges it)
+        if (dt > 0.03) n = 0;  // (the 64-submission window restarts after a long gap; sequences in lock step leave gaps of a step between their bursts -- those count)
         rate_avg *= std::exp(-dt / kTau);
     }
     const double load_avg = rate_avg * kSolve;  // slots kept busy, averaged over ~40 ms, as of just before this submission
@@ -411,22 +411,25 @@ bool BaDemand::submit(double now) {
     ++total;
     t[n++ & 63] = now;
     if (!on) {
-        // coming: 64 submissions in a row at a rate that fills 10 of the 16 slots (the bursts of a slower loop never get there,
-        // nor does a chance cluster of independent arrivals at half that rate)
+        // coming: 64 submissions in a row at a rate that fills 8 of the 16 slots (the bursts of a slower loop never get there,
+        // nor does a chance cluster of independent arrivals at half that rate).  The threshold has to lie well BELOW what the
+        // launch path delivers when it is saturated (~2500 windows / s = 9.6 slots with 32 sequences in a closed loop): at 10
+        // slots a run whose first steps were slow never saw the rate that would have brought the grid up, and stayed at half
+        // the throughput for good (one of three driver-command runs on the same code, round 4).
         if (n >= 64 && now - flip > 0.02) {
             const double span = now - t[n & 63];  // (the oldest of the 64)
-            if (63.0 / std::max(span, 1e-6) * kSolve >= 0.625 * BA_SERVICE_SLOTS) {
+            if (63.0 / std::max(span, 1e-6) * kSolve >= 0.5 * BA_SERVICE_SLOTS) {
                 on = true;
                 flip = now;
                 low_since = -1;
-                rate_avg = std::max(rate_avg, 0.65 * BA_SERVICE_SLOTS / kSolve);
+                rate_avg = std::max(rate_avg, 0.5 * BA_SERVICE_SLOTS / kSolve);
                 ++flips;
             }
         }
-    } else if (load_avg > 0.5 * BA_SERVICE_SLOTS) {
+    } else if (load_avg > 0.3125 * BA_SERVICE_SLOTS) {
         low_since = -1;
     } else {
-        // going: the average below half the slots for 80 ms in a row (the last steps of a run -- callers finishing one after
+        // going: the average below 5 of the 16 slots for 80 ms in a row (the last steps of a run -- callers finishing one after
         // the other -- and the first ones after a pause look like low demand for a few milliseconds)
         if (low_since < 0) low_since = now;
         if (now - low_since > 0.08) {

@@ -21,6 +21,15 @@ def _bursts(period, n, steps, t0=0.0, jitter=0.002, seed=0):
     return np.sort(np.concatenate([t0 + s * period + rng.uniform(0, jitter, n) for s in range(steps)]))
 
 
+def test_the_saturated_launch_path_brings_the_grid_up(mvo):
+    """32 sequences in a closed loop on the launch path deliver ~2500 windows/s (9.6 slots' worth): the grid must come up from
+    there -- with the threshold at 10 slots it never did when a run's first steps were slow, and the run stayed at half speed."""
+    on, flips = _replay(mvo, np.sort(np.random.RandomState(7).uniform(0, 0.5, 1250)))
+    assert flips == 1 and on[-1]
+    on, flips = _replay(mvo, _bursts(0.0128, 32, 40))   # the same rate in lock step
+    assert flips == 1 and on[-1]
+
+
 def test_saturating_load_brings_the_grid_up_within_two_steps_and_keeps_it(mvo):
     # 24 sequences, one window each per 7-ms step = 3400 windows/s = 13 slots
     on, flips = _replay(mvo, _bursts(0.007, 24, 60))
@@ -36,7 +45,8 @@ def test_partial_load_stays_on_the_launch_path(mvo):
     # tracking rows in the loop: 24 windows per 16 ms = 1500 windows/s = 5.7 slots, in bursts
     on, flips = _replay(mvo, _bursts(0.016, 24, 80))
     assert flips == 0 and not on.any()
-    on, flips = _replay(mvo, np.sort(np.random.RandomState(2).uniform(0, 1.0, 1500)))
+    # independent arrivals at half the rate that brings the grid up (8 of 16 slots = 2100 windows/s): no chance cluster does
+    on, flips = _replay(mvo, np.sort(np.random.RandomState(2).uniform(0, 1.0, 1050)))
     assert flips == 0 and not on.any()
     # one sequence at 400 frames/s
     on, flips = _replay(mvo, np.arange(400) * 0.0025)
@@ -58,7 +68,7 @@ def test_pauses_and_the_end_of_a_run_do_not_look_like_low_load(mvo):
 
 def test_sustained_low_load_takes_the_grid_off(mvo):
     high = _bursts(0.007, 24, 30)
-    low = _bursts(0.016, 24, 40, t0=high[-1] + 0.2, seed=5)
+    low = _bursts(0.024, 24, 40, t0=high[-1] + 0.2, seed=5)     # 1000 windows/s = 3.8 slots (the grid leaves below 5)
     on, flips = _replay(mvo, np.concatenate([high, low]))
     assert flips == 2 and on[len(high) - 1] and not on[-1]
     off_at = low[int(np.argmin(on[len(high):]))] - low[0]
