@@ -230,7 +230,7 @@ __device__ __forceinline__ int solve_block(int sl_off, int pan_off, int xout_off
                 const int j = js + jj;
                 double d = D[jj][jj];
                 if (j >= R) d = 1.0;  // (column R of the last block: never a pivot)
-                ok &= ((d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX)) | (j >= n);
+                ok &= (d >= BA_PIVOT_MIN) & (d <= BA_PIVOT_MAX);  // (the identity rows behind n have the pivot 1)
                 const double r = ba_rcp_pivot(d);
                 c[jj] = p[jj];
                 nl[jj] = -(p[jj] * r);

@@ -12,22 +12,25 @@ mkdir -p $OUT
 ONE="python bench.py --steps 3 --warmup 1 --streams 1 --pipeline 0 --no-cpu-baseline --no-secondary"
 DRV="python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-secondary"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -o bench -- $DRV > $OUT/prof_default.log 2>&1
+# QUICK=1: only the passes whose numbers moved since the last full collection (kernel stats, config 4, the bench lines); the PMC
+# passes of the 5-keyframe configurations are skipped
+Q=${QUICK:-0}
 # the same with the launch path (no resident grid): per-launch k_ba_lm durations of the throughput cut
-MVO_BA_SERVICE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default_launches -o bench -- $DRV > $OUT/prof_default_launches.log 2>&1
+[ $Q = 1 ] || MVO_BA_SERVICE=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default_launches -o bench -- $DRV > $OUT/prof_default_launches.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_streams1 -o bench -- python bench.py --steps 6 --warmup 1 --streams 1 --pipeline 0 --no-cpu-baseline --no-secondary > $OUT/prof_streams1.log 2>&1
-timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- $ONE > $OUT/pmc_fetch.log 2>&1
-timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- $ONE > $OUT/pmc_write.log 2>&1
-timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- $ONE > $OUT/pmc_mfma.log 2>&1
-python tools/pmc_summary.py fetch_write $OUT/pmc_fetch/bench_counter_collection.csv $OUT/pmc_write/bench_counter_collection.csv $OUT/pmc_streams1_fetch_write_size.csv "$ONE"
+[ $Q = 1 ] || timeout 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o bench -- $ONE > $OUT/pmc_fetch.log 2>&1
+[ $Q = 1 ] || timeout 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o bench -- $ONE > $OUT/pmc_write.log 2>&1
+[ $Q = 1 ] || timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o bench -- $ONE > $OUT/pmc_mfma.log 2>&1
+[ $Q = 1 ] || python tools/pmc_summary.py fetch_write $OUT/pmc_fetch/bench_counter_collection.csv $OUT/pmc_write/bench_counter_collection.csv $OUT/pmc_streams1_fetch_write_size.csv "$ONE"
 # the same two passes on the DEFAULT command (24 shards: the solver launches hold ~8 windows): what bench.py's
 # roofline.traffic reads
 DEF="env MVO_BA_SERVICE=2 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary"
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_default -o bench -- $DEF > $OUT/pmc_fetch_default.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_default -o bench -- $DEF > $OUT/pmc_write_default.log 2>&1
-python tools/pmc_summary.py fetch_write $OUT/pmc_fetch_default/bench_counter_collection.csv $OUT/pmc_write_default/bench_counter_collection.csv $OUT/pmc_fetch_write_size_per_kernel.csv "$DEF" $((32 * 12 * 10))
-python tools/pmc_summary.py table $OUT/pmc_mfma/bench_counter_collection.csv $OUT/pmc_mfma_busy.txt "$ONE"
-timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_lds -o bench -- $ONE > $OUT/pmc_lds.log 2>&1
-python tools/pmc_summary.py table $OUT/pmc_lds/bench_counter_collection.csv $OUT/pmc_lds.txt "$ONE"
+[ $Q = 1 ] || timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_default -o bench -- $DEF > $OUT/pmc_fetch_default.log 2>&1
+[ $Q = 1 ] || timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_default -o bench -- $DEF > $OUT/pmc_write_default.log 2>&1
+[ $Q = 1 ] || python tools/pmc_summary.py fetch_write $OUT/pmc_fetch_default/bench_counter_collection.csv $OUT/pmc_write_default/bench_counter_collection.csv $OUT/pmc_fetch_write_size_per_kernel.csv "$DEF" $((32 * 12 * 10))
+[ $Q = 1 ] || python tools/pmc_summary.py table $OUT/pmc_mfma/bench_counter_collection.csv $OUT/pmc_mfma_busy.txt "$ONE"
+[ $Q = 1 ] || timeout 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $OUT/pmc_lds -o bench -- $ONE > $OUT/pmc_lds.log 2>&1
+[ $Q = 1 ] || python tools/pmc_summary.py table $OUT/pmc_lds/bench_counter_collection.csv $OUT/pmc_lds.txt "$ONE"
 # BASELINE configs[3] (S1242 / 4000 kp / BA10): the same passes on that config
 C4="python bench.py --width 1242 --height 375 --max-kp 4000 --ba-poses 10 --ba-points 4000 --streams 8 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_config4 -o bench -- $C4 > $OUT/prof_config4.log 2>&1
@@ -40,9 +43,9 @@ timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2> $OUT/bench_driver_command.err
 timeout 200 python bench.py --track --no-cpu-baseline --no-secondary > $OUT/bench_track.json 2> $OUT/bench_track.err
 # tracking rows: clean per-kernel durations (one shard, serial loop)
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_track1 -o bench -- python bench.py --track --steps 6 --warmup 1 --streams 1 --pipeline 0 --no-cpu-baseline --no-secondary > $OUT/prof_track1.log 2>&1
+[ $Q = 1 ] || timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_track1 -o bench -- python bench.py --track --steps 6 --warmup 1 --streams 1 --pipeline 0 --no-cpu-baseline --no-secondary > $OUT/prof_track1.log 2>&1
 timeout 200 python bench.py --width 1242 --height 375 --max-kp 4000 --ba-poses 10 --ba-points 4000 --streams 8 --steps 6 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_config4.json 2> $OUT/bench_config4.err
 ls -la $OUT | head -30
-cat $OUT/pmc_fetch_write_size_per_kernel.csv $OUT/pmc_streams1_fetch_write_size.csv $OUT/pmc_mfma_busy.txt $OUT/config4_pmc_fetch_write_size_per_kernel.csv $OUT/config4_pmc_mfma_busy.txt
+cat $OUT/pmc_fetch_write_size_per_kernel.csv $OUT/pmc_streams1_fetch_write_size.csv $OUT/pmc_mfma_busy.txt $OUT/config4_pmc_fetch_write_size_per_kernel.csv $OUT/config4_pmc_mfma_busy.txt 2>/dev/null
 for d in prof_default prof_default_launches prof_streams1 prof_config4 prof_track1; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; cut -c1-160 $f | head -8; done
 tail -c 600 $OUT/bench_default.json
