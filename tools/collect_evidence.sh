@@ -47,5 +47,5 @@ timeout 200 python bench.py --track --no-cpu-baseline --no-secondary > $OUT/benc
 timeout 200 python bench.py --width 1242 --height 375 --max-kp 4000 --ba-poses 10 --ba-points 4000 --streams 8 --steps 6 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/bench_config4.json 2> $OUT/bench_config4.err
 ls -la $OUT | head -30
 cat $OUT/pmc_fetch_write_size_per_kernel.csv $OUT/pmc_streams1_fetch_write_size.csv $OUT/pmc_mfma_busy.txt $OUT/config4_pmc_fetch_write_size_per_kernel.csv $OUT/config4_pmc_mfma_busy.txt 2>/dev/null
-for d in prof_default prof_default_launches prof_streams1 prof_config4 prof_track1; do f=$(find $OUT/$d -name "*kernel_stats.csv" | head -1); echo "== $d"; cut -c1-160 $f | head -8; done
-tail -c 600 $OUT/bench_default.json
+for d in prof_default prof_default_launches prof_streams1 prof_config4 prof_track1; do f=$(find $OUT/$d -name "*kernel_stats.csv" 2>/dev/null | head -1); echo "== $d"; [ -n "$f" ] && cut -c1-160 "$f" | head -8; done < /dev/null
+tail -c 600 $OUT/bench_default.json < /dev/null
