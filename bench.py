@@ -318,12 +318,12 @@ def algorithmic_work(args):
     }
 
 
-def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary
-    (profiles/r*_pmc_fetch_write_size_per_kernel.csv, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes; columns located by the header line).  None if absent."""
+def pmc_traffic(kernel, pattern="r[0-9]*_pmc_fetch_write_size_per_kernel.csv"):
+    """HBM-side bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary matching `pattern`
+    (profiles/r*_pmc_fetch_write_size_per_kernel.csv and its siblings, written by tools/pmc_summary.py from separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes; columns located by the header line).  None if absent."""
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch_write_size_per_kernel.csv"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             cols = None
             for line in open(path):
@@ -363,11 +363,11 @@ def kernel_resources(kernel):
     return best
 
 
-def pmc_mfma_busy(kernel):
+def pmc_mfma_busy(kernel, pattern="r[0-9]*_pmc_mfma_busy.txt"):
     """SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs of the grid) of `kernel` from the newest committed PMC pass
     (profiles/r*_pmc_mfma_busy.txt; the summary's header names the command).  (fraction, source) or None."""
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*_pmc_mfma_busy.txt"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             cols = None
             for line in open(path):
@@ -566,25 +566,37 @@ def main(argv=None, env=None):
                             algorithmic_per_launch=flops / max(launch["launches"], 1),
                             trials_per_solve=trials / max(solves, 1), launch_thread_ms=launch.get("service_ms"),
                             timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2))
-            tr = pmc_traffic("k_ba_lm")
+            # HBM-side bytes per launch from the rocprofv3 PMC passes of the same kind of launch (tools/collect_evidence.sh); the
+            # hand-offs are 8-byte accesses, a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported
+            # uncorrected
+            config4 = args.ba_poses == 10 and args.width == 1242 and args.ba_points == 4000
+            wpl = launch["windows"] / max(launch["launches"], 1)
             if resident:
                 # the resident grid: bytes per WINDOW of the profiled run (its dispatches span the run) x the windows of this one
                 trw = pmc_traffic("k_ba_service_per_window")
                 tr = (trw[0] * launch["windows"], trw[1]) if trw else None
-            # HBM-side bytes per launch from the rocprofv3 PMC passes of the same command (tools/collect_evidence.sh); the
-            # hand-offs are 8-byte accesses, a width the guide's 2x FETCH_SIZE correction is not calibrated for -> reported
-            # uncorrected
+            elif config4:
+                # BASELINE configs[3]: the profiled launches of the same command hold ~3.9 BA10 windows like the ones timed here
+                tr = pmc_traffic("k_ba_lm", "r[0-9]*_config4_pmc_fetch_write_size.csv")
+            elif args.ba_poses == 5 and not fix:
+                # launch path, 5-keyframe windows: bytes of the profiled single-window launch x the windows of a launch here
+                trw = pmc_traffic("k_ba_lm", "r[0-9]*_pmc_streams1_fetch_write_size.csv")
+                tr = (trw[0] * wpl, trw[1] + " (single-window launch x %.2f windows per launch)" % wpl) if trw else None
+            else:
+                tr = None  # (no PMC pass of this window shape has been committed)
             roof["traffic"], roof["traffic_source"] = (tr[0], tr[1]) if tr else (None, None)
             # what the compiler gave the dominant kernel (build remarks of the shipped sources) and how busy its matrix cores
-            # were in the single-window PMC pass (SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the CUs the window occupies)
-            roof["resources"] = kernel_resources("k_ba_service<32,2>" if resident else "k_ba_lm<false,32,1>")
-            mb = pmc_mfma_busy("k_ba_lm")
+            # were in the PMC pass of that kernel (SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the CUs its windows occupy)
+            cls = 32 if args.ba_poses <= 5 else (64 if args.ba_poses <= 10 else 0)
+            roof["resources"] = kernel_resources("k_ba_service<32,2>" if resident else ("k_ba_lm<false,64,2>" if config4 else "k_ba_lm<false,%d,1>" % cls))
+            mb = pmc_mfma_busy("k_ba_lm", "r[0-9]*_config4_pmc_mfma_busy.txt") if config4 else (pmc_mfma_busy("k_ba_lm") if cls == 32 and not fix else None)
             if mb:
-                # the profiled single-window launch: latency cut, 28 workgroups = 28 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over
-                # the 8 XCDs (the launch's duration in cycles = a eighth of it)
-                wgs = 28
-                roof["mfma_busy"] = round(mb[0] / max(mb[1] / 8.0 * wgs * 4, 1.0), 4)
-                roof["mfma_busy_source"] = mb[2] + " (single-window launch, %d CUs: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x %d SIMDs))" % (wgs, wgs * 4)
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs (the launch's duration in cycles = an eighth of it); the profiled
+                # launches: one window of 28 workgroups (latency cut), or ~3.9 BA10 windows of 56
+                cus = 3.93 * 56 if config4 else 28
+                roof["mfma_busy"] = round(mb[0] / max(mb[1] / 8.0 * cus * 4, 1.0), 4)
+                roof["mfma_busy_source"] = mb[2] + " (%s: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x %d SIMDs))" % (
+                    "launches of 3.93 BA10 windows on 56 CUs each" if config4 else "single-window launch, 28 CUs", int(cus * 4))
             per_kernel["k_ba_lm"] = (launch.get("elapsed_ms", 0.0) if resident else launch["ms"]) / max(R["nframes"] * args.streams, 1)
         else:
             roof = None
