@@ -224,6 +224,7 @@ int mvo_ensure_pinned(mvo_ctx* ctx, size_t bytes);
 int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int channels, int nlevels);
 int orb_launch_detect(mvo_ctx* ctx, uint8_t* host, bool ordered);
 int orb_launch_blur(mvo_ctx* ctx, int nlevels);
+bool orb_brief_from_levels(const mvo_ctx* ctx);
 int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps, uint8_t* desc_host);
 // match_kernels.hip
 int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int32_t* d_out,

@@ -301,6 +301,8 @@ int orb_detect_device(mvo_ctx* ctx, const uint8_t* d_img, int w, int h, int stri
     const bool ordered = !ctx->ba_throughput_mode;
     if ((r = orb_launch_detect(ctx, ctx->h_pin, ordered))) return r;
     MVO_HIP(hipEventRecord(ctx->ev, ctx->stream));
+    // a ctx that describes from whole blurred levels has them blurred now, behind the event: while this thread selects keypoints
+    if (orb_brief_from_levels(ctx) && (r = orb_launch_blur(ctx, P.nlevels))) return r;
     ht.lap(0);
     MVO_HIP(hipEventSynchronize(ctx->ev));
     gate.release();

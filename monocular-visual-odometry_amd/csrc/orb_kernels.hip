@@ -17,7 +17,8 @@
 //                   pinned host buffer (no candidate compaction on the device, no copy dispatch)
 //   k_brief         one WAVE per keypoint: the 45x56 raw window is staged in LDS, blurred there (separable 7x7
 //                   fixed-point Gaussian, the keypoint's window only) and sampled: 512 rotated taps, 4 ballots = 256 bits
-//   k_blur          whole-level blur, kept for mvo_debug_get_level(blurred) only
+//   k_blur          whole-level blur + k_brief_sample: the same descriptors for a ctx in throughput mode (a sixth of the
+//                   instructions per frame); also behind mvo_debug_get_level(blurred)
 // Compiled with -ffp-contract=off: the float expressions (Harris response, fastAtan2, tap rotation) are
 // canonical arithmetic and must round exactly like the oracle.
 #include "mvo_internal.h"
@@ -744,10 +745,47 @@ __global__ __launch_bounds__(64 * WAVES) void k_brief(const uint8_t* __restrict_
     }
 }
 
+// The same descriptor from a level that has been blurred as a whole (k_blur): one WAVE per keypoint, 8 byte loads per lane.
+// A ctx that shares the GPU with many others (throughput mode) takes this form: blurring every level once costs a sixth of
+// the instructions of blurring 2000 keypoint windows (0.8 M against ~5 M wave instructions per S640 frame), and under the
+// resident solver grid the extraction lives on 6 CUs per XCD where instructions, not launches, are what a frame costs.  The
+// blur is queued right behind the detection kernel: it runs while the host thread selects the keypoints.
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_brief_sample(const uint8_t* __restrict__ blurpyr, const DevDescKp* __restrict__ kps,
+                                                             uint8_t* __restrict__ desc, uint8_t* __restrict__ desc_host, PyrInfo P,
+                                                             int n) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ki = blockIdx.x * WAVES + wave;
+    if (ki >= n) return;
+    const DevDescKp kp = kps[ki];
+    const LevelInfo L = P.lv[__builtin_amdgcn_readfirstlane(kp.level)];
+    const int stride = L.stride;
+    const uint8_t* wb = blurpyr + L.off + (size_t)(kp.cy + MVO_BORDER) * stride + (kp.cx + MVO_BORDER);
+    const float a = kp.a, b = kp.b;
+    u64 words[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const signed char* pt = c_pattern + 4 * (lane + 64 * k);
+        float px0 = (float)pt[0], py0 = (float)pt[1], px1 = (float)pt[2], py1 = (float)pt[3];
+        int ix0 = __float2int_rn(__fsub_rn(__fmul_rn(px0, a), __fmul_rn(py0, b)));
+        int iy0 = __float2int_rn(__fadd_rn(__fmul_rn(px0, b), __fmul_rn(py0, a)));
+        int ix1 = __float2int_rn(__fsub_rn(__fmul_rn(px1, a), __fmul_rn(py1, b)));
+        int iy1 = __float2int_rn(__fadd_rn(__fmul_rn(px1, b), __fmul_rn(py1, a)));
+        int t0 = wb[iy0 * stride + ix0];
+        int t1 = wb[iy1 * stride + ix1];
+        words[k] = __ballot(t0 < t1);
+    }
+    if (lane < 4) {
+        reinterpret_cast<u64*>(desc + (size_t)ki * 32)[lane] = words[lane];
+        if (desc_host) reinterpret_cast<u64*>(desc_host + (size_t)ki * 32)[lane] = words[lane];
+    }
+}
+
 // ================================================================================================ launchers
 static bool g_tables_ready[16] = {false};
 int g_pyr_force_chain = 0;  // test hook: the per-pixel chain kernel instead of the LDS-tiled one
 int g_pyr_full_pool = std::getenv("MVO_PYR_FULL_POOL") ? std::atoi(std::getenv("MVO_PYR_FULL_POOL")) : 0;  // A/B: the fixed 32-KB pool
+int g_brief_level_blur = std::getenv("MVO_BRIEF_LEVEL_BLUR") ? std::atoi(std::getenv("MVO_BRIEF_LEVEL_BLUR")) : -1;  // -1 = by mode (throughput ctx: whole-level blur + k_brief_sample), 0 = always the fused k_brief, 1 = always the level form (A/B)
 int g_brief_waves = std::getenv("MVO_BRIEF_WAVES") ? std::atoi(std::getenv("MVO_BRIEF_WAVES")) : 4;        // A/B: 1 = one keypoint per workgroup (measured: no gain under load, 3 us slower alone)
 
 static int upload_constant_tables(mvo_ctx* ctx) {
@@ -819,7 +857,11 @@ int orb_launch_detect(mvo_ctx* ctx, uint8_t* host, bool ordered) {
     return MVO_OK;
 }
 
-// whole-level blur into d_blur: mvo_debug_get_level(blurred) only (the product path blurs inside k_brief)
+// does this ctx describe from whole blurred levels (k_blur + k_brief_sample) or from keypoint windows (k_brief)?
+bool orb_brief_from_levels(const mvo_ctx* ctx) {
+    return g_brief_level_blur < 0 ? ctx->ba_throughput_mode != 0 : g_brief_level_blur != 0;
+}
+// whole-level blur into d_blur: for k_brief_sample and for mvo_debug_get_level(blurred)
 int orb_launch_blur(mvo_ctx* ctx, int nlevels) {
     const PyrInfo& P = ctx->pyr;
     int nb = nlevels < P.nlevels ? P.lv[nlevels].btile_off : P.n_btiles;
@@ -832,6 +874,16 @@ int orb_launch_blur(mvo_ctx* ctx, int nlevels) {
 
 int orb_launch_brief(mvo_ctx* ctx, int n, const DevDescKp* kps, uint8_t* desc_host) {
     if (n <= 0) return MVO_OK;
+    if (orb_brief_from_levels(ctx)) {
+        if (!ctx->blur_valid) {  // (normally queued behind the detection already: orb_detect_device)
+            int r = orb_launch_blur(ctx, ctx->pyr_levels_built);
+            if (r) return r;
+        }
+        ProfScope ps(ctx, "k_brief");
+        hipLaunchKernelGGL((k_brief_sample<4>), dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_blur, kps, ctx->d_desc, desc_host, ctx->pyr, n);
+        MVO_HIP(hipGetLastError());
+        return MVO_OK;
+    }
     ProfScope ps(ctx, "k_brief");
     if (g_brief_waves == 4)
         hipLaunchKernelGGL((k_brief<4>), dim3((n + 3) / 4), dim3(256), 0, ctx->stream, ctx->d_raw, kps, ctx->d_desc, desc_host, ctx->pyr, n);

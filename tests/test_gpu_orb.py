@@ -245,4 +245,14 @@ def test_both_candidate_orderings_bit_exact(mvo, O, w, h):
             k = c.calc_keypoints(img, cap=8192)
             assert_struct_equal(k, O.calc_keypoints(img, p).astype(k.dtype), "calcKeyPoints, %s mode, run %d" % (mode, rep))
             _cand_cmp(mvo, c.debug_candidates(), O.candidates(img, p))
+            # descriptors: keypoint windows blurred inside k_brief (latency mode) or whole levels blurred behind the detection
+            # kernel and sampled by k_brief_sample (throughput mode) -- the oracle's bits either way, with and without reuse
+            ko = O.calc_keypoints(img, p)
+            k2, d = c.calc_descriptors(img, k, reuse_pyramid=True)
+            ko2, do = O.calc_descriptors(img, ko, p)
+            assert_struct_equal(k2, ko2.astype(k.dtype), "calcDescriptors keypoints, %s mode" % mode)
+            assert np.array_equal(d, do), "descriptors, %s mode: %d rows differ" % (mode, (d != do).any(1).sum())
+            k3, d3 = c.calc_descriptors(img, k, reuse_pyramid=False)
+            assert np.array_equal(d3, do), "descriptors without reuse, %s mode" % mode
+            assert np.array_equal(c.debug_level(1, True), O.pyramid_level(img, p, 1, True))
         c.close()
