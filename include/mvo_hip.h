@@ -175,7 +175,9 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
  * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
- * calling thread (~75 us of host time per frame instead of ~8 us of kernel time).
+ * calling thread (~75 us of host time per frame instead of ~8 us of kernel time), and descriptors are sampled from whole
+ * blurred pyramid levels (one blur of every level behind the detection kernel instead of one blur per keypoint window: a fifth
+ * of the instructions, one launch more).
  * The summation order of a solve (hence the last bits of its result) follows the cut; every cut is deterministic and is what
  * mvo_debug_get_ba_plan reports.  Results of the extraction do not depend on the mode.
  * SHARED: many sequences are in flight, but the bundle adjustment is not what their frames mostly wait for (tracking rows --
