@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_knn2(const uint4* __restrict__ q, int n
         __hip_atomic_store(mine, ((u64)(uint32_t)p.y << 32) | (uint32_t)p.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(mine + 1, ((u64)(uint32_t)p.w << 32) | (uint32_t)p.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores are complete before this workgroup is counted
+    MVO_WAIT_VM0();  // the write-through stores are complete before this workgroup is counted
     int last = 0;
     if (lane == 0) {
         last = __hip_atomic_fetch_add(arrive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == MK_GROUPS - 1;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void mm_fold(uint32_t& b0, uint32_t& b1, uint32_t key
 __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ q, int nq, const uint32_t* __restrict__ t, int nt,
                                                    int slice, u64* __restrict__ part, int32_t* __restrict__ arrive,
                                                    int32_t* __restrict__ out_idx, int32_t* __restrict__ out_dist) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char mm_lds[];
+    MVO_DYN_LDS_ALIGNED16(unsigned char, mm_lds);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j0 = blockIdx.y * slice, jn = max(0, min(slice, nt - j0));  // trains j0 .. j0 + jn - 1
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_knn2_mfma(const uint32_t* __restrict__ 
     // ---- slice partials -> the last workgroup of the query group folds them (arrival counter per group, self re-arming)
     u64* mine = part + ((size_t)blockIdx.y * nq + qc);
     if (kb == 0 && qi < nq) __hip_atomic_store(mine, ((u64)b1 << 32) | b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVO_WAIT_VM0();
     __syncthreads();
     __shared__ int s_last;
     if (tid == 0) {

@@ -4,6 +4,21 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The dynamic LDS segment of a kernel and kernel-only attributes.  tests/sim compiles the kernel SOURCES for the host against an
+// emulation of the HIP runtime (a test aid: MVO_KERNEL_SIM is defined by its stand-in for <hip/hip_runtime.h>, the library has
+// no CPU path); there the segment comes from the emulated launch and the attributes mean nothing.
+#ifndef MVO_KERNEL_SIM
+#define MVO_DYN_LDS(T, name) extern __shared__ T name[]
+#define MVO_DYN_LDS_ALIGNED16(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
+#define MVO_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#define MVO_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")  // this wave's global stores have left for memory
+#else
+#define MVO_DYN_LDS(T, name) T* name = static_cast<T*>(emu_dyn_lds())
+#define MVO_DYN_LDS_ALIGNED16(T, name) T* name = static_cast<T*>(emu_dyn_lds())
+#define MVO_WAVES_PER_EU(lo, hi)
+#define MVO_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#endif
+
 #include <map>
 #include <atomic>
 #include <string>

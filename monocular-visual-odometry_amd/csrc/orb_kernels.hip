@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
                                                  const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
     // region pool: dynamic LDS sized by the host for the hungriest tile of THIS launch (orb_setup_geometry: ~9 KB for the
     // 4-level 640 x 480 pyramid; the fixed 32 KB pool of round 3 let only four workgroups share a CU)
-    extern __shared__ uint8_t lds[];
+    MVO_DYN_LDS(uint8_t, lds);
     __shared__ int sbox[4];
     const int tid = threadIdx.x;
     int l = l0;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     if (!order_rows) return;
     // ---- 4. the tile row's last workgroup orders the row
     // (dynamic LDS, sized by the host for the widest level: orb_detect_order_lds)
-    extern __shared__ int s_dyn[];
+    MVO_DYN_LDS(int, s_dyn);
     const int mtx = P.lv[0].tiles_x;                     // level 0 is the widest
     __shared__ int s_last;
     int* s_off = s_dyn;                                  // [FT_H * mtx] exclusive scan over (line, tile)
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     typedef uint16_t TileStarts[FT_H + 1];
     TileStarts* s_tstart = reinterpret_cast<TileStarts*>(s_tpre + mtx + 1);  // [mtx][17] line starts inside every tile
     __shared__ int s_wsum[4];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MVO_WAIT_VM0();
     __syncthreads();
     const int t0 = L.tile_off + ty * L.tiles_x;  // first tile of the row: names the row
     if (tid == 0) {

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(pw::kHypLanes) void k_pnp_hypotheses(const float* _
     __shared__ pw::HypLds lds;
     pnp_hypothesis_body(p3, p2, n, subsets, cam, thr2, models, counts, masks, h_models, h_counts, lds);
 }
-__global__ __launch_bounds__(pw::kHypLanes) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_pnp_hypotheses_occ2(
+__global__ __launch_bounds__(pw::kHypLanes) MVO_WAVES_PER_EU(2, 2) void k_pnp_hypotheses_occ2(
     const float* __restrict__ p3, const float* __restrict__ p2, int n, const int32_t* __restrict__ subsets, TrackCamera cam, float thr2,
     double* __restrict__ models, int32_t* __restrict__ counts, uint8_t* __restrict__ masks, double* __restrict__ h_models,
     int32_t* __restrict__ h_counts) {

@@ -58,6 +58,7 @@ struct Wave {
     int live = 0, arrived = 0;
     unsigned gen = 0;
     EmuWaveBuf buf;
+    EmuI8Buf i8;
 };
 struct Group {  // one workgroup
     std::vector<Fiber> fib;
@@ -244,6 +245,7 @@ long long emu_clock() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 EmuWaveBuf& emu_wave_buf() { return tl_group->waves[tl_group->cur >> 6].buf; }
+EmuI8Buf& emu_wave_i8() { return tl_group->waves[tl_group->cur >> 6].i8; }
 void* emu_dyn_lds() { return tl_group->dyn_lds; }
 
 // ---------------------------------------------------------------------------------------------- streams and launches
@@ -301,22 +303,29 @@ void emu_launch(std::function<void()> body, dim3 grid, dim3 block, size_t dyn_ld
     if (const char* e = getenv("EMU_ORDER")) order_mode = !strcmp(e, "reverse") ? 1 : (!strcmp(e, "shuffle") ? 2 : 0);
     std::thread([=]() {
         if (prev) prev->wait();  // stream order
-        const int nb = (int)grid.x, nt = (int)block.x;
+        const int gx = (int)grid.x, gy = (int)grid.y, nb = gx * gy, nt = (int)block.x;  // (1-D blocks, 1-D / 2-D grids)
+        // every workgroup of a grid of up to 1024 runs on its own OS thread at once (the solver's workgroups wait for each
+        // other); larger grids -- extraction kernels on big images, whose workgroups never wait for one another -- are worked
+        // off by 256 threads
+        const int nthreads = nb <= 1024 ? nb : 256;
+        std::atomic<int> next{0};
         std::vector<std::thread> th;
-        th.reserve(nb);
-        for (int b = 0; b < nb; ++b)
-            th.emplace_back([&, b]() {
-                Group g;
-                g.fib.resize(nt);
-                g.waves.resize((nt + 63) / 64);
-                g.body = &body;
-                g.bdim = {(unsigned)nt, 1, 1};
-                g.bidx = {(unsigned)b, 0, 0};
-                g.gdim = {(unsigned)nb, 1, 1};
-                static const int fill = getenv("EMU_LDS_FILL") ? (int)strtol(getenv("EMU_LDS_FILL"), nullptr, 0) : 0xcd;
-                std::vector<char> lds(dyn_lds_bytes + 64, (char)fill);  // LDS is not zero-initialised on the device either
-                g.dyn_lds = (void*)(((uintptr_t)lds.data() + 63) & ~(uintptr_t)63);
-                run_group(g, order_mode, 12345u + (unsigned)b);
+        th.reserve(nthreads);
+        for (int w = 0; w < nthreads; ++w)
+            th.emplace_back([&]() {
+                for (int b = next.fetch_add(1); b < nb; b = next.fetch_add(1)) {
+                    Group g;
+                    g.fib.resize(nt);
+                    g.waves.resize((nt + 63) / 64);
+                    g.body = &body;
+                    g.bdim = {(unsigned)nt, 1, 1};
+                    g.bidx = {(unsigned)(b % gx), (unsigned)(b / gx), 0};
+                    g.gdim = {(unsigned)gx, (unsigned)gy, 1};
+                    static const int fill = getenv("EMU_LDS_FILL") ? (int)strtol(getenv("EMU_LDS_FILL"), nullptr, 0) : 0xcd;
+                    std::vector<char> lds(dyn_lds_bytes + 64, (char)fill);  // LDS is not zero-initialised on the device either
+                    g.dyn_lds = (void*)(((uintptr_t)lds.data() + 63) & ~(uintptr_t)63);
+                    run_group(g, order_mode, 12345u + (unsigned)b);
+                }
             });
         for (auto& t : th) t.join();
         task->finish();

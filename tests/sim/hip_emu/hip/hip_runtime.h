@@ -35,6 +35,8 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static thread_local  // one OS thread per workgroup: thread-local = workgroup-local
+#define __constant__                    // (plain globals; hipMemcpyToSymbol below)
+#define HIP_SYMBOL(x) x
 
 struct emu_uint3 {
     unsigned x, y, z;
@@ -94,6 +96,30 @@ inline unsigned long long __ballot(int pred) {
     emu_wave_sync();
     return m;
 }
+inline unsigned __shfl_xor(unsigned v, int mask) { return (unsigned)emu_exchange_u64(v, emu_lane() ^ mask); }
+inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return emu_exchange_u64(v, emu_lane() ^ mask); }
+inline long long __shfl_xor(long long v, int mask) { return (long long)emu_exchange_u64((unsigned long long)v, emu_lane() ^ mask); }
+inline float __shfl_xor(float v, int mask) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    u = (unsigned)emu_exchange_u64(u, emu_lane() ^ mask);
+    memcpy(&v, &u, 4);
+    return v;
+}
+inline unsigned __shfl(unsigned v, int src) { return (unsigned)emu_exchange_u64(v, src); }
+inline float __shfl(float v, int src) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    u = (unsigned)emu_exchange_u64(u, src);
+    memcpy(&v, &u, 4);
+    return v;
+}
+// lane l receives the value of lane l - delta; the lanes below delta keep their own
+inline int __shfl_up(int v, unsigned delta) {
+    const int l = emu_lane();
+    return (int)emu_exchange_u64((unsigned)v, l >= (int)delta ? l - (int)delta : l);
+}
+inline unsigned __shfl_up(unsigned v, unsigned delta) { return (unsigned)__shfl_up((int)v, delta); }
 #define __builtin_amdgcn_readlane(v, src) ((int)emu_exchange_u64((unsigned)(v), (src)))
 #define __builtin_amdgcn_readfirstlane(v) ((int)emu_exchange_u64((unsigned)(v), 0))
 #define __builtin_amdgcn_wave_barrier() emu_wave_sync()
@@ -126,6 +152,33 @@ inline emu_v4d emu_mfma_f64_16x16x4(double a, double b, emu_v4d c) {
     return r;
 }
 #define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64_16x16x4((a), (b), (c))
+// v_mfma_i32_16x16x64_i8: D = A (16 x 64) * B (64 x 16) + C in exact integers.  Lane (i = lane & 15, kb = lane >> 4) supplies the 16
+// bytes A[i][16 kb .. 16 kb + 15] and, as the B operand, B[16 kb .. 16 kb + 15][i]; register r of lane (q = lane >> 4,
+// j = lane & 15) holds D[4 q + r][j] (the layout csrc/match_kernels.hip relies on, validated on the MI355X by its tests).
+typedef int emu_v4i __attribute__((ext_vector_type(4)));
+struct EmuI8Buf {
+    signed char a[64][16], b[64][16];
+};
+EmuI8Buf& emu_wave_i8();
+inline emu_v4i emu_mfma_i32_16x16x64_i8(emu_v4i a, emu_v4i b, emu_v4i c) {
+    EmuI8Buf& w = emu_wave_i8();
+    const int lane = emu_lane();
+    memcpy(w.a[lane], &a, 16);
+    memcpy(w.b[lane], &b, 16);
+    emu_wave_sync();
+    const int q = lane >> 4, j = lane & 15;
+    emu_v4i r;
+    for (int reg = 0; reg < 4; ++reg) {
+        const int i = 4 * q + reg;
+        int acc = c[reg];
+        for (int kb = 0; kb < 4; ++kb)
+            for (int k = 0; k < 16; ++k) acc += (int)w.a[16 * kb + i][k] * (int)w.b[16 * kb + j][k];
+        r[reg] = acc;
+    }
+    emu_wave_sync();
+    return r;
+}
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, x, y, z) emu_mfma_i32_16x16x64_i8((a), (b), (c))
 
 // ---------------------------------------------------------------------------------------------- scalar helpers
 inline int __double2loint(double v) {
@@ -154,6 +207,40 @@ inline double __longlong_as_double(long long u) {
     memcpy(&v, &u, 8);
     return v;
 }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+// (this build is compiled with -ffp-contract=off: the plain operators round once, like the _rn intrinsics)
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline int __float2int_rn(float v) { return (int)lrintf(v); }  // round to nearest even (the default rounding mode)
+inline int __float2int_rd(float v) { return (int)floorf(v); }
+inline unsigned emu_sad_u8(unsigned a, unsigned b, unsigned c) {
+    for (int k = 0; k < 4; ++k) {
+        const int x = (int)((a >> (8 * k)) & 255u), y = (int)((b >> (8 * k)) & 255u);
+        c += (unsigned)(x > y ? x - y : y - x);
+    }
+    return c;
+}
+#define __builtin_amdgcn_sad_u8(a, b, c) emu_sad_u8((a), (b), (c))
+#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// vector types of the HIP headers that the kernels use
+struct int2 { int x, y; };
+struct uint2 { unsigned x, y; };
+struct float2 { float x, y; };
+struct int4 { int x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
+struct float4 { float x, y, z, w; };
+struct ulonglong2 { unsigned long long x, y; };
+inline int2 make_int2(int x, int y) { return {x, y}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+inline float2 make_float2(float x, float y) { return {x, y}; }
+inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return {x, y}; }
 using std::max;
 using std::min;
 inline int min(int a, unsigned b) { return a < (int)b ? a : (int)b; }
@@ -169,6 +256,7 @@ inline size_t max(size_t a, int b) { return a > (size_t)b ? a : (size_t)b; }
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add((p), (v), __ATOMIC_RELAXED)
 #define __hip_atomic_exchange(p, v, order, scope) __atomic_exchange_n((p), (v), __ATOMIC_RELAXED)
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---------------------------------------------------------------------------------------------- host runtime subset
@@ -221,11 +309,18 @@ hipError_t hipMemsetAsync(void* p, int v, size_t bytes, hipStream_t s);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+enum { hipDeviceScheduleAuto = 0, hipDeviceScheduleSpin = 1, hipDeviceScheduleYield = 2, hipDeviceScheduleBlockingSync = 4 };
+inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
+template <class T>
+inline hipError_t hipMemcpyToSymbol(T& symbol, const void* src, size_t bytes, size_t offset = 0, hipMemcpyKind = hipMemcpyHostToDevice) {
+    memcpy(reinterpret_cast<char*>(&symbol) + offset, src, bytes);
+    return hipSuccess;
+}
 
 // A launch: `body` is executed by every GPU thread of the grid; asynchronous on `stream` like the real thing.
 void emu_launch(std::function<void()> body, dim3 grid, dim3 block, size_t dyn_lds_bytes, hipStream_t stream);
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-    emu_launch([=]() { kernel(__VA_ARGS__); }, dim3(grid), dim3(block), (lds), (stream))
+    emu_launch([=]() { (kernel)(__VA_ARGS__); }, dim3(grid), dim3(block), (lds), (stream))
 // dynamic LDS segment of the calling workgroup
 void* emu_dyn_lds();
 

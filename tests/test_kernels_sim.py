@@ -1,0 +1,152 @@
+"""The extraction, matching, tracking and key-frame kernel SOURCES (csrc/orb_kernels.hip, match_kernels.hip, track_kernels.hip) with
+their host side (csrc/mvo_api.cpp, orb_host.cpp, track_host.cpp), compiled for x86 against tests/sim/hip_emu and executed thread for
+thread on the CPU -- every GPU thread a fiber, wave operations (ballots, shuffles, the i8 MFMA of the matcher) rendez-vous points of
+the 64 fibers of a wave, arrival counters and write-through partials real shared memory.  The tests below are the MI355X tests of
+tests/test_gpu_*.py themselves, run through that build: the same calls into the same C-ABI, the same comparison with the oracle,
+available where no GPU exists (pytest -m "not gpu").  The emulation is a test aid: nothing of it is linked into libmvo_hip.so
+(test_abi.py); the product has no CPU path."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+import test_gpu_keyframe as T_kf
+import test_gpu_match as T_match
+import test_gpu_orb as T_orb
+import test_gpu_track as T_track
+
+SIM_DIR = os.path.join(ROOT, "tests", "sim")
+SIM_LIB = os.path.join(SIM_DIR, "_build", "libmvo_sim.so")
+
+
+@pytest.fixture(scope="module")
+def simlib():
+    subprocess.check_call(["make", "-C", SIM_DIR, "-s", "-j8", "_build/libmvo_sim.so"])
+    lib = C.CDLL(SIM_LIB)
+    lib.mvo_last_error.restype = C.c_char_p
+    lib.mvo_destroy.restype = None
+    return lib
+
+
+@pytest.fixture()
+def simmvo(mvo, simlib, monkeypatch):
+    """The product's Python mirror of the C-ABI with its library handle pointing at the emulated build."""
+    real_init = mvo.Context.__init__
+
+    class SimContext(mvo.Context):
+        def __init__(self, device=0, **orb_params):
+            real_init(self, device, **orb_params)
+
+    class HostTensor:  # "device memory" of the emulated runtime is host memory: stands in for torch's .cuda() tensors
+        def __init__(self, a):
+            self.a = np.ascontiguousarray(a)
+
+        def data_ptr(self):
+            return self.a.ctypes.data
+
+    monkeypatch.setattr(mvo, "load_library", lambda: simlib)
+    monkeypatch.setattr(mvo, "Context", SimContext)
+    monkeypatch.setattr(T_track, "_to_device", HostTensor)
+    return mvo
+
+
+@pytest.fixture()
+def simctx(simmvo):
+    c = simmvo.Context(0)
+    yield c
+    c.close()
+
+
+# ------------------------------------------------------------------------------------------------ extraction
+@pytest.mark.parametrize("w,h,ch", [(160, 120, 3), (333, 251, 1), (640, 480, 3)])
+def test_pyramid_blur_candidates(simmvo, O, simctx, w, h, ch):
+    T_orb.test_pyramid_blur_candidates_bit_exact(simmvo, O, simctx, w, h, ch)
+
+
+@pytest.mark.parametrize("nlevels,sf", [(4, 1.2), (8, 1.2), (3, 2.0)])
+def test_both_pyramid_kernels(simmvo, O, simctx, nlevels, sf):
+    T_orb.test_both_pyramid_kernels_bit_exact(simmvo, O, simctx, nlevels, sf)
+
+
+@pytest.mark.parametrize("w,h,ch", [(160, 120, 3), (333, 251, 1), (640, 480, 3)])
+def test_keypoints_and_descriptors(simmvo, O, simctx, w, h, ch):
+    T_orb.test_keypoints_and_descriptors_bit_exact(simmvo, O, simctx, w, h, ch)
+
+
+def test_selection_shapes_and_degenerate_images(simmvo, O, simctx):
+    T_orb.test_legacy_inter_linear_pyramid_bit_exact(simmvo, O, simctx)
+    T_orb.test_quota_limited_selection_and_small_thresholds(simmvo, O, simctx)
+    T_orb.test_other_pyramid_shapes(simmvo, O, simctx)
+    T_orb.test_grid_latching_and_degenerate_images(simmvo, O, simctx)
+    T_orb.test_error_paths(simmvo, simctx)
+
+
+@pytest.mark.parametrize("w,h", [(333, 251), (640, 480)])
+def test_both_candidate_orderings_and_both_descriptor_forms(simmvo, O, w, h):
+    T_orb.test_both_candidate_orderings_bit_exact(simmvo, O, w, h)
+
+
+# ------------------------------------------------------------------------------------------------ matching
+@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("kind,nq,nt", [("uniform", 2000, 2000), ("ties", 1, 1), ("perturbed", 63, 65), ("ties", 129, 15),
+                                        ("perturbed", 1000, 2500), ("uniform", 17, 255)])
+def test_knn2(simmvo, O, simctx, kind, nq, nt, mfma):
+    T_match.test_knn2_bit_exact(simmvo, O, simctx, kind, nq, nt, mfma)
+
+
+def test_matcher_structured_empty_radius(simmvo, O, simctx):
+    T_match.test_knn2_mfma_on_structured_descriptors(simmvo, O, simctx)
+    T_match.test_knn2_empty_sets(simmvo, O, simctx)
+    for nq, nt, r in [(500, 700, 50.0), (64, 64, 0.0), (100, 3, 1e6)]:
+        T_match.test_radius_l1_bit_exact(simmvo, O, simctx, nq, nt, r)
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_match_features(simmvo, O, simctx, method):
+    T_match.test_match_features_bit_exact(simmvo, O, simctx, method, "perturbed")
+    T_match.test_match_features_bit_exact(simmvo, O, simctx, method, "ties")
+
+
+# ------------------------------------------------------------------------------------------------ tracking rows
+@pytest.mark.parametrize("seed,n_map", [(3, 4000), (4, 1), (6, 1025)])
+def test_map_points_in_view(simmvo, O, simctx, seed, n_map):
+    T_track.test_map_points_in_view_bit_exact(simmvo, O, simctx, seed, n_map)
+
+
+def test_solve_pnp_ransac(simmvo, O, simctx):
+    T_track.test_solve_pnp_ransac_matches_the_oracle(simmvo, O, simctx, 11, {})
+    T_track.test_solve_pnp_ransac_matches_the_oracle(simmvo, O, simctx, 12, dict(outlier_frac=0.5))
+    T_track.test_all_hypotheses_bit_exact(simmvo, O, simctx)
+    T_track.test_solve_pnp_ransac_edge_cases(simmvo, O, simctx)
+    T_track.test_host_corrects_a_wrong_device_choice(simmvo, O, simctx)
+
+
+def test_tracking_step(simmvo, O, simctx):
+    T_track.test_tracking_step_end_to_end(simmvo, O, simctx)
+
+
+# ------------------------------------------------------------------------------------------------ key-frame row
+def test_triangulation_and_essential_matrix(simmvo, O, simctx):
+    T_kf.test_triangulate_points_bit_exact(simmvo, O, simctx, 600, 21, {})
+    T_kf.test_triangulate_points_bit_exact(simmvo, O, simctx, 257, 23, dict(outlier_frac=0.5))
+    T_kf.test_triangulate_edge_cases(simmvo, O, simctx)
+    T_kf.test_retain_good_triangulation_matches_oracle(simmvo, O, simctx)
+    T_kf.test_find_essential_inliers_matches_the_oracle(simmvo, O, simctx, 500, 8, {})
+    T_kf.test_find_essential_inliers_matches_the_oracle(simmvo, O, simctx, 500, 9, dict(outlier_frac=0.5))
+    T_kf.test_find_essential_inliers_edge_cases(simmvo, O, simctx)
+
+
+def test_keyframe_insertion(simmvo, O, simctx):
+    T_kf.test_keyframe_insertion_end_to_end(simmvo, O, simctx)
+
+
+# ------------------------------------------------------------------------------------------------ the whole hot path, several callers
+def test_concurrent_contexts_and_siblings(simmvo):
+    """Six host threads, a ctx each, extraction + matching + BA at the same time through one emulated device; a sibling ctx on
+    its parent's stream: every caller gets what a lone ctx gets (tests/test_gpu_concurrency.py)."""
+    import test_gpu_concurrency as T_conc
+    T_conc.test_concurrent_contexts_reproduce_the_serial_results(simmvo)
+    T_conc.test_sibling_context_shares_the_stream_and_nothing_else(simmvo)
