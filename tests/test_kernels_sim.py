@@ -150,3 +150,39 @@ def test_concurrent_contexts_and_siblings(simmvo):
     import test_gpu_concurrency as T_conc
     T_conc.test_concurrent_contexts_reproduce_the_serial_results(simmvo)
     T_conc.test_sibling_context_shares_the_stream_and_nothing_else(simmvo)
+
+
+# ------------------------------------------------------------------------------------------------ the C++ side of the boundary
+@pytest.fixture()
+def sim_as_the_library(simlib, tmp_path, monkeypatch):
+    """The C++ test programs of host/tests and the headless run_vo link libmvo_hip.so by name (DT_RUNPATH): a directory in front of the
+    search path that holds the emulated build under that name makes the SAME binaries run on the CPU."""
+    d = tmp_path / "simlib"
+    d.mkdir()
+    os.symlink(SIM_LIB, d / "libmvo_hip.so")
+    monkeypatch.setenv("LD_LIBRARY_PATH", str(d) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    return d
+
+
+def test_cpp_dropin_translation_units(mvo, O, tmp_path, sim_as_the_library):
+    """The two drop-in translation units (feature_match_mvo.cpp, g2o_ba_mvo.cpp) behind the reference-shaped headers, driven like the
+    reference's call sites (tests/test_gpu_host_adapter.py): extraction, the three matchers, both bundle adjustments, every function
+    of the replaced headers."""
+    import test_gpu_host_adapter as T_host
+    T_host.test_cpp_dropin_matches_oracle(mvo, O, tmp_path)
+    T_host.test_every_function_of_the_replaced_headers_runs_like_the_reference(mvo, O, tmp_path)
+
+
+def test_cpp_tracking_and_keyframe_mirrors(mvo, O, tmp_path, sim_as_the_library):
+    import test_gpu_host_adapter as T_host
+    T_host.test_cpp_tracking_mirror_matches_oracle(mvo, O, tmp_path)
+    T_host.test_cpp_keyframe_mirror_matches_oracle(mvo, O, tmp_path)
+
+
+def test_tracking_loop_and_headless_run_vo(mvo, O, tmp_path, sim_as_the_library):
+    """The frame loop of the C++ mirror on a synthetic sequence and the headless run_vo on PNG frames, stage by stage against the
+    oracle chain (tests/test_gpu_host_adapter.py, tests/test_gpu_run_vo.py) -- extraction to bundle adjustment in one process."""
+    import test_gpu_host_adapter as T_host
+    import test_gpu_run_vo as T_vo
+    T_host.test_cpp_tracking_loop_follows_the_ground_truth(mvo, tmp_path)
+    T_vo.test_run_vo_equals_the_oracle_chain(mvo, O, tmp_path)
