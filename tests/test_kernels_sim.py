@@ -186,3 +186,17 @@ def test_tracking_loop_and_headless_run_vo(mvo, O, tmp_path, sim_as_the_library)
     import test_gpu_run_vo as T_vo
     T_host.test_cpp_tracking_loop_follows_the_ground_truth(mvo, tmp_path)
     T_vo.test_run_vo_equals_the_oracle_chain(mvo, O, tmp_path)
+
+
+@pytest.mark.parametrize("order", ["reverse", "shuffle"])
+def test_results_do_not_depend_on_the_thread_order(simmvo, O, simctx, order, monkeypatch):
+    """A missing barrier or wave hand-off shows as a result that depends on the order in which the emulated threads of a workgroup
+    run between two rendez-vous points: extraction (both descriptor forms), both matchers, the PnP hypotheses."""
+    monkeypatch.setenv("EMU_ORDER", order)
+    T_orb.test_keypoints_and_descriptors_bit_exact(simmvo, O, simctx, 333, 251, 1)
+    T_orb.test_both_candidate_orderings_bit_exact(simmvo, O, 333, 251)
+    for mfma in (1, 0):
+        T_match.test_knn2_bit_exact(simmvo, O, simctx, "ties", 300, 700, mfma)
+    T_track.test_map_points_in_view_bit_exact(simmvo, O, simctx, 6, 1025)
+    T_track.test_all_hypotheses_bit_exact(simmvo, O, simctx)
+    T_kf.test_find_essential_inliers_matches_the_oracle(simmvo, O, simctx, 500, 8, {})
