@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One rank per GPU.  Every rank owns `--streams` independent sequence shards (S640, seed 1234 + shard id), each
+One rank per GPU: started WITHOUT a launcher (no WORLD_SIZE in the environment) and --gpus N > 1, the script starts the N ranks
+itself (spawn_ranks: torch.distributed.run on 127.0.0.1 with a free port) and relays rank 0's JSON line.  Every rank owns `--streams` independent sequence shards (S640, seed 1234 + shard id), each
 driven by its own host thread through the native frame loop (host/driver/frame_loop.cpp): the path is serial inside
 a sequence and embarrassingly parallel across sequences, so this is how one GPU is filled.  A "step" =
 `--frames-per-step` (default 10) consecutive frames of every shard of the rank (one batch of synthetic input: 240 frames
@@ -75,6 +76,7 @@ def parse(argv=None):
                          "vo_addFrame.cpp:93-118) on every N-th frame")
     ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed loop's outputs (the `parity` object)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-sequence and resident-window runs")
     ap.add_argument("--cpu-frames", type=int, default=150)
     ap.add_argument("--cpu-threads", type=int, default=-1,
@@ -125,6 +127,10 @@ def frame_loop_lib():
         lib.frame_loop_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.frame_loop_get_state.argtypes = [C.c_void_p, C.POINTER(FrameLoopState)]
         lib.frame_loop_destroy.argtypes = [C.c_void_p]
+        lib.frame_loop_export_window.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8
+        lib.frame_loop_capture.argtypes = [C.c_void_p, C.c_int]
+        lib.frame_loop_capture.restype = None
+        lib.frame_loop_get_capture.argtypes = [C.c_void_p] + [C.c_void_p] * 6
         _frame_loop = lib
     return _frame_loop
 
@@ -231,6 +237,33 @@ class Shard:
             raise RuntimeError("frame loop failed (%d): %s | %s" % (r, self.ctx.last_error(), self.ctx_ba.last_error()))
         self.traj.extend(list(out))
 
+    def export_window(self, k):
+        """Window k of the pool as the loop hands it to the solver (restored, marshalled from the Frame / MapPoint objects,
+        flattened: host/driver/frame_loop.cpp:frame_loop_export_window) -> (poses, points, edge_pose, edge_point, edge_uv) and
+        (poses_now, points_now): the state the window's objects were in BEFORE this call restored them (for the window of the
+        last frame of a run: what its solve wrote back), in the same flat order."""
+        pb = self.pool[k]
+        F, L, cap = len(pb["poses0"]), len(pb["points0"]), len(pb["edge_pose"])
+        poses, pts, poses_now, pts_now = np.zeros((F, 4, 4)), np.zeros((L, 3)), np.zeros((F, 4, 4)), np.zeros((L, 3))
+        ep, el, uv = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros((cap, 2))
+        fle = np.zeros(3, np.int32)
+        r = frame_loop_lib().frame_loop_export_window(self.loop, k, cap, *[x.ctypes.data_as(C.c_void_p)
+                                                                          for x in (poses, pts, ep, el, uv, fle, poses_now, pts_now)])
+        if r != 0:
+            raise RuntimeError("frame_loop_export_window failed (%d)" % r)
+        return (poses[:fle[0]], pts[:fle[1]], ep[:fle[2]], el[:fle[2]], uv[:fle[2]]), (poses_now[:fle[0]], pts_now[:fle[1]])
+
+    def captured_frame(self):
+        """Keypoints, descriptors and matches of the last frame extracted while frame_loop_capture was on."""
+        lib = frame_loop_lib()
+        fn, n, nm = C.c_int32(-1), C.c_int32(0), C.c_int32(0)
+        lib.frame_loop_get_capture(self.loop, C.byref(fn), C.byref(n), C.byref(nm), None, None, None)
+        kps = np.zeros(max(n.value, 1), self.mvo.KEYPOINT_DTYPE)
+        desc = np.zeros((max(n.value, 1), 32), np.uint8)
+        m = np.zeros(max(nm.value, 1), self.mvo.DMATCH_DTYPE)
+        lib.frame_loop_get_capture(self.loop, C.byref(fn), C.byref(n), C.byref(nm), *[x.ctypes.data_as(C.c_void_p) for x in (kps, desc, m)])
+        return fn.value, kps[:n.value], desc[:n.value], m[:nm.value]
+
     def close(self):
         frame_loop_lib().frame_loop_destroy(self.loop)
         self.loop = None
@@ -314,6 +347,8 @@ def algorithmic_work(args):
         "k_pyramid": ("hbm", w * h * 3 + P),                           # BGR in, every level out (frames excluded)
         "k_fast_harris": ("hbm", P + (81 + 749) * 8000 + 16 * 8000),   # levels in, Harris/IC windows in, records out
         "k_brief": ("hbm", (45 * 56 + 32 + 16) * K),                   # raw window in, descriptor out
+        "k_blur": ("hbm", 2 * P),                                      # every level in, its blurred copy out (throughput mode)
+        "k_brief_sample": ("hbm", (512 + 32 + 16) * K),                # 512 taps of the blurred level in, descriptor out
         "k_knn2": ("valu", 16.0 * K * K),
     }
 
@@ -456,7 +491,9 @@ class GpuEnv:
         # on an interrupt instead of spinning when its threads outnumber its CPUs.  Measured for ONE rank confined like a rank of
         # an 8-GPU node (32 of 256 CPUs, tools/gpu_r04_s.sh): block 5029, yield 4955, spin 4904 frames/s vs 5054 unconfined; the
         # N > 1 run itself is the driver's; the control flow is exercised on CPU by tests/test_distributed_gloo.py
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        # (no LOCAL_WORLD_SIZE -- a launcher that does not say how many ranks share this host: no confinement rather than a
+        # slice of 1/WORLD_SIZE of the CPUs on a multi-node job)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
         self.cpus = confine_rank_to_its_cpus(self.local, local_world, host_numa_maps(local_world) if local_world > 1 else (None, None))
         torch.cuda.set_device(self.local)
         self.device = "cuda"
@@ -519,16 +556,60 @@ def run_benchmark(args, env):
                 launch=launch, st_before=st_before, st_after=st_after, traj_all=traj_all)
 
 
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, torch.distributed.run on this node,
+    rendezvous on 127.0.0.1 at a free port), pass the command line through, relay rank 0's JSON line and return it parsed.
+    MVO_BENCH_RANK_SCRIPT names the script the ranks run (default: this file; tests/ substitute a CPU stand-in that calls
+    bench.main with a gloo environment)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = os.environ.get("MVO_BENCH_RANK_SCRIPT", os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    result = None
+    for line in proc.stdout.splitlines():
+        if line.startswith("{") and '"metric"' in line:
+            result = json.loads(line)
+            print(line)
+        elif line.strip():
+            print(line, file=sys.stderr)
+    if proc.returncode != 0 or result is None:
+        raise SystemExit("bench.py: the %d-rank run failed (exit code %d)" % (args.gpus, proc.returncode))
+    return result
+
+
+def contract_line(args, R):
+    """The fields of the driver's contract that do not need a device to fill in."""
+    return {"metric": METRIC, "value": R["value"], "unit": "frames/s", "n_gpus": R["world"], "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": R["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (extract/match) + f64 (BA)", "data": "synthetic"}
+
+
 def main(argv=None, env=None):
     args = parse(argv)
+    if env is None and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
     env = env or GpuEnv(args)
     R = run_benchmark(args, env)
     world, rank, dist, shards, pipeline = R["world"], R["rank"], R["dist"], R["shards"], R["pipeline"]
     elapsed, value, launch, st_before, st_after = R["elapsed"], R["value"], R["launch"], R["st_before"], R["st_after"]
     s0 = shards[0]
+    if world != args.gpus and rank == 0:
+        print("[bench] --gpus %d but the launcher started %d rank(s): n_gpus reports the ranks that ran" % (args.gpus, world), file=sys.stderr)
 
     result = None
-    if rank == 0:
+    if rank == 0 and getattr(env, "minimal_report", False):      # CPU stand-in environments (tests/): the contract fields only
+        result = contract_line(args, R)
+        print(json.dumps(result))
+    elif rank == 0:
+        # ---- parity of what the timed loop produced (oracle = the checker; outside the timing)
+        parity = None if args.no_parity else parity_check(args, shards, R["nframes"])
         trials = sum(a.ba_trials - b.ba_trials for a, b in zip(st_after, st_before))
         solves = sum(a.ba_solves - b.ba_solves for a, b in zip(st_after, st_before))
         edges = sum(a.ba_edges - b.ba_edges for a, b in zip(st_after, st_before))
@@ -608,8 +689,10 @@ def main(argv=None, env=None):
             s_.ctx.synchronize()
         time.sleep(0.02)
         env.sync()
+        # The shard runs in the MODE of the headline shards (THROUGHPUT with > 8 sequences: candidates interleaved by the host,
+        # descriptors from k_blur + k_brief_sample), so `kernels` lists the kernels the headline number launched.
         kshard = env.make_shard(shard_ids(rank, args.streams)[0], args, "none", False,
-                                frames=(s0.host_frames, s0.dev_frames), pool=s0.pool, ba_cut="latency")
+                                frames=(s0.host_frames, s0.dev_frames), pool=s0.pool, ba_cut=s0.ba_cut)
         kshard.run(3)
         kshard.ctx.profile_enable(True)
         kshard.ctx.profile_reset()
@@ -714,12 +797,15 @@ def main(argv=None, env=None):
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (extract/match) + f64 (BA)", "data": "synthetic",
-            "config": {"workload": "S%d: %dx%d BGR frames resident in HBM, <=%d kp (ORB 8000 -> grid), 2-NN Hamming + "
+            "config": {"workload": "S%d: %dx%d BGR frames resident in HBM (every shard cycles %d pre-rendered frames of its own "
+                                   "sequence, rendered from a 1024x1024 texture; SURVEY 8d plans 150 frames from 2048x2048), <=%d kp "
+                                   "(ORB 8000 -> grid), 2-NN Hamming + "
                                    "Lowe 0.8 + de-dup vs previous frame, BA%d %s with the BA window rebuilt per frame "
-                                   "(%d distinct windows per shard rotated; marshalled from Frame/MapPoint objects like "
+                                   "(%d distinct SYNTHETIC windows per shard rotated -- SURVEY 8d config 3 generator, independent of "
+                                   "the extracted frames; secondary.chained_fps is the loop whose windows come from PnP inliers --; marshalled from Frame/MapPoint objects like "
                                    "vo.cpp:408-449, flattened, uploaded, solved, written back: %d poses / %d landmarks / "
                                    "~%d edges, 50 LM iterations)"
-                                   % (args.width, args.width, args.height, args.max_kp + 1, args.ba_poses, args.ba,
+                                   % (args.width, args.width, args.height, args.frames, args.max_kp + 1, args.ba_poses, args.ba,
                                       len(s0.pool), args.ba_poses, args.ba_points, int(E_avg))
                        if args.ba_mode == "rebuild" else "S%d extract+match, BA mode %s" % (args.width, args.ba_mode),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world * max(1, args.frames_per_step),
@@ -727,6 +813,8 @@ def main(argv=None, env=None):
                                % (max(1, args.frames_per_step), args.streams * world, args.streams * world * R["nframes"]),
                        "frame_loop": "native (host/driver/frame_loop.cpp)" + (", extraction of frame i+1 overlapped with BA of frame i (a ctx + its sibling per sequence, THROUGHPUT mode when > 8 sequences)" if pipeline else ""),
                        "keypoints": st.n_kp, "matches": st.n_match,
+                       # (copy of the top-level `parity` object's verdicts: what the timed loop produced, held to the oracle)
+                       "parity": parity and {k: parity.get(k) for k in ("ba", "ba_windows_checked", "ba_workgroups_per_window", "orb", "match")},
                        "ba_trials_per_solve": trials / max(solves, 1),
                        "tracking_rows": ("map in view (3000 pts) + match vs map + solvePnPRansac (%d pairs, %d inliers) every "
                                          "frame; keyframe row (findEssentialMat filter on 1000 matches + triangulation + "
@@ -734,6 +822,7 @@ def main(argv=None, env=None):
                                          % (len(s0.track["pts3d"]), st.n_inliers, st.n_tri, args.keyframe_every))
                        if args.track else "off"},
             "roofline": roof,
+            "parity": parity,
             "cpu_baseline": cpu,
             "cpu_baseline_all_threads": cpu_mt,
             "secondary": secondary,
@@ -747,6 +836,65 @@ def main(argv=None, env=None):
         dist.barrier()
         dist.destroy_process_group()
     return result
+
+
+def traj_row(T):
+    """4 x 4 cam->world pose -> the 12 numbers of a trajectory row (x y z, then R column by column: vo_io.cpp:58-75)."""
+    return np.concatenate([T[:3, 3], T[:3, :3].T.reshape(-1)])
+
+
+def parity_check(args, shards, nframes, max_windows=32):
+    """Holds the outputs of the TIMED loop to the oracle (test infrastructure, outside the timing, like cpu_baseline):
+    * BA: for every shard, the window of its last timed frame -- exported as the loop marshalled it -- is solved by the blocked
+      oracle with the summation plan that solve ran with (mvo_debug_get_ba_plan of the shard's BA context: the cut and kernel
+      flavour the headline number used); the trajectory row the timed loop wrote, all poses and the landmarks it scattered back
+      into the MapPoint objects (f32) must equal the oracle's bit for bit (g2o_ba.cpp:193-289, 298-316);
+    * ORB + matching: shard 0 advances two more frames with capture on; the keypoints, descriptors and matches its loop held
+      are compared with the oracle's on the same two images (feature_match.cpp:11-49, 126-260)."""
+    O = graft.load_oracle()
+    out = {"checked_by": "oracle/ (blocked BA oracle with the device's summation plan; ORB / matcher oracle)"}
+    if args.ba_mode == "rebuild" and not args.track:
+        bad, cuts, n_checked = [], set(), 0
+        fix = args.ba == "pose_only"
+        for s in shards[:max_windows]:
+            k = (s.state().frame_no - 1) % len(s.pool)
+            plan = s.ctx_ba.ba_plan()
+            (P0, X0, ep, el, uv), (P_now, X_now) = s.export_window(k)
+            pb = s.pool[k]
+            Po, Xo, sto, _ = O.bundle_adjustment_blocked(P0, X0, ep, el, uv, pb["focal"], pb["cx"], pb["cy"], plan=plan, fix_points=fix)
+            row = np.asarray(s.traj[-1])
+            ok = (np.array_equal(row, traj_row(Po[0])) and np.array_equal(P_now, Po)
+                  and (fix or np.array_equal(X_now.astype(np.float32), Xo.astype(np.float32))))
+            n_checked += 1
+            cuts.add(int(plan["wgs"]))
+            if not ok:
+                bad.append(dict(shard=s.id, window=k, max_pose_diff=float(np.abs(P_now - Po).max()), trials_oracle=sto["trials"]))
+        out["ba"] = "bit-exact" if not bad else "MISMATCH"
+        out["ba_windows_checked"] = n_checked
+        out["ba_workgroups_per_window"] = sorted(cuts)
+        out["ba_note"] = ("last timed frame of every shard: trajectory row, all %d poses and the landmarks written back (f32) vs "
+                          "oracle/ba_blocked_oracle.cpp with the plan of that solve" % args.ba_poses)
+        if bad:
+            out["ba_mismatches"] = bad[:4]
+    s0 = shards[0]
+    lib = frame_loop_lib()
+    lib.frame_loop_capture(s0.loop, 1)
+    s0.run(2)
+    lib.frame_loop_capture(s0.loop, 0)
+    fn, kps, desc, m = s0.captured_frame()
+    p = O.default_params(max_keypoints=args.max_kp)
+    feats = []
+    for f in (fn - 1, fn):
+        img = s0.host_frames[f % len(s0.host_frames)]
+        ko = O.calc_keypoints(img, p)
+        feats.append(O.calc_descriptors(img, ko, p))
+    mo = O.match_features(feats[0][1], feats[1][1], 2, 2.0, 0.8)
+    ko, do = feats[1]
+    out["orb"] = "bit-exact" if (len(kps) == len(ko) and kps.tobytes() == ko.tobytes() and np.array_equal(desc, do)) else "MISMATCH"
+    out["match"] = "bit-exact" if m.tobytes() == mo.tobytes() else "MISMATCH"
+    out["orb_match_note"] = ("frame %d of shard %d as its loop extracted and matched it (%d keypoints, %d matches) vs oracle/orb_oracle.cpp, "
+                             "oracle/match_oracle.cpp on the same images" % (fn, s0.id, len(kps), len(m)))
+    return out
 
 
 def cpu_baseline(args, shard):

@@ -73,6 +73,7 @@ int mvo_synchronize(mvo_ctx* ctx);
  * there are enough cores), 1 spin, 2 yield, 3 block on an interrupt.  A process whose waiting threads outnumber its CPUs
  * (one rank of a multi-GPU node confined to its share of the cores, 24 sequence threads each) should yield or block.  No
  * reference counterpart (OpenCV / g2o do not wait for a device). */
+/* (The calling thread's current HIP device is left as it was.) */
 #define MVO_WAIT_AUTO 0
 #define MVO_WAIT_SPIN 1
 #define MVO_WAIT_YIELD 2
@@ -171,7 +172,7 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * workgroup (the 5-keyframe window of the benchmark: 28 CUs of one XCD, shortest solve) and solved by a launch of its own;
  * the detection kernel also puts its candidates in order on the device.
  * THROUGHPUT: many sequences are in flight on this GPU -- CU time counts, not latency.  While the offered load keeps it
- * busy (64 submissions in a row at a rate x solve time of >= 8 of its 16 slots; it leaves after 80 ms below 5), 5-keyframe windows are cut into ~720 observations
+ * busy (128 submissions in a row at a rate x solve time of >= 8 of its 16 slots; it leaves after 80 ms below 7), 5-keyframe windows are cut into ~720 observations
  * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
  * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
@@ -189,6 +190,33 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
 #define MVO_BA_MODE_THROUGHPUT 1
 #define MVO_BA_MODE_SHARED 2
 int mvo_ba_set_mode(mvo_ctx* ctx, int mode);
+/* Admission gate of the extraction / matching kernels (no reference counterpart).  Contexts in THROUGHPUT or SHARED mode pass a
+ * process-wide, per-device counting gate around every launch-and-wait section of mvo_calc_keypoints*, mvo_calc_descriptors* and
+ * the matchers: at most `n` such sections are in flight on a device at once (default 8; 0 = no limit).  With 24-32 sequences
+ * next to the resident solver grid the frames' kernels share the few CUs the grid leaves; more than ~8 frames interleaving
+ * there LOWER their combined throughput (14 in flight: 3400 frames/s of extraction, 8-9: 4600; values 4...12 are within 4 % of
+ * each other).  LATENCY-mode contexts never wait at the gate.  Returns the previous value. */
+int mvo_set_extract_concurrency(int n);
+
+/* ---- operating knobs, in one place -------------------------------------------------------------------------------------
+ * What a caller chooses (API):
+ *   mvo_ba_set_mode(ctx, LATENCY | THROUGHPUT | SHARED)   how this ctx shares the GPU (above)
+ *   mvo_set_extract_concurrency(n)                        admission gate of the frame kernels (above)
+ *   mvo_set_wait_policy(device, AUTO|SPIN|YIELD|BLOCK)    how host threads wait for the device
+ *   mvo_orb_params.pyramid_interpolation                  which OpenCV resampling the pyramid restates
+ * Environment variables, read once at start-up -- defaults in [] -- for A/B measurements and development; results never
+ * depend on them except through the summation plan of a BA window, which mvo_debug_get_ba_plan always reports:
+ *   MVO_EXTRACT_CONCURRENCY [8]   start-up value of mvo_set_extract_concurrency
+ *   MVO_BA_SERVICE [1]            resident solver service: 0 never, 1 by offered load (mvo_ba_set_mode), 2 always
+ *   MVO_BA_XCD_RESERVE [4]        CUs per XCD a BA window leaves to other kernels (THROUGHPUT adds 2: 2 x 13 workgroups per XCD)
+ *   MVO_BA_WGS, MVO_BA_NSPLIT     force the workgroups / Schur column pieces of a window (= the debug keys ba_wgs, ...)
+ *   MVO_BA_CU_SHARE [all]         CUs one launch-path grid may take
+ *   MVO_BA_GROUPS [1], MVO_BA_ALIAS_SL [1], MVO_BA_BLOCK_SOLVER [0]   A/B switches of DESIGN.md 4.3 (grouped Schur exchange,
+ *                                 reduced system inside the U area, block LDL^T for the 5-pose class)
+ *   MVO_BRIEF_LEVEL_BLUR [by mode] 1 = descriptors from whole blurred levels (k_blur + k_brief_sample), 0 = per-keypoint windows
+ *   MVO_BRIEF_WAVES [4], MVO_MATCH_SLICE [256], MVO_PYR_FULL_POOL [0], MVO_PNP_OCC [by mode]   kernel shape A/Bs
+ *   MVO_BA_PLAN_TRACE, MVO_HOST_TIMING   development output on stderr
+ * mvo_debug_set(key, value) (bottom of this file) sets the same switches at run time for the tests. */
 
 /* The same call in two halves, so that the host thread can do other work (e.g. extract the next frame on another
  * ctx) while the window is being solved: _begin builds the window, uploads it and queues the launch, _end blocks

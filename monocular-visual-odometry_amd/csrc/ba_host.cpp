@@ -47,12 +47,13 @@ int g_ba_uv_global = 1;     // 0 = measurements always in LDS (the form before t
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 int g_ba_groups = std::getenv("MVO_BA_GROUPS") ? std::atoi(std::getenv("MVO_BA_GROUPS")) : 1;  // 0 = one flat Schur exchange whatever the window's size (A/B)
+int g_ba_one_hop = std::getenv("MVO_BA_ONE_HOP") ? std::atoi(std::getenv("MVO_BA_ONE_HOP")) : 1;  // 0 = slice owners + republished sums also for windows of one XCD (the form up to round 4; A/B)
 int g_ba_alias_sl = std::getenv("MVO_BA_ALIAS_SL") ? std::atoi(std::getenv("MVO_BA_ALIAS_SL")) : 1;  // 0 = the reduced system always has LDS of its own (A/B)
 
 // The demand estimate of the resident solver service (a plain state machine over submission times, so that it can be
 // replayed by the tests: mvo_debug_ba_demand_replay).
 struct BaDemand {
-    double t[64] = {0}, flip = -1e9, low_since = -1, last = 0, rate_avg = 0;  // rate_avg: submissions / s, exponentially averaged
+    double t[128] = {0}, flip = -1e9, low_since = -1, last = 0, rate_avg = 0;  // rate_avg: submissions / s, exponentially averaged
     long long n = 0, total = 0, flips = 0;
     bool on = false;
     bool submit(double now);
@@ -73,7 +74,7 @@ struct Carver {
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
         ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0, uv_global = 0,
-        alias_sl = 0, groups = 1;
+        alias_sl = 0, groups = 1, one_hop = 0;
     bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
@@ -187,7 +188,7 @@ struct BaService {
     // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
     // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
     // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
-    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: 64 submissions in a row
+    // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: 128 submissions in a row
     // at a rate that fills 10 slots; going: the 40-ms average below 8 slots for 80 ms in a row (BaService::wanted).
     std::mutex m_demand;
     BaDemand demand;
@@ -253,9 +254,11 @@ void BaService::run() {
                 if (!flights.empty()) {  // (launch-path grids and the resident grid never share the device)
                     cv_flight.wait(lk, [&] { return flights.empty(); });
                 }
-                if (!resident && free_gate > 0) cv_work.wait(lk, [&] { return free_gate == 0; });
                 // (a window planned for more workgroups per slot than the grid on the device has: the grid is relaunched)
                 if (resident && q.front()->ws->plan.G > wgs_launched) stop_resident(lk);
+                // frees in progress keep the grid off the device.  Checked AFTER the stop above (stop_resident drops the mutex
+                // while it waits for the grid: a free may have begun meanwhile) and again after every wake-up.
+                while (!resident && free_gate > 0) cv_work.wait(lk, [&] { return free_gate == 0; });
                 if (!resident && start_resident() != 0) {
                     BaJob* j = q.front();
                     q.pop_front();
@@ -409,16 +412,18 @@ bool BaDemand::submit(double now) {
     rate_avg += 1.0 / kTau;
     last = now;
     ++total;
-    t[n++ & 63] = now;
+    t[n++ & 127] = now;
     if (!on) {
-        // coming: 64 submissions in a row at a rate that fills 8 of the 16 slots (the bursts of a slower loop never get there,
+        // coming: 128 submissions in a row at a rate that fills 8 of the 16 slots (the bursts of a slower loop never get there,
         // nor does a chance cluster of independent arrivals at half that rate).  The threshold has to lie well BELOW what the
         // launch path delivers when it is saturated (~2500 windows / s = 9.6 slots with 32 sequences in a closed loop): at 10
         // slots a run whose first steps were slow never saw the rate that would have brought the grid up, and stayed at half
-        // the throughput for good (one of three driver-command runs on the same code, round 4).
-        if (n >= 64 && now - flip > 0.02) {
-            const double span = now - t[n & 63];  // (the oldest of the 64)
-            if (63.0 / std::max(span, 1e-6) * kSolve >= 0.5 * BA_SERVICE_SLOTS) {
+        // the throughput for good (one of three driver-command runs on the same code, round 4).  128 in a row, not 64 (round 5):
+        // independent arrivals at 1500 windows / s (5.7 slots: the tracking rows in the loop) show a 64-long cluster at the
+        // 8-slot rate every second or so -- each one cost a grid start and a drain --, a 128-long one a few times a minute.
+        if (n >= 128 && now - flip > 0.02) {
+            const double span = now - t[n & 127];  // (the oldest of the 128)
+            if (127.0 / std::max(span, 1e-6) * kSolve >= 0.5 * BA_SERVICE_SLOTS) {
                 on = true;
                 flip = now;
                 low_since = -1;
@@ -426,11 +431,15 @@ bool BaDemand::submit(double now) {
                 ++flips;
             }
         }
-    } else if (load_avg > 0.3125 * BA_SERVICE_SLOTS) {
+    } else if (load_avg > 0.4375 * BA_SERVICE_SLOTS) {
         low_since = -1;
     } else {
-        // going: the average below 5 of the 16 slots for 80 ms in a row (the last steps of a run -- callers finishing one after
-        // the other -- and the first ones after a pause look like low demand for a few milliseconds)
+        // going: the average below 7 of the 16 slots for 80 ms in a row (the last steps of a run -- callers finishing one after
+        // the other -- and the first ones after a pause look like low demand for a few milliseconds).  With the grid ON a loop
+        // that waits for the solver offers far more than that (the grid delivers ~5000 windows/s = 19 slots' worth of
+        // submissions); callers that offer less than 7 with the grid on are bound elsewhere (tracking rows in the loop: ~1500
+        // windows/s = 5.7 slots, 1800 frames/s with the grid vs 2470 without) and a chance cluster of their arrivals that
+        // brought the grid up must not keep it (round 4 left at 5: above which such a load stayed on for good).
         if (low_since < 0) low_since = now;
         if (now - low_since > 0.08) {
             on = false;
@@ -522,10 +531,13 @@ void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;  // (a slot that never answers: give up waiting)
         }
     }
+    // still outstanding after the bail-out: their clients must not wait for ever -- but they get their (failed) jobs back only
+    // once the grid has left the device: until then it may still be writing into their workspaces
+    BaJob* stuck[BA_SERVICE_SLOTS];
+    int nstuck = 0;
     for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl)
-        if (BaJob* j = slot_job[sl]) {  // still outstanding after the bail-out: its client must not wait for ever
-            j->err = hipErrorUnknown;
-            j->done = true;
+        if (BaJob* j = slot_job[sl]) {
+            stuck[nstuck++] = j;
             slot_job[sl] = nullptr;
             --slots_busy;
         }
@@ -533,6 +545,10 @@ void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
     lk.unlock();
     (void)hipStreamSynchronize(resident_stream);
     lk.lock();
+    for (int i = 0; i < nstuck; ++i) {
+        stuck[i]->err = hipErrorUnknown;
+        stuck[i]->done = true;
+    }
     resident = false;
     cv_done.notify_all();
 }
@@ -916,6 +932,11 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         if (G % K == 0 && G / K <= 32 && uarea >= (size_t)K * (size_t)(nlow + nhp)) P.groups = K;
     }
     P.slice = (nlow + G / P.groups - 1) / (G / P.groups);
+    // Windows of one group (<= 32 workgroups: one XCD): every workgroup reads the G partials straight from the L2 and adds them in
+    // range order itself -- ONE far-memory hop per trial instead of two (slice sum -> republish -> gather).  Same order of the
+    // additions, hence the same bits; the partials alternate between two buffers (a trial that ends at the failed factorisation has
+    // no all-to-all behind it: a workgroup may publish the next trial's partials while a slower one still reads this trial's).
+    P.one_hop = (G > 1 && P.groups == 1 && g_ba_one_hop) ? 1 : 0;
     // ---- edges sorted by (owner workgroup, pose); adjacency tables
     std::vector<int>&e_pose = SC.e_pose, &e_point = SC.e_point, &ptstart = SC.ptstart, &ptlist = SC.ptlist;
     std::vector<double>& e_uv = SC.e_uv;
@@ -984,7 +1005,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // left them -- memory that only ever held granules, matched by tag.  When their layout does change they are cleared
     // (below): bytes that once held ordinary data must never be taken for a published value.
     Carver cv;
-    P.o_xp = cv.take((size_t)G * npk * 16);
+    P.o_xp = cv.take((size_t)G * npk * 16 * (P.one_hop ? 2 : 1));
     P.o_xr = cv.take((size_t)npk * 16 * (P.groups > 1 ? 2 * P.groups : 1));
     P.o_xh = cv.take((size_t)G * nhp * 16);
     P.o_xc = cv.take((size_t)2 * G * 4 * 8);
@@ -1077,6 +1098,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.uv_global = P.uv_global;
     B.alias_sl = P.alias_sl;
     B.groups = P.groups;
+    B.one_hop = P.one_hop;
     B.uv_dev = (double*)(D + P.o_uvd);
     B.npt = P.npt;
     B.panel = P.panel;

@@ -122,14 +122,24 @@ int mvo_set_wait_policy(int device, int policy) {
     if (policy < MVO_WAIT_AUTO || policy > MVO_WAIT_BLOCK) return MVO_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MVO_ERR_NO_DEVICE;
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     if (hipSetDevice(device) != hipSuccess) return MVO_ERR_NO_DEVICE;
     static const unsigned flags[4] = {hipDeviceScheduleAuto, hipDeviceScheduleSpin, hipDeviceScheduleYield, hipDeviceScheduleBlockingSync};
     const hipError_t e = hipSetDeviceFlags(flags[policy]);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);  // (the flags belong to `device`; the caller's current device is not ours to change)
     if (e != hipSuccess) {
         (void)hipGetLastError();
         return MVO_ERR_HIP;
     }
     return MVO_OK;
+}
+
+int mvo_set_extract_concurrency(int n) {
+    const int prev = g_extract_concurrency;
+    g_extract_concurrency = n < 0 ? 0 : n;
+    for (int d = 0; d < 16; ++d) g_gates[d].cv.notify_all();  // (a raised limit lets waiting sections in)
+    return prev;
 }
 
 int mvo_create_sibling(mvo_ctx* parent, mvo_ctx** out) {

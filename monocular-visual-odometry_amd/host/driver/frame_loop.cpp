@@ -108,6 +108,13 @@ struct Loop {
     optimization::BundleAdjustmentJob job;
     vo::BaWindow pending;  // pointer lists of the solve in flight (must outlive it)
     Window* pending_w = nullptr;
+    // parity capture (frame_loop_capture): keypoints, descriptors and matches of the last extracted frame, copied out of the
+    // buffers the loop works on -- what bench.py hands to the oracle after the timed region
+    bool capture = false;
+    int cap_frame = -1, cap_n = 0, cap_nm = 0;
+    std::vector<mvo_keypoint> cap_kps;
+    std::vector<uint8_t> cap_desc;
+    std::vector<mvo_dmatch> cap_matches;
 };
 
 void restore(Window& w) {
@@ -135,13 +142,21 @@ int extract_and_match(Loop& L, int frame_no, const void** d_desc, int* n_out, in
                                            (int)L.kps.size(), &n))) {
         return r;
     }
-    if ((r = mvo_calc_descriptors_dev(c.ctx, L.kps.data(), &n, nullptr, d_desc))) return r;
+    if (L.capture) L.cap_desc.resize(32 * L.kps.size());
+    if ((r = mvo_calc_descriptors_dev(c.ctx, L.kps.data(), &n, L.capture ? L.cap_desc.data() : nullptr, d_desc))) return r;
     *n_match = 0;
     if (L.prev_desc && n && L.prev_n) {
         int nm = 0;
         if ((r = mvo_match_features_dev(c.ctx, L.prev_desc, L.prev_n, *d_desc, n, 2, 2.0, 0.8, L.matches.data(), (int)L.matches.size(), &nm)))
             return r;
         *n_match = nm;
+    }
+    if (L.capture) {
+        L.cap_frame = frame_no;
+        L.cap_n = n;
+        L.cap_nm = *n_match;
+        L.cap_kps.assign(L.kps.begin(), L.kps.begin() + n);
+        L.cap_matches.assign(L.matches.begin(), L.matches.begin() + *n_match);
     }
     L.prev_desc = *d_desc;
     L.prev_n = n;
@@ -426,6 +441,58 @@ int frame_loop_run(void* h, int steps, double* traj) {
 }
 
 void frame_loop_get_state(void* h, frame_loop_state* out) { *out = static_cast<Loop*>(h)->st; }
+
+// ---- parity hooks for bench.py (outside the timed region) ----------------------------------------------------------------
+// Window k of the pool at its initial state, marshalled and flattened exactly as frame_loop_run hands it to the solver
+// (restore -> buildBundleAdjustmentWindow -> FlatBundle::flatten: edge order = the iteration order of the frames'
+// unordered_maps, f32 storage of pixels and landmarks widened to f64): what the oracle must be given to reproduce the
+// trajectory row the timed loop wrote for a frame that used this window.  Arrays: poses F x 16, points L x 3, edges E.
+// poses_now / points_now (optional): the state the objects are in when this is called -- for the window of the last frame
+// of a run, what its solve wrote back (poses as f64, landmarks as f32: g2o_ba.cpp:298-316) -- in the same flat order.
+int frame_loop_export_window(void* h, int k, int cap_edges, double* poses, double* points, int32_t* edge_pose, int32_t* edge_point,
+                             double* edge_uv, int32_t* FLE, double* poses_now, double* points_now) {
+    Loop& L = *static_cast<Loop*>(h);
+    if (k < 0 || (size_t)k >= L.windows.size()) return MVO_ERR_INVALID;
+    Window& w = *L.windows[(size_t)k];
+    if (poses_now || points_now) {
+        vo::BaWindow now = vo::buildBundleAdjustmentWindow(w.frames_buff, w.map, w.F);
+        optimization::FlatBundle fn;
+        fn.flatten(now.v_pts_2d, now.v_pts_2d_to_3d_idx, L.K, now.um_pts_3d_in_prev_frames, now.v_camera_poses, L.info, L.c.fix_points != 0);
+        if (fn.pr.n_poses > w.F || fn.pr.n_points > w.L) return MVO_ERR_CAPACITY;
+        if (poses_now) std::memcpy(poses_now, fn.poses.data(), fn.poses.size() * sizeof(double));
+        if (points_now) std::memcpy(points_now, fn.pts.data(), fn.pts.size() * sizeof(double));
+    }
+    restore(w);
+    vo::BaWindow bw = vo::buildBundleAdjustmentWindow(w.frames_buff, w.map, w.F);
+    optimization::FlatBundle fb;
+    fb.flatten(bw.v_pts_2d, bw.v_pts_2d_to_3d_idx, L.K, bw.um_pts_3d_in_prev_frames, bw.v_camera_poses, L.info, L.c.fix_points != 0);
+    FLE[0] = fb.pr.n_poses;
+    FLE[1] = fb.pr.n_points;
+    FLE[2] = fb.pr.n_edges;
+    if (fb.pr.n_edges > cap_edges || fb.pr.n_poses > w.F || fb.pr.n_points > w.L) return MVO_ERR_CAPACITY;
+    std::memcpy(poses, fb.poses.data(), fb.poses.size() * sizeof(double));
+    std::memcpy(points, fb.pts.data(), fb.pts.size() * sizeof(double));
+    std::memcpy(edge_pose, fb.ep.data(), fb.ep.size() * sizeof(int32_t));
+    std::memcpy(edge_point, fb.el.data(), fb.el.size() * sizeof(int32_t));
+    std::memcpy(edge_uv, fb.uv.data(), fb.uv.size() * sizeof(double));
+    return MVO_OK;
+}
+
+// on != 0: every extraction from now on also copies its keypoints, descriptors (through the host output of
+// mvo_calc_descriptors_dev) and matches aside.
+void frame_loop_capture(void* h, int on) { static_cast<Loop*>(h)->capture = on != 0; }
+
+// The last captured frame: frame number (-1 = none), counts; kps / desc (n x 32) / matches are copied when non-null.
+int frame_loop_get_capture(void* h, int32_t* frame_no, int32_t* n, int32_t* nm, mvo_keypoint* kps, uint8_t* desc, mvo_dmatch* matches) {
+    Loop& L = *static_cast<Loop*>(h);
+    *frame_no = L.cap_frame;
+    *n = L.cap_n;
+    *nm = L.cap_nm;
+    if (kps) std::memcpy(kps, L.cap_kps.data(), (size_t)L.cap_n * sizeof(mvo_keypoint));
+    if (desc) std::memcpy(desc, L.cap_desc.data(), (size_t)L.cap_n * 32);
+    if (matches) std::memcpy(matches, L.cap_matches.data(), (size_t)L.cap_nm * sizeof(mvo_dmatch));
+    return MVO_OK;
+}
 
 void frame_loop_destroy(void* h) {
     Loop* L = static_cast<Loop*>(h);

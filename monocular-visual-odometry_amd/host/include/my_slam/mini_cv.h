@@ -108,6 +108,13 @@ public:
     T& at(int r, int c) { return ptr<T>(r)[c]; }
     template <class T>
     const T& at(int r, int c) const { return ptr<T>(r)[c]; }
+    // rows [r0, r1) sharing the storage (cv::Mat::rowRange)
+    Mat rowRange(int r0, int r1) const {
+        Mat m = *this;
+        m.rows = r1 - r0;
+        m.data = data ? data + (size_t)r0 * step : nullptr;
+        return m;
+    }
     Mat clone() const {
         Mat m(rows, cols, type_);
         for (int r = 0; r < rows; ++r) std::memcpy(m.ptr<uchar>(r), ptr<uchar>(r), (size_t)cols * elemSize());

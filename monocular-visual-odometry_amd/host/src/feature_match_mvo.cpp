@@ -9,6 +9,9 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
 #include <stdexcept>
 #include <unordered_map>
 
@@ -62,6 +65,17 @@ bool& reuse_pyramid_flag() { return ctx_state().reuse_pyramid; }
 // who owns the pyramid cached in the ctx: the Frame's unique id + 1 (ids are never reused, unlike addresses), 0 after
 // any direct call of the free functions
 long long& pyramid_token() { return ctx_state().pyramid_token; }
+
+// The C-ABI takes n x 32 contiguous descriptor bytes (ORB: 256 bits).  A cv::Mat may be a ROI / a row range of a wider
+// matrix (step != 32): its rows are packed into `tmp`; any other width is refused -- cv::batchDistance would take it, the
+// Hamming kernels of this path are written for cv::ORB's 32 bytes (feature_match.cpp:45-48 is the only producer).
+const uint8_t* packed_descriptors(const cv::Mat& d, std::vector<uint8_t>& tmp, const char* who) {
+    if (d.rows > 0 && d.cols != 32) throw std::runtime_error(std::string(who) + ": descriptors must be n x 32 bytes (cv::ORB)");
+    if (d.rows <= 0 || d.step == 32) return d.data;
+    tmp.resize((size_t)d.rows * 32);
+    for (int r = 0; r < d.rows; ++r) std::memcpy(tmp.data() + 32 * (size_t)r, d.ptr<unsigned char>(r), 32);
+    return tmp.data();
+}
 }  // namespace detail
 
 void calcKeyPoints(const cv::Mat& image, vector<cv::KeyPoint>& keypoints) {
@@ -88,7 +102,9 @@ void calcDescriptors(const cv::Mat& image, vector<cv::KeyPoint>& keypoints, cv::
                                    reinterpret_cast<mvo_keypoint*>(keypoints.data()), &n, descriptors.data, nullptr),
               "calcDescriptors");
     keypoints.resize(n);
-    descriptors.rows = n;
+    // cv::ORB::compute hands back exactly one row per surviving keypoint: shrink through the matrix header's own operation
+    // (rowRange keeps dataend / datalimit of a real cv::Mat consistent; writing `rows` directly does not)
+    descriptors = descriptors.rowRange(0, n);
 }
 
 void removeDuplicatedMatches(vector<cv::DMatch>& matches) {
@@ -129,9 +145,12 @@ void matchFeatures(const cv::Mat1b& descriptors_1, const cv::Mat1b& descriptors_
         }
     }
     const int n1 = descriptors_1.rows, n2 = descriptors_2.rows;
+    std::vector<uint8_t> pack1, pack2;
+    const uint8_t* d1 = detail::packed_descriptors(descriptors_1, pack1, "matchFeatures");
+    const uint8_t* d2 = detail::packed_descriptors(descriptors_2, pack2, "matchFeatures");
     matches.resize(n1 > 0 ? n1 : 1);
     int n = 0;
-    mvo_check(mvo_match_features(hot_path_ctx(), descriptors_1.data, n1, descriptors_2.data, n2, method_index,
+    mvo_check(mvo_match_features(hot_path_ctx(), d1, n1, d2, n2, method_index,
                                  xiang_gao_method_match_ratio, lowe_method_dist_ratio, xy1.data(), xy2.data(),
                                  max_matching_pixel_dist, reinterpret_cast<mvo_dmatch*>(matches.data()),
                                  (int)matches.size(), &n),
@@ -163,7 +182,10 @@ vector<cv::DMatch> matchByRadiusAndBruteForce(const vector<cv::KeyPoint>& keypoi
         xy2.push_back(k.pt.y);
     }
     vector<int32_t> idx((size_t)(N1 > 0 ? N1 : 1)), sum((size_t)(N1 > 0 ? N1 : 1));
-    mvo_check(mvo_match_radius_l1(hot_path_ctx(), descriptors_1.data, xy1.data(), N1, descriptors_2.data, xy2.data(), N2,
+    std::vector<uint8_t> pack1, pack2;
+    const uint8_t* d1 = detail::packed_descriptors(descriptors_1, pack1, "matchByRadiusAndBruteForce");
+    const uint8_t* d2 = detail::packed_descriptors(descriptors_2, pack2, "matchByRadiusAndBruteForce");
+    mvo_check(mvo_match_radius_l1(hot_path_ctx(), d1, xy1.data(), N1, d2, xy2.data(), N2,
                                   max_matching_pixel_dist, idx.data(), sum.data()),
               "matchByRadiusAndBruteForce");
     vector<cv::DMatch> matches;

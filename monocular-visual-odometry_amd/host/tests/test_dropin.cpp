@@ -95,6 +95,33 @@ int main(int argc, char** argv) {
             threw = true;
         }
         if (!threw) return 4;
+        // descriptors handed over as a ROI of a wider matrix (step 40 != 32: not continuous) must match like their packed copy;
+        // a width other than cv::ORB's 32 bytes is refused, not silently misread
+        {
+            const int n0 = f0->descriptors_.rows, n1 = f1->descriptors_.rows;
+            vector<unsigned char> wide0((size_t)n0 * 40 + 40, 0xAB), wide1((size_t)n1 * 40 + 40, 0xCD);
+            for (int r = 0; r < n0; ++r) memcpy(&wide0[(size_t)r * 40], f0->descriptors_.ptr<unsigned char>(r), 32);
+            for (int r = 0; r < n1; ++r) memcpy(&wide1[(size_t)r * 40], f1->descriptors_.ptr<unsigned char>(r), 32);
+            cv::Mat roi0(n0, 32, CV_8UC1, wide0.data(), 40), roi1(n1, 32, CV_8UC1, wide1.data(), 40);
+            for (int method = 1; method <= 3; ++method) {
+                vector<cv::DMatch> a, b;
+                geometry::matchFeatures(f0->descriptors_, f1->descriptors_, a, method, false, f0->keypoints_, f1->keypoints_, 50.f);
+                geometry::matchFeatures(roi0, roi1, b, method, false, f0->keypoints_, f1->keypoints_, 50.f);
+                if (a.size() != b.size() || a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(cv::DMatch))) {
+                    fprintf(stderr, "method %d: ROI descriptors give %zu matches, packed ones %zu\n", method, b.size(), a.size());
+                    return 8;
+                }
+            }
+            cv::Mat wrong(n0, 40, CV_8UC1, wide0.data(), 40);
+            threw = false;
+            try {
+                vector<cv::DMatch> m;
+                geometry::matchFeatures(wrong, roi1, m, 2);
+            } catch (const std::runtime_error&) {
+                threw = true;
+            }
+            if (!threw) return 9;
+        }
 
         // ---- vo.cpp:384-462: a 3-frame window, pointers into Frame / MapPoint storage
         const double fx = 517.3, cx = 325.1, cy = 249.7;

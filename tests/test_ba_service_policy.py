@@ -34,11 +34,11 @@ def test_saturating_load_brings_the_grid_up_within_two_steps_and_keeps_it(mvo):
     # 24 sequences, one window each per 7-ms step = 3400 windows/s = 13 slots
     on, flips = _replay(mvo, _bursts(0.007, 24, 60))
     first = int(np.argmax(on))
-    assert flips == 1 and on[-1] and first < 4 * 24 and on[first:].all()
+    assert flips == 1 and on[-1] and first < 6 * 24 and on[first:].all()        # (128 submissions in a row at that rate)
     # the same rate without the lock step of the sequences
     t = np.sort(np.random.RandomState(1).uniform(0, 0.42, 1440))
     on, flips = _replay(mvo, t)
-    assert flips == 1 and on[-1] and t[int(np.argmax(on))] < 0.03
+    assert flips == 1 and on[-1] and t[int(np.argmax(on))] < 0.05
 
 
 def test_partial_load_stays_on_the_launch_path(mvo):
@@ -48,13 +48,20 @@ def test_partial_load_stays_on_the_launch_path(mvo):
     # independent arrivals at half the rate that brings the grid up (8 of 16 slots = 2100 windows/s): no chance cluster does
     on, flips = _replay(mvo, np.sort(np.random.RandomState(2).uniform(0, 1.0, 1050)))
     assert flips == 0 and not on.any()
+    # independent arrivals at the rate of the tracking-rows loop (1500 windows/s = 5.7 slots), 20 s of them: the grid (it would
+    # hold 208 CUs for slots that are two thirds empty: 1800 frames/s with it, 2470 without) stays off, or -- when a chance
+    # cluster of 128 arrivals at the 8-slot rate brings it up -- leaves again (it leaves below 7 slots; ADVICE r04: with the
+    # leave threshold at 5 and 64 arrivals such a load flipped it on for good)
+    for seed in range(4):
+        on, flips = _replay(mvo, np.sort(np.random.RandomState(100 + seed).uniform(0, 20.0, 30000)))
+        assert flips <= 8 and on.mean() < 0.03 and (flips % 2 == 0) == (not on[-1]), (seed, flips, on.mean())
     # one sequence at 400 frames/s
     on, flips = _replay(mvo, np.arange(400) * 0.0025)
     assert flips == 0 and not on.any()
 
 
 def test_pauses_and_the_end_of_a_run_do_not_look_like_low_load(mvo):
-    warm = _bursts(0.007, 24, 5)
+    warm = _bursts(0.007, 24, 8)
     for pause in (0.03, 0.3, 3.0):                       # barrier between warm-up and timed region, a long stop
         t = np.concatenate([warm, _bursts(0.007, 24, 20, t0=warm[-1] + pause, seed=3)])
         on, flips = _replay(mvo, t)

@@ -46,7 +46,8 @@ def test_algorithmic_work_table_names_the_kernels_of_a_frame():
     import bench
     args = bench.parse([])
     work = bench.algorithmic_work(args)
-    assert set(work) == {"k_pyramid", "k_fast_harris", "k_brief", "k_knn2"}
+    # (k_brief: latency-mode contexts; k_blur + k_brief_sample: the throughput-mode contexts of the headline run)
+    assert set(work) == {"k_pyramid", "k_fast_harris", "k_brief", "k_blur", "k_brief_sample", "k_knn2"}
     assert work["k_knn2"] == ("valu", 16.0 * 2000 * 2000)
     # BA5 is 11.2 MFLOP per LM trial
     assert abs(bench.ba_trial_flops(9386, 2000, 5, False) / 1e6 - 11.2) < 0.3

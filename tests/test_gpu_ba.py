@@ -303,6 +303,89 @@ def test_bitwise_the_benchmarked_window_all_50_iterations(mvo, O, ctx):
     assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 28  # (one XCD minus the 4 CUs left to other kernels)
 
 
+def _bench_windows(mvo):
+    """The first windows of shard 0 / shard 1 of bench.py's pool (bench.window_pool: seed 7 + 1000 x shard + k)."""
+    return [mvo.synth.ba_problem(5, 2000, 7), mvo.synth.ba_problem(5, 2000, 8), mvo.synth.ba_problem(5, 2000, 1007)]
+
+
+@pytest.mark.parametrize("route", ["resident_grid", "launch_path"])
+def test_bitwise_throughput_cut_and_service(mvo, O, route):
+    """The flavour bench.py's headline number runs (g2o_ba.cpp:193-289 semantics, write-back :298-316): THROUGHPUT mode, the
+    window cut into 13 workgroups (~720 observations per range: the second edge of a thread in LDS, measurements re-read from
+    device memory, two chunks of U) -- once through the resident solver grid (k_ba_service<32,2>: inputs read from the pinned
+    image, slots pulling from mailboxes) and once with the same cut on the launch path (k_ba_lm<false,32,2>; MVO_BA_MODE_SHARED
+    is the mode that always takes it).  Held to the blocked oracle trial by trial ON THE DEVICE, not only in the emulator."""
+    c = mvo.Context(0)
+    try:
+        if route == "resident_grid":
+            c.ba_set_mode("throughput")
+            mvo.debug_set("ba_service", 2)          # (the default policy brings the grid up under load only)
+        else:
+            c.ba_set_mode("shared")
+        c.ba_launch_stats(reset=True)
+        for pb in _bench_windows(mvo):
+            st, plan = _bitwise(mvo, O, c, pb, fix_points=False)
+            assert plan["wgs"] == 13 and (plan["nsplit"] & 0xFFFF) >= 2 and st["iterations"] == 50 and st["trials"] > 60, (plan["wgs"], plan["nsplit"], st)
+        stats = c.ba_launch_stats()
+        if route == "resident_grid":
+            assert stats["resident_windows"] >= 3, stats
+        else:
+            assert stats["resident_windows"] == 0, stats
+        _bitwise(mvo, O, c, _bench_windows(mvo)[0], fix_points=True)      # pose-only windows always take the launch path
+    finally:
+        mvo.debug_set("ba_service", 1)
+        c.close()
+
+
+def test_bitwise_ba10_windows_sharing_launches(mvo, O):
+    """BASELINE configs[3] the way bench.py --width 1242 --height 375 --max-kp 4000 --ba-poses 10 --ba-points 4000 --streams 8 loads
+    the device: several sequences submit BA10 windows at once, the launch thread packs ~4 of them (56 workgroups each, Schur
+    partials summed per XCD group first) into one grid.  Every one of them still equals the blocked oracle bit for bit."""
+    import threading
+    pbs = [mvo.synth.ba_problem(10, 4000, 13 + k, width=1242, height=375, K=mvo.synth.KITTI_K) for k in range(4)]
+    errors, plans = [], []
+    gate = threading.Barrier(len(pbs))
+
+    def work(k):
+        try:
+            c = mvo.Context(0)
+            for _ in range(2):
+                gate.wait()
+                st, plan = _bitwise(mvo, O, c, pbs[k], fix_points=False)
+                plans.append((plan["wgs"], plan["groups"], st["iterations"]))
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((k, repr(e)[:2000]))
+            gate.abort()
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(pbs))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[0]
+    assert len(plans) == 8 and all(g >= 56 and k >= 2 and it == 50 for g, k, it in plans), plans
+
+
+def test_bitwise_schur_exchange_forms(mvo, O, ctx):
+    """Windows of one XCD add their Schur partials in ONE hop (every workgroup reads the G partials and sums them in range order;
+    two buffers alternate) -- the round-4 form (a slice owner per packed range, sums republished) is kept behind `ba_one_hop` = 0:
+    the same additions in the same order, the same bits, for both cuts and for a window whose failed trials have no all-to-all
+    between two exchanges."""
+    for hop in (0, 1):
+        mvo.debug_set("ba_one_hop", hop)
+        try:
+            st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
+            assert plan["wgs"] == 28 and st["trials"] > st["iterations"]
+            for wgs in (13, 2, 31):
+                mvo.debug_set("ba_wgs", wgs)
+                _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 8), fix_points=False, max_iterations=14)
+                mvo.debug_set("ba_wgs", 0)
+        finally:
+            mvo.debug_set("ba_one_hop", 1)
+            mvo.debug_set("ba_wgs", 0)
+
+
 def test_bitwise_config4_ba10_window(mvo, O, ctx):
     """BASELINE configs[3]: 10 keyframes / 4000 landmarks / ~36k edges (KITTI shape), no fixed vertex."""
     pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)

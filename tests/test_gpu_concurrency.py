@@ -51,29 +51,36 @@ def test_concurrent_contexts_reproduce_the_serial_results(mvo):
             assert results[s][r] == expected[s], "thread %d round %d differs from the lone-ctx result" % (s, r)
 
 
-def test_throughput_mode_follows_the_load(mvo):
+def test_throughput_mode_follows_the_load(mvo, O):
     """mvo_ba_set_mode(THROUGHPUT) = "many sequences share this GPU": a lone caller's windows keep the launch path and the
     latency cut (the resident grid would hold 2 x 13 CUs of every XCD for nothing); 24 callers submitting back to back
-    bring the resident solver service up, and their windows move to its slots.  Whatever the route, a result equals one of
-    the two cuts' results bit for bit."""
+    bring the resident solver service up, and their windows move to its slots.  Whatever the route, a result equals the ORACLE's
+    result for one of the two cuts bit for bit."""
     pb = mvo.synth.ba_problem(5, 2000, 7)
     args = (pb["poses0"], pb["points0"], pb["edge_pose"], pb["edge_point"], pb["edge_uv"], pb["focal"], pb["cx"], pb["cy"])
     ref = mvo.Context(0)
     lat = ref.bundle_adjustment(*args, fix_points=False)
-    assert ref.ba_plan()["wgs"] == 28
+    plan_lat = ref.ba_plan()
+    assert plan_lat["wgs"] == 28
     ref.ba_set_mode("throughput")
     mvo.debug_set("ba_service", 2)
     try:
         svc = ref.bundle_adjustment(*args, fix_points=False)
-        assert ref.ba_plan()["wgs"] == 13
+        plan_svc = ref.ba_plan()
+        assert plan_svc["wgs"] == 13
     finally:
         mvo.debug_set("ba_service", 1)
+    # what a result may be is said by the ORACLE (its blocked twin with the plan of either cut), not by an earlier GPU run
+    olat = O.bundle_adjustment_blocked(*args, plan=plan_lat, fix_points=False)
+    osvc = O.bundle_adjustment_blocked(*args, plan=plan_svc, fix_points=False)
+    assert lat[0].tobytes() == olat[0].tobytes() and lat[1].tobytes() == olat[1].tobytes()
+    assert svc[0].tobytes() == osvc[0].tobytes() and svc[1].tobytes() == osvc[1].tobytes()
     ref.synchronize()
     ref.ba_launch_stats(reset=True)
     lone = ref.bundle_adjustment(*args, fix_points=False)                       # default policy, no load
     assert ref.ba_plan()["wgs"] == 28 and lone[0].tobytes() == lat[0].tobytes()
     assert ref.ba_launch_stats()["resident_windows"] == 0
-    ok = {(r[0].tobytes(), r[1].tobytes()) for r in (lat, svc)}
+    ok = {(r[0].tobytes(), r[1].tobytes()) for r in (olat, osvc)}
     errors, routes = [], []
 
     def worker(k):
