@@ -47,7 +47,6 @@ int g_ba_uv_global = 1;     // 0 = measurements always in LDS (the form before t
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 int g_ba_groups = std::getenv("MVO_BA_GROUPS") ? std::atoi(std::getenv("MVO_BA_GROUPS")) : 1;  // 0 = one flat Schur exchange whatever the window's size (A/B)
-int g_ba_one_hop = std::getenv("MVO_BA_ONE_HOP") ? std::atoi(std::getenv("MVO_BA_ONE_HOP")) : 1;  // 0 = slice owners + republished sums also for windows of one XCD (the form up to round 4; A/B)
 int g_ba_alias_sl = std::getenv("MVO_BA_ALIAS_SL") ? std::atoi(std::getenv("MVO_BA_ALIAS_SL")) : 1;  // 0 = the reduced system always has LDS of its own (A/B)
 
 // The demand estimate of the resident solver service (a plain state machine over submission times, so that it can be
@@ -74,7 +73,7 @@ struct Carver {
 struct BaPlan {
     int F = 0, L = 0, E = 0, G = 1, nfree = 0, n = 0, NT = 1, npair = 1, nlow = 0, npk = 16, slice = 0, nsplit = 1, npar = 1, nseq = 1,
         ldu = 16, nhp = 1, maxEg = 0, maxLg = 0, max_dup = 0, fix_points = 0, e2_edges = 0, slots = 1, npt = 1, panel = 0, uv_global = 0,
-        alias_sl = 0, groups = 1, one_hop = 0;
+        alias_sl = 0, groups = 1;
     bool service = false;  // solved by the resident solver service (inputs are read from the pinned image: no upload)
     size_t uarea = 0;
     size_t lds = 0;
@@ -932,11 +931,6 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
         if (G % K == 0 && G / K <= 32 && uarea >= (size_t)K * (size_t)(nlow + nhp)) P.groups = K;
     }
     P.slice = (nlow + G / P.groups - 1) / (G / P.groups);
-    // Windows of one group (<= 32 workgroups: one XCD): every workgroup reads the G partials straight from the L2 and adds them in
-    // range order itself -- ONE far-memory hop per trial instead of two (slice sum -> republish -> gather).  Same order of the
-    // additions, hence the same bits; the partials alternate between two buffers (a trial that ends at the failed factorisation has
-    // no all-to-all behind it: a workgroup may publish the next trial's partials while a slower one still reads this trial's).
-    P.one_hop = (G > 1 && P.groups == 1 && g_ba_one_hop) ? 1 : 0;
     // ---- edges sorted by (owner workgroup, pose); adjacency tables
     std::vector<int>&e_pose = SC.e_pose, &e_point = SC.e_point, &ptstart = SC.ptstart, &ptlist = SC.ptlist;
     std::vector<double>& e_uv = SC.e_uv;
@@ -1005,7 +999,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // left them -- memory that only ever held granules, matched by tag.  When their layout does change they are cleared
     // (below): bytes that once held ordinary data must never be taken for a published value.
     Carver cv;
-    P.o_xp = cv.take((size_t)G * npk * 16 * (P.one_hop ? 2 : 1));
+    P.o_xp = cv.take((size_t)G * npk * 16);
     P.o_xr = cv.take((size_t)npk * 16 * (P.groups > 1 ? 2 * P.groups : 1));
     P.o_xh = cv.take((size_t)G * nhp * 16);
     P.o_xc = cv.take((size_t)2 * G * 4 * 8);
@@ -1098,7 +1092,6 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.uv_global = P.uv_global;
     B.alias_sl = P.alias_sl;
     B.groups = P.groups;
-    B.one_hop = P.one_hop;
     B.uv_dev = (double*)(D + P.o_uvd);
     B.npt = P.npt;
     B.panel = P.panel;

@@ -1128,8 +1128,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             // chunk: one chain per (tile pair, column piece); the pieces of a pair are added in piece order.
             if (do_schur) {
                 ++tagA;
-                // where this exchange's partials go: with the one-hop exchange two buffers alternate (see stage 1 below)
-                u64* const xPw = B.xP + (B.one_hop ? (size_t)(tagA & 1) * 2 * (size_t)G * npk : 0);
                 double* split_stage = W.SL;  // (free until the assemble step) npair x (npar - 1) x 256
                 // running sums of this wave's first two tile pairs over the chunks (windows with more than 16 tile pairs are
                 // planned with one chunk: a wave then publishes every pair straight from the chain)
@@ -1234,7 +1232,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                                         const int rr = (lane >> 4) + 4 * j, c = lane & 15;
                                         const int pk = a == wave ? pk4[j] : pkt_g[pr * 256 + rr * 16 + c];
                                         if (pk >= 0) {
-                                            if (G > 1) gstore_d(xPw + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], grp_l2);
+                                            if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], grp_l2);
                                             else W.Rl[pk] = r[j];
                                         }
                                     }
@@ -1256,7 +1254,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                                 tot = (ch == 0 && sp == 0) ? acc : tot + acc;
                             }
                             W.Rl[pk] = tot;
-                            if (last && G > 1) gstore_d(xPw + 2 * ((size_t)g * npk + pk), tag0 + tagA, tot, grp_l2);
+                            if (last && G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, tot, grp_l2);
                         }
                     }
                     if (!last) __syncthreads();  // (the chunk and the split tiles are consumed)
@@ -1277,60 +1275,11 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     u64* xR = B.xR + (K > 1 ? 2 * (size_t)(tagA & 1) * K * npk : 0);
                     const int nhpx = hp_pending ? B.nhp - 1 : 0, nlowx = nlow + nhpx;
                     const int slicex = hp_pending ? (nlowx + Gk - 1) / Gk : slice;
-                    for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(xPw + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], grp_l2);
-                    if (B.one_hop) {
-                        // ONE hop (windows of one group: all workgroups on one XCD's L2): thread e reads entry e of all G partials
-                        // itself -- up to BA_XB granule pairs in flight -- and adds them in workgroup order: the very additions the
-                        // slice owner of the two-hop form makes, so the bits are the same; nothing is republished.  Buffers: a trial
-                        // that ends at the failed factorisation has no all-to-all behind it, so a workgroup may publish the partials
-                        // of exchange t + 1 while a slower one still reads those of exchange t -- they go to the other buffer.  It
-                        // cannot get to exchange t + 2 before everybody has published t + 1, i.e. has finished reading t.
-#ifndef BA_XB_N
-#define BA_XB_N 14
-#endif
-                        constexpr int BA_XB = BA_XB_N;  // (granule pairs a thread keeps in flight; -DBA_XB_N=.. for the A/B)
-                        for (int e = tid; e < nlowx; e += BA_THREADS) {
-                            const u64* src = xPw + 2 * (size_t)e;
-                            double sum = 0;
-                            for (int w0 = 0; w0 < G; w0 += BA_XB) {
-                                double v[BA_XB];
-                                unsigned pending = 0;
-#pragma unroll
-                                for (int u = 0; u < BA_XB; ++u)
-                                    if (w0 + u < G) pending |= 1u << u;
-                                for (unsigned spin = 0; pending; ++spin) {
-                                    bool got[BA_XB];
-#pragma unroll
-                                    for (int u = 0; u < BA_XB; ++u) {
-                                        got[u] = false;
-                                        double t = 0;
-                                        if (pending & (1u << u)) got[u] = gtry_d(src + 2 * (size_t)(w0 + u) * npk, tag0 + tagA, t);
-                                        if (got[u]) v[u] = t;
-                                    }
-#pragma unroll
-                                    for (int u = 0; u < BA_XB; ++u)
-                                        if (got[u]) pending &= ~(1u << u);
-                                    if (pending) {
-                                        if (spin > BA_SPIN_LIMIT) {
-                                            sFlag[2] = 1;
-                                            break;
-                                        }
-                                        if (PROF) ++ph[PROF ? 12 : 0];
-                                        __builtin_amdgcn_s_sleep(1);
-                                    }
-                                }
-#pragma unroll
-                                for (int u = 0; u < BA_XB; ++u)
-                                    if (w0 + u < G) sum += v[u];
-                            }
-                            W.Rl[e] = sum;
-                        }
-                        STAMP(10);
-                    } else {
+                    for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(B.xP + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], grp_l2);
                     const int sl0 = gj * slicex, sln = max(0, min(slicex, nlowx - sl0));
                     if (sln > 0) {
                         // item q = (w, el): partial of the group's workgroup w (= workgroup w K + gk), entry sl0 + el
-                        if (!gather_tagged(xPw + 2 * ((size_t)gk * npk + sl0), sln * Gk, sln, (size_t)K * npk, tag0 + tagA, W.SL, PROF ? &ph[PROF ? 12 : 0] : nullptr)) sFlag[2] = 1;
+                        if (!gather_tagged(B.xP + 2 * ((size_t)gk * npk + sl0), sln * Gk, sln, (size_t)K * npk, tag0 + tagA, W.SL, PROF ? &ph[PROF ? 12 : 0] : nullptr)) sFlag[2] = 1;
                     }
                     STAMP(7);
                     __syncthreads();
@@ -1366,7 +1315,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                         }
                     }
                     STAMP(10);
-                    }  // (two-hop form)
                     if (hp_pending) {  // the summed pose blocks of this iteration: [H_pp | -b_p] of every free pose
                         __syncthreads();
                         if (tid < BA_HP * nfree) {

@@ -60,8 +60,6 @@ struct BaDev {
     int npk;     // nlow rounded up to 16: row pitch of the partial exchange
     int slice;   // packed entries every workgroup reduces in stage 1
     int groups;  // K: the Schur exchange sums the partials of the workgroups g = k mod K first (one XCD each), then the K group sums
-    int one_hop;  // 1 (K = 1 only): every workgroup reads the G partials itself and adds them in range order -- no slice owner, no
-                  // republished sums; xP then holds TWO buffers that alternate with the exchange number
     int nsplit;  // consecutive column pieces of a Schur chain (results added in piece order) = nseq x npar
     int npar;    // pieces that run side by side on different waves (one chunk of the U area holds npar pieces)
     int nseq;    // chunks of the U area that are built and consumed one after the other
@@ -95,7 +93,7 @@ struct BaDev {
     const int* slot_pose;     // nfree
     const short* pk_of_tile;  // npair x 256: packed index of tile entry (pair, r, c), -1 if not needed
     // cross-workgroup exchange: 8-byte granules {tag : 32 | half a double : 32}, two per value
-    ba_u64* xP;  // G x npk x 2   Schur partials (x 2 buffers with one_hop)
+    ba_u64* xP;  // G x npk x 2   Schur partials
     ba_u64* xR;  // npk x 2       the same entries summed over the workgroups
     ba_u64* xH;  // G x nhp x 2   pose-block partials (+ max diagonal)
     ba_u64* xC;  // 2 (parity) x G x 2 x 2   chi2 / predicted-decrease partials

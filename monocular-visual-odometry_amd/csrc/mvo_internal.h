@@ -12,11 +12,15 @@
 #define MVO_DYN_LDS_ALIGNED16(T, name) extern __shared__ __attribute__((aligned(16))) T name[]
 #define MVO_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
 #define MVO_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")  // this wave's global stores have left for memory
+// the value of a 32-bit vector register is taken as unknown from here on: keeps loop-invariant unpacking / address arithmetic
+// INSIDE a loop (hoisted, a dozen packed table entries become three dozen live registers)
+#define MVO_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
 #define MVO_DYN_LDS(T, name) T* name = static_cast<T*>(emu_dyn_lds())
 #define MVO_DYN_LDS_ALIGNED16(T, name) T* name = static_cast<T*>(emu_dyn_lds())
 #define MVO_WAVES_PER_EU(lo, hi)
 #define MVO_WAIT_VM0() __atomic_thread_fence(__ATOMIC_SEQ_CST)
+#define MVO_OPAQUE(x) (void)(x)
 #endif
 
 #include <map>

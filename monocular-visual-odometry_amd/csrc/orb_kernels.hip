@@ -255,6 +255,15 @@ __device__ __forceinline__ int find_level_by(const PyrInfo& P, int idx, int whic
     return l;
 }
 
+#ifndef MVO_KERNEL_SIM
+typedef short mvo_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mvo_s16x2, a), __builtin_bit_cast(mvo_s16x2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(mvo_s16x2, a), __builtin_bit_cast(mvo_s16x2, b)));
+}
+#endif
 // cornerScore<16>: the largest threshold for which the pixel is still a FAST-9 corner; 0 if it is not one at
 // threshold thr.  d[k] = centre - circle[k].
 __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
@@ -273,7 +282,37 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
         return (c & (x >> 8) & 0xffffu) != 0;
     };
     if (!has9(dark) && !has9(bright)) return 0;
-    // sliding minimum / maximum over 9 consecutive circle pixels by doubling
+#ifndef MVO_KERNEL_SIM
+    // sliding minimum / maximum over 9 consecutive circle pixels by doubling, two differences per register: |d| <= 255 fits
+    // int16, so the 16 values travel as 8 packed pairs P[j] = (d[2j], d[2j+1]) and every level of the doubling is one
+    // v_pk_min_i16 / v_pk_max_i16 per pair (Q = the pairs shifted by one element; shifts by 2 / 4 / 8 elements are whole
+    // registers).  Half the instructions and a third of the registers of the scalar form below (the kernel's occupancy was bound
+    // by them: 96 VGPRs, five workgroups per CU); exactly the same integers.
+    uint32_t P[8], mn[8], mx[8], t[8], u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) P[j] = ((uint32_t)d[2 * j] & 0xffffu) | ((uint32_t)d[2 * j + 1] << 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t Q = __builtin_amdgcn_alignbit(P[(j + 1) & 7], P[j], 16);  // (d[2j+1], d[2j+2])
+        mn[j] = pk_min_i16(P[j], Q);
+        mx[j] = pk_max_i16(P[j], Q);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = pk_min_i16(mn[j], mn[(j + 1) & 7]), u[j] = pk_max_i16(mx[j], mx[(j + 1) & 7]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mn[j] = pk_min_i16(t[j], t[(j + 2) & 7]), mx[j] = pk_max_i16(u[j], u[(j + 2) & 7]);
+    uint32_t a = pk_min_i16(mn[0], P[4]), b = pk_max_i16(mx[0], P[4]);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+        a = pk_max_i16(a, pk_min_i16(mn[j], P[(j + 4) & 7]));  // max over k of min(d[k .. k+8])
+        b = pk_min_i16(b, pk_max_i16(mx[j], P[(j + 4) & 7]));  // min over k of max(d[k .. k+8])
+    }
+    const int A = max((int)(int16_t)(a & 0xffffu), (int)(int16_t)(a >> 16));
+    const int Bn = min((int)(int16_t)(b & 0xffffu), (int)(int16_t)(b >> 16));
+    const int best = max(A, -Bn);
+    return best > thr ? best - 1 : 0;
+#else
+    // (the emulated build of tests/sim: the scalar form)
     int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -298,6 +337,7 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
     }
     int best = max(A, B);
     return best > thr ? best - 1 : 0;
+#endif
 }
 
 // cv::fastAtan2 (degrees)
@@ -380,7 +420,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         sc[sr * 68 + scx] = (uint8_t)fast_score16(d, thr);
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the survivor loop below works on scalar addresses)
     for (int ly = wave; ly < FT_H; ly += 4) {
         const int gx = x0 + lane, gy = y0 + ly;
         const uint8_t* s = sc + (ly + 1) * 68 + (lane + 1);
@@ -418,33 +458,41 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     // this lane's pixels of the intensity-centroid disc (k = lane, lane + 64, ...): offsets and (u, v) once per workgroup,
     // not once per survivor
     constexpr int DISC_IT = (768 + 63) / 64;
-    int doff[DISC_IT], duv[DISC_IT];
+    // (u + 15, v + 15) of this lane's disc pixels, packed: all the survivor loop keeps of the table.  Offsets are taken from the
+    // corner (gx - 15, gy - 15) of the patch, so that they are non-negative 32-bit lane offsets on one scalar base.
+    unsigned duv[DISC_IT];
 #pragma unroll
     for (int q = 0; q < DISC_IT; ++q) {
         const int k = lane + 64 * q;
         const int u = k < ndisc ? c_disc[2 * k] : 0, v = k < ndisc ? c_disc[2 * k + 1] : 0;
-        doff[q] = k < ndisc ? v * step + u : 0;
-        duv[q] = k < ndisc ? (int)((unsigned)(u & 0xffff) | ((unsigned)v << 16)) : 0;  // (a padded lane re-reads the centre with weight 0)
+        duv[q] = (unsigned)(u + 15) | ((unsigned)(v + 15) << 8);  // (a padded lane: u = v = 0 -- it re-reads the centre with weight 0)
     }
+    const unsigned hb = lane < 49 ? (unsigned)(lane / 7 + 12) * (unsigned)step + (unsigned)(lane % 7 + 12) : 0u;  // this lane's Harris block position
     for (int i = wave; i < total; i += 4) {
         // survivor i -> (row, i-th set bit of the row's mask)
         int r = 0;
 #pragma unroll
         for (int k = 1; k < FT_H; ++k)
             if (i >= rowstart[k]) r = k;
+        r = __builtin_amdgcn_readfirstlane(r);
         const u64 m = rowmask[r];
         const int kth = i - rowstart[r];
         const bool me = ((m >> lane) & 1) && (int)__popcll(m & ((1ull << lane) - 1)) == kth;
-        const int lx = __ffsll((long long)__ballot(me)) - 1;
+        // (one survivor per wave: its position is wave-uniform -- said to the compiler, so that the ~20 byte loads below take ONE
+        // scalar base + a 32-bit lane offset each instead of a 64-bit address per load: the kernel's register peak was here)
+        const int lx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(me)) - 1);
         const int gx = x0 + lx, gy = y0 + r;
-        const uint8_t* ctr = base + (size_t)(gy + MVO_BORDER) * step + MVO_BORDER + gx;
+        const uint8_t* lo = base + (size_t)(gy + MVO_BORDER - 15) * step + (MVO_BORDER + gx - 15);  // patch corner (scalar)
         // HarrisResponses, blockSize 7: lanes 0..48 take one block position each
         int a = 0, b = 0, c = 0;
         if (lane < 49) {
-            int bi = lane / 7 - 3, bj = lane % 7 - 3;
-            const uint8_t* p = ctr + bi * step + bj;
-            int Ix = ((int)p[1] - p[-1]) * 2 + ((int)p[-step + 1] - p[-step - 1]) + ((int)p[step + 1] - p[step - 1]);
-            int Iy = ((int)p[step] - p[-step]) * 2 + ((int)p[step - 1] - p[-step - 1]) + ((int)p[step + 1] - p[-step + 1]);
+            unsigned o = hb;
+            MVO_OPAQUE(o);
+            const unsigned st = (unsigned)step;
+            const int p_l = lo[o - 1], p_r = lo[o + 1], p_u = lo[o - st], p_d = lo[o + st];
+            const int p_ul = lo[o - st - 1], p_ur = lo[o - st + 1], p_dl = lo[o + st - 1], p_dr = lo[o + st + 1];
+            int Ix = (p_r - p_l) * 2 + (p_ur - p_ul) + (p_dr - p_dl);
+            int Iy = (p_d - p_u) * 2 + (p_dl - p_ul) + (p_dr - p_ur);
             a = Ix * Ix;
             b = Iy * Iy;
             c = Ix * Iy;
@@ -456,9 +504,12 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         int m10 = 0, m01 = 0;
 #pragma unroll
         for (int q = 0; q < DISC_IT; ++q) {
-            const int val = ctr[doff[q]];
-            m10 += (int)(int16_t)(duv[q] & 0xffff) * val;
-            m01 += (duv[q] >> 16) * val;
+            unsigned e = duv[q];
+            MVO_OPAQUE(e);
+            const unsigned ub = e & 0xffu, vb = (e >> 8) & 0xffu;
+            const int val = lo[vb * (unsigned)step + ub];
+            m10 += ((int)ub - 15) * val;
+            m01 += ((int)vb - 15) * val;
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);

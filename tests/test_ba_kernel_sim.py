@@ -263,22 +263,3 @@ def test_windows_of_changing_shape_on_one_context(mvo, O, simctx):
         _bitwise(mvo, O, simctx, mvo.synth.ba_problem(F, L, seed), fix_points=False, max_iterations=3)
     _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True, max_iterations=3)
 
-
-def test_schur_exchange_forms(mvo, O, simctx, simlib, monkeypatch):
-    """One-hop exchange (default for windows of one group) and the two-hop form behind ba_one_hop = 0: the same bits; the one-hop
-    form also under a shuffled thread order (its two partial buffers alternate: a fast workgroup publishes the next trial's partials
-    while a slow one still reads this trial's)."""
-    for hop in (0, 1):
-        simlib.mvo_debug_set(b"ba_one_hop", hop)
-        try:
-            st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=20)
-            assert plan["wgs"] == 28 and st["trials"] > st["iterations"]
-        finally:
-            simlib.mvo_debug_set(b"ba_one_hop", 1)
-    monkeypatch.setenv("EMU_ORDER", "shuffle")
-    simlib.mvo_debug_set(b"ba_wgs", 13)
-    try:
-        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=30)
-        assert plan["wgs"] == 13 and st["trials"] > st["iterations"] + 5
-    finally:
-        simlib.mvo_debug_set(b"ba_wgs", 0)

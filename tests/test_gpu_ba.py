@@ -367,25 +367,6 @@ def test_bitwise_ba10_windows_sharing_launches(mvo, O):
     assert len(plans) == 8 and all(g >= 56 and k >= 2 and it == 50 for g, k, it in plans), plans
 
 
-def test_bitwise_schur_exchange_forms(mvo, O, ctx):
-    """Windows of one XCD add their Schur partials in ONE hop (every workgroup reads the G partials and sums them in range order;
-    two buffers alternate) -- the round-4 form (a slice owner per packed range, sums republished) is kept behind `ba_one_hop` = 0:
-    the same additions in the same order, the same bits, for both cuts and for a window whose failed trials have no all-to-all
-    between two exchanges."""
-    for hop in (0, 1):
-        mvo.debug_set("ba_one_hop", hop)
-        try:
-            st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
-            assert plan["wgs"] == 28 and st["trials"] > st["iterations"]
-            for wgs in (13, 2, 31):
-                mvo.debug_set("ba_wgs", wgs)
-                _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 8), fix_points=False, max_iterations=14)
-                mvo.debug_set("ba_wgs", 0)
-        finally:
-            mvo.debug_set("ba_one_hop", 1)
-            mvo.debug_set("ba_wgs", 0)
-
-
 def test_bitwise_config4_ba10_window(mvo, O, ctx):
     """BASELINE configs[3]: 10 keyframes / 4000 landmarks / ~36k edges (KITTI shape), no fixed vertex."""
     pb = mvo.synth.ba_problem(10, 4000, 13, width=1242, height=375, K=mvo.synth.KITTI_K)
