@@ -129,6 +129,20 @@ __device__ __forceinline__ int pyr_sample(const uint8_t* __restrict__ S, const P
                  : ((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
 }
 
+// (row, column) of element i of a region w wide: i / w by a float reciprocal and one correction step (exact for the
+// region sizes in play, i < 2^22; the integer division it replaces was a third of the instructions of the region loops)
+__device__ __forceinline__ void region_row_col(int i, int w, float rcp_w, int& ry, int& rx) {
+    ry = (int)((float)i * rcp_w);
+    rx = i - ry * w;
+    if (rx < 0) {
+        --ry;
+        rx += w;
+    } else if (rx >= w) {
+        ++ry;
+        rx -= w;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
                                                  const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
     // region pool: dynamic LDS sized by the host for the hungriest tile of THIS launch (orb_setup_geometry: ~9 KB for the
@@ -200,8 +214,10 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
     {
         const PyrRegion R = reg[depth];
         uint8_t* dst = lds + regoff[depth];
+        const float rcp_w = 1.0f / (float)R.w;
         for (int i = tid; i < R.w * R.h; i += 256) {
-            const int ry = i / R.w, rx = i - ry * R.w;
+            int ry, rx;
+            region_row_col(i, R.w, rcp_w, ry, rx);
             dst[i] = (uint8_t)pyr_px<0>(B, raw, P, tabs, B.level, R.x0 + rx, R.y0 + ry, exact);
         }
     }
@@ -213,8 +229,10 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
         const uint8_t* src = lds + regoff[d + 1];
         uint8_t* dst = lds + regoff[d];
         const int sw = P.lv[m - 1].w, sh = P.lv[m - 1].h, toff = P.lv[m].tab_off, mw = P.lv[m].w;
+        const float rcp_w = 1.0f / (float)R.w;
         for (int i = tid; i < R.w * R.h; i += 256) {
-            const int ry = i / R.w, rx = i - ry * R.w;
+            int ry, rx;
+            region_row_col(i, R.w, rcp_w, ry, rx);
             dst[i] = (uint8_t)pyr_sample(src, S, sw, sh, tabs[toff + R.x0 + rx], tabs[toff + mw + R.y0 + ry], exact);
         }
         __syncthreads();
@@ -255,7 +273,23 @@ __device__ __forceinline__ int find_level_by(const PyrInfo& P, int idx, int whic
     return l;
 }
 
-#ifndef MVO_KERNEL_SIM
+// A/B switches of k_fast_harris (csrc/Makefile `alt` target; defaults = the shipped form)
+#ifndef MVO_FH_COMPACT
+#define MVO_FH_COMPACT 1  // 1: pixels that pass the FAST quick test are queued and scored densely; 0: scored in place (round 4)
+#endif
+#ifndef MVO_FH_DPP
+#define MVO_FH_DPP 1      // 1: wave sums of the survivor phase by DPP row shifts; 0: by ds_bpermute shuffles (round 4)
+#endif
+#ifndef MVO_FH_PACKED
+#define MVO_FH_PACKED 0   // 1: the sliding min / max of the score on packed int16 pairs
+#endif
+#if defined(MVO_KERNEL_SIM)
+#undef MVO_FH_DPP
+#define MVO_FH_DPP 0
+#undef MVO_FH_PACKED
+#define MVO_FH_PACKED 0
+#endif
+#if MVO_FH_PACKED
 typedef short mvo_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mvo_s16x2, a), __builtin_bit_cast(mvo_s16x2, b)));
@@ -264,10 +298,10 @@ __device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(mvo_s16x2, a), __builtin_bit_cast(mvo_s16x2, b)));
 }
 #endif
-// cornerScore<16>: the largest threshold for which the pixel is still a FAST-9 corner; 0 if it is not one at
-// threshold thr.  d[k] = centre - circle[k].
-__device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
-    // quick reject: bit masks of circle pixels darker / brighter than the centre by more than thr
+// cornerScore<16> in two halves.  d[k] = centre - circle[k].
+// fast_quick_test: can the pixel be a FAST-9 corner at threshold thr at all?  (bit masks of the circle pixels darker / brighter
+// than the centre by more than thr; nine consecutive set bits in either)
+__device__ __forceinline__ bool fast_quick_test(const int (&d)[16], int thr) {
     uint32_t dark = 0, bright = 0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -281,13 +315,14 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
         uint32_t c = b & (b >> 4);
         return (c & (x >> 8) & 0xffffu) != 0;
     };
-    if (!has9(dark) && !has9(bright)) return 0;
-#ifndef MVO_KERNEL_SIM
-    // sliding minimum / maximum over 9 consecutive circle pixels by doubling, two differences per register: |d| <= 255 fits
-    // int16, so the 16 values travel as 8 packed pairs P[j] = (d[2j], d[2j+1]) and every level of the doubling is one
-    // v_pk_min_i16 / v_pk_max_i16 per pair (Q = the pairs shifted by one element; shifts by 2 / 4 / 8 elements are whole
-    // registers).  Half the instructions and a third of the registers of the scalar form below (the kernel's occupancy was bound
-    // by them: 96 VGPRs, five workgroups per CU); exactly the same integers.
+    return has9(dark) || has9(bright);
+}
+// fast_score_full: the largest threshold for which the pixel is still a FAST-9 corner (for a pixel that passed the quick test):
+// max over the 16 arcs of 9 consecutive circle pixels of min(d) and of min(-d), by a sliding minimum / maximum with doubling.
+__device__ __forceinline__ int fast_score_full(const int (&d)[16], int thr) {
+#if MVO_FH_PACKED
+    // two differences per register (|d| <= 255 fits int16): P[j] = (d[2j], d[2j+1]); every level of the doubling is one
+    // v_pk_min_i16 / v_pk_max_i16 per pair (Q = the pairs shifted by one element; shifts by 2 / 4 / 8 elements are whole registers)
     uint32_t P[8], mn[8], mx[8], t[8], u[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) P[j] = ((uint32_t)d[2 * j] & 0xffffu) | ((uint32_t)d[2 * j + 1] << 16);
@@ -312,7 +347,6 @@ __device__ __forceinline__ int fast_score16(const int (&d)[16], int thr) {
     const int best = max(A, -Bn);
     return best > thr ? best - 1 : 0;
 #else
-    // (the emulated build of tests/sim: the scalar form)
     int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -363,9 +397,23 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
+#if MVO_FH_DPP
+    // Inclusive scan inside each row of 16 lanes by DPP row shifts (a lane outside the row contributes 0), then the row totals
+    // are carried over by the two row broadcasts: lane 63 holds the sum of the wave and is read back as a scalar.  Six VALU
+    // instructions instead of six ds_bpermute round trips (each ~60 cycles of dependent latency: five sums per survivor were the
+    // longest chain of the survivor phase).  Integer adds: the order does not matter.
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8   -> lane 15 of every row: the row's total
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3 -> lane 63: the total
+    return __builtin_amdgcn_readlane(v, 63);
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+#endif
 }
 
 // k_fast_harris: one 64 x 16 tile per workgroup, everything cv::ORB::detect computes per corner in ONE launch:
@@ -410,6 +458,48 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     // FAST circle (x, y), same enumeration as the oracle
     constexpr int CX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int CY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+#if MVO_FH_COMPACT
+    // The quick test decides for every pixel of the tile + ring; the few that pass (a few per cent even on busy images) are
+    // queued and scored DENSELY afterwards: scored in place, nearly every wave would walk the whole sliding-minimum code for
+    // a handful of live lanes (that code was ~40 % of the kernel's instructions).
+    __shared__ uint16_t fq[FT_SH * FT_SW];
+    __shared__ int fq_n;
+    if (tid == 0) fq_n = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < FT_SH * FT_SW; i0 += 256) {
+        const int i = i0 + tid;
+        bool pass = false;
+        if (i < FT_SH * FT_SW) {
+            int sr = i / FT_SW, scx = i - sr * FT_SW;
+            const uint8_t* c = pb + (sr + 3) * FT_PW + (scx + 3);  // (ly, lx) = (sr-1, scx-1); +4 halo
+            int v = c[0];
+            int d[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) d[k] = v - (int)c[CX[k] + CY[k] * FT_PW];
+            pass = fast_quick_test(d, thr);
+            if (!pass) sc[sr * 68 + scx] = 0;
+        }
+        const u64 pm = __ballot(pass);
+        if (pm) {  // (wave-uniform) one LDS atomic per wave, the lanes take consecutive places
+            int at = 0;
+            if ((tid & 63) == 0) at = __hip_atomic_fetch_add(&fq_n, (int)__popcll(pm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            at = __shfl(at, 0);
+            if (pass) fq[at + (int)__popcll(pm & ((1ull << (tid & 63)) - 1))] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    for (int q = tid; q < fq_n; q += 256) {
+        const int i = fq[q];
+        int sr = i / FT_SW, scx = i - sr * FT_SW;
+        const uint8_t* c = pb + (sr + 3) * FT_PW + (scx + 3);
+        int v = c[0];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) d[k] = v - (int)c[CX[k] + CY[k] * FT_PW];
+        sc[sr * 68 + scx] = (uint8_t)fast_score_full(d, thr);
+    }
+    __syncthreads();
+#else
     for (int i = tid; i < FT_SH * FT_SW; i += 256) {
         int sr = i / FT_SW, scx = i - sr * FT_SW;
         const uint8_t* c = pb + (sr + 3) * FT_PW + (scx + 3);  // (ly, lx) = (sr-1, scx-1); +4 halo
@@ -417,9 +507,10 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         int d[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) d[k] = v - (int)c[CX[k] + CY[k] * FT_PW];
-        sc[sr * 68 + scx] = (uint8_t)fast_score16(d, thr);
+        sc[sr * 68 + scx] = (uint8_t)(fast_quick_test(d, thr) ? fast_score_full(d, thr) : 0);
     }
     __syncthreads();
+#endif
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the survivor loop below works on scalar addresses)
     for (int ly = wave; ly < FT_H; ly += 4) {
         const int gx = x0 + lane, gy = y0 + ly;
