@@ -129,20 +129,6 @@ __device__ __forceinline__ int pyr_sample(const uint8_t* __restrict__ S, const P
                  : ((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
 }
 
-// (row, column) of element i of a region w wide: i / w by a float reciprocal and one correction step (exact for the
-// region sizes in play, i < 2^22; the integer division it replaces was a third of the instructions of the region loops)
-__device__ __forceinline__ void region_row_col(int i, int w, float rcp_w, int& ry, int& rx) {
-    ry = (int)((float)i * rcp_w);
-    rx = i - ry * w;
-    if (rx < 0) {
-        --ry;
-        rx += w;
-    } else if (rx >= w) {
-        ++ry;
-        rx -= w;
-    }
-}
-
 __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
                                                  const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
     // region pool: dynamic LDS sized by the host for the hungriest tile of THIS launch (orb_setup_geometry: ~9 KB for the
@@ -210,15 +196,28 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
     __shared__ int regoff[PYR_GROUP + 1];
     if (tid == 0) pyr_regions(P, tabs, l, depth, sbox[0], sbox[1], sbox[2], sbox[3], reg, regoff);
     __syncthreads();
+    // Mapping of the region loops and of the tile: lane = column (two columns per lane for regions wider than 64), wave =
+    // every fourth row.  What depends on the column alone -- its resize-table entry, the clamped neighbour, the byte offset in
+    // the image -- is made ONCE per lane instead of once per sample, what depends on the row alone is wave-uniform (scalar
+    // loads), and no sample pays for an index -> (row, column) split: ~14 vector instructions per bilinear sample instead of
+    // ~40, ~9 per gray conversion instead of ~25 (the kernel was instruction-bound on the few CUs the solver grid leaves).
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- base region
     {
         const PyrRegion R = reg[depth];
         uint8_t* dst = lds + regoff[depth];
-        const float rcp_w = 1.0f / (float)R.w;
-        for (int i = tid; i < R.w * R.h; i += 256) {
-            int ry, rx;
-            region_row_col(i, R.w, rcp_w, ry, rx);
-            dst[i] = (uint8_t)pyr_px<0>(B, raw, P, tabs, B.level, R.x0 + rx, R.y0 + ry, exact);
+        for (int cx = lane; cx < R.w; cx += 64) {
+            if (B.img) {
+                const uint8_t* col = B.img + (size_t)R.y0 * B.istride + (size_t)(R.x0 + cx) * B.ch;
+                for (int ry = wv; ry < R.h; ry += 4) {
+                    const uint8_t* px = col + (size_t)ry * B.istride;
+                    dst[ry * R.w + cx] = (uint8_t)(B.ch == 1 ? (int)px[0] : (px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14);
+                }
+            } else {
+                const LevelInfo& Lb = P.lv[B.level];
+                const uint8_t* col = raw + Lb.off + (size_t)(R.y0 + MVO_BORDER) * Lb.stride + MVO_BORDER + R.x0 + cx;
+                for (int ry = wv; ry < R.h; ry += 4) dst[ry * R.w + cx] = col[(size_t)ry * Lb.stride];
+            }
         }
     }
     __syncthreads();
@@ -229,27 +228,41 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
         const uint8_t* src = lds + regoff[d + 1];
         uint8_t* dst = lds + regoff[d];
         const int sw = P.lv[m - 1].w, sh = P.lv[m - 1].h, toff = P.lv[m].tab_off, mw = P.lv[m].w;
-        const float rcp_w = 1.0f / (float)R.w;
-        for (int i = tid; i < R.w * R.h; i += 256) {
-            int ry, rx;
-            region_row_col(i, R.w, rcp_w, ry, rx);
-            dst[i] = (uint8_t)pyr_sample(src, S, sw, sh, tabs[toff + R.x0 + rx], tabs[toff + mw + R.y0 + ry], exact);
+        for (int cx = lane; cx < R.w; cx += 64) {
+            const ResizeEntry tx = tabs[toff + R.x0 + cx];
+            const int sx0 = tx.ofs - S.x0, sx1 = min(tx.ofs + 1, sw - 1) - S.x0;
+            for (int ry = wv; ry < R.h; ry += 4) {
+                const ResizeEntry ty = tabs[toff + mw + R.y0 + ry];
+                const uint8_t* r0 = src + (ty.ofs - S.y0) * S.w;
+                const uint8_t* r1 = src + (min(ty.ofs + 1, sh - 1) - S.y0) * S.w;
+                const int h0 = r0[sx0] * tx.c0 + r0[sx1] * tx.c1, h1 = r1[sx0] * tx.c0 + r1[sx1] * tx.c1;
+                dst[ry * R.w + cx] = (uint8_t)(exact ? ((ty.c0 * h0 + ty.c1 * h1 + 32768) >> 16) & 0xff
+                                                     : ((((ty.c0 * (h0 >> 4)) >> 16) + ((ty.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff);
+            }
         }
         __syncthreads();
     }
-    // ---- the tile itself, frame included
-    if (oy >= bh) return;
+    // ---- the tile itself, frame included: lane = bordered column bx0 + lane, wave w = rows by0 + w, w + 4, ...
     {
         const PyrRegion S = reg[1];
         const uint8_t* src = lds + regoff[1];
         const int sw = P.lv[l - 1].w, sh = P.lv[l - 1].h;
-        const ResizeEntry tyE = tabs[L.tab_off + L.w + reflect101(oy - MVO_BORDER, L.h)];
-        uint32_t out = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (ox4 + k < bw)
-                out |= (uint32_t)pyr_sample(src, S, sw, sh, tabs[L.tab_off + reflect101(ox4 + k - MVO_BORDER, L.w)], tyE, exact) << (8 * k);
-        *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)oy * L.stride + ox4) = out;
+        const int ox = bx0 + lane;
+        const bool live = ox < bw;  // (the columns between the bordered width and the 64-byte row stride are written as zeros)
+        const ResizeEntry txE = tabs[L.tab_off + reflect101(min(ox, bw - 1) - MVO_BORDER, L.w)];
+        const int sx0 = txE.ofs - S.x0, sx1 = min(txE.ofs + 1, sw - 1) - S.x0;
+        uint8_t* out = raw + L.off + ox;
+        for (int ry = wv; ry < PT_H; ry += 4) {
+            const int oyy = by0 + ry;
+            if (oyy >= bh) break;
+            const ResizeEntry tyE = tabs[L.tab_off + L.w + reflect101(oyy - MVO_BORDER, L.h)];
+            const uint8_t* r0 = src + (tyE.ofs - S.y0) * S.w;
+            const uint8_t* r1 = src + (min(tyE.ofs + 1, sh - 1) - S.y0) * S.w;
+            const int h0 = r0[sx0] * txE.c0 + r0[sx1] * txE.c1, h1 = r1[sx0] * txE.c0 + r1[sx1] * txE.c1;
+            const int v = exact ? ((tyE.c0 * h0 + tyE.c1 * h1 + 32768) >> 16) & 0xff
+                                : ((((tyE.c0 * (h0 >> 4)) >> 16) + ((tyE.c1 * (h1 >> 4)) >> 16) + 2) >> 2) & 0xff;
+            out[(size_t)oyy * L.stride] = (uint8_t)(live ? v : 0);
+        }
     }
 }
 
