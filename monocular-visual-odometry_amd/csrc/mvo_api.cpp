@@ -167,7 +167,7 @@ void mvo_destroy(mvo_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     track_release(ctx);
     ba_pool_release(ctx);
-    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_tabs,
+    void* dev[] = {ctx->d_img, ctx->d_raw,  ctx->d_blur, ctx->d_tabs, ctx->d_pyr_regs,
                    ctx->d_kp,   ctx->d_desc_buf, ctx->d_mq,    ctx->d_mt,   ctx->d_mqxy,      ctx->d_mtxy,
                    ctx->d_mout, ctx->d_fh_slots, ctx->d_fh_line, ctx->d_fh_arrive};
     for (void* p : dev)

@@ -112,6 +112,16 @@ MVO_HD inline int pyr_regions(const PyrInfo& P, const ResizeEntry* tabs, int l, 
     return used;
 }
 
+// The regions of one tile as orb_setup_geometry works them out once per image geometry (the tile grid of a pyramid never
+// changes between frames): k_pyramid reads its entry instead of deriving it -- a serial chain of dependent table look-ups on ONE
+// thread in front of every deep tile.  128 bytes per bordered tile.
+struct PyrTileRegs {
+    PyrRegion reg[5];  // [1 .. depth]
+    int off[5];
+    int pad[7];
+};
+static_assert(sizeof(PyrTileRegs) == 128, "one 128-byte line per tile");
+
 // k_fast_harris output: every 64 x 16 tile owns FT_TILE_CAP record slots (3x3 NMS leaves at most one survivor per
 // 2 x 2 pixels: 256 per tile) and one count, in pinned host memory
 #define FT_TILE_CAP 256
@@ -178,6 +188,7 @@ struct mvo_ctx {
     uint8_t *d_raw = nullptr, *d_blur = nullptr;
     size_t pyr_bytes = 0;
     ResizeEntry* d_tabs = nullptr;
+    PyrTileRegs* d_pyr_regs = nullptr;  // per bordered tile: the source regions of k_pyramid (orb_setup_geometry)
     // k_fast_harris: per-tile record slots + line counts in device memory, arrival counter per tile row (self re-arming)
     void* d_fh_slots = nullptr;
     void* d_fh_line = nullptr;

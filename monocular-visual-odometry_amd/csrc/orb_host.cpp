@@ -180,6 +180,7 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
     free_dev(ctx->d_raw);
     free_dev(ctx->d_blur);
     free_dev(ctx->d_tabs);
+    free_dev(ctx->d_pyr_regs);
     free_dev(ctx->d_fh_slots);
     free_dev(ctx->d_fh_line);
     free_dev(ctx->d_fh_arrive);
@@ -204,6 +205,8 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
         while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
         return i;
     };
+    std::vector<PyrTileRegs> tile_regs((size_t)std::max(btiles, 1));
+    std::memset(tile_regs.data(), 0, tile_regs.size() * sizeof(PyrTileRegs));
     for (int l0 = 0; l0 < p.nlevels; l0 += 4) {
         bool fits = true;
         int need = 0;
@@ -226,11 +229,15 @@ int orb_setup_geometry(mvo_ctx* ctx, int w, int h) {
                     const int used = pyr_regions(P, tabs.data(), l, l - base, xlo, xhi, ylo, yhi, reg, off);
                     need = std::max(need, used);
                     fits = used <= PYR_LDS_BYTES;
+                    PyrTileRegs& T = tile_regs[(size_t)L.btile_off + (size_t)ty * L.btiles_x + tx];
+                    for (int d = 1; d <= l - base && d <= 4; ++d) T.reg[d] = reg[d], T.off[d] = off[d];
                 }
         }
         ctx->pyr_group_tiled[l0 / 4] = fits;
         ctx->pyr_group_lds[l0 / 4] = std::min(PYR_LDS_BYTES, (need + 255) & ~255);  // (dynamic LDS of the group's launch)
     }
+    MVO_HIP(hipMalloc((void**)&ctx->d_pyr_regs, tile_regs.size() * sizeof(PyrTileRegs)));
+    MVO_HIP(hipMemcpy(ctx->d_pyr_regs, tile_regs.data(), tile_regs.size() * sizeof(PyrTileRegs), hipMemcpyHostToDevice));
     ctx->pyr = P;
     ctx->pyr_bytes = bytes;
     ctx->img_w = w;

@@ -130,11 +130,11 @@ __device__ __forceinline__ int pyr_sample(const uint8_t* __restrict__ S, const P
 }
 
 __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict__ raw, PyrInfo P,
-                                                 const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact) {
+                                                 const ResizeEntry* __restrict__ tabs, int l0, int nl, int exact,
+                                                 const PyrTileRegs* __restrict__ tile_regs) {
     // region pool: dynamic LDS sized by the host for the hungriest tile of THIS launch (orb_setup_geometry: ~9 KB for the
     // 4-level 640 x 480 pyramid; the fixed 32 KB pool of round 3 let only four workgroups share a CU)
     MVO_DYN_LDS(uint8_t, lds);
-    __shared__ int sbox[4];
     const int tid = threadIdx.x;
     int l = l0;
     for (int k = 1; k < PYR_GROUP; ++k)
@@ -170,32 +170,13 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
         *reinterpret_cast<uint32_t*>(raw + L.off + (size_t)oy * L.stride + ox4) = out;
         return;
     }
-    // ---- interior footprint of the tile: bounding box of the reflected coordinates
-    if (tid < 64) {
-        const int x = reflect101(min(bx0 + tid, bw - 1) - MVO_BORDER, L.w);
-        int lo = x, hi = x;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, __shfl_xor(lo, o));
-            hi = max(hi, __shfl_xor(hi, o));
-        }
-        if (tid == 0) sbox[0] = lo, sbox[1] = hi;
-    } else if (tid < 128) {
-        const int y = reflect101(min(by0 + min(tid - 64, PT_H - 1), bh - 1) - MVO_BORDER, L.h);
-        int lo = y, hi = y;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, __shfl_xor(lo, o));
-            hi = max(hi, __shfl_xor(hi, o));
-        }
-        if (tid == 64) sbox[2] = lo, sbox[3] = hi;
-    }
+    // ---- the regions of the levels l-1 .. l-depth: this tile's entry of the table the host made with pyr_regions() when the
+    // image geometry was set up (the same function it checks the LDS fit with)
+    __shared__ PyrTileRegs sregs;
+    if (tid < 32) reinterpret_cast<int*>(&sregs)[tid] = reinterpret_cast<const int*>(tile_regs + (blockIdx.x + P.lv[l0].btile_off))[tid];
     __syncthreads();
-    // ---- the regions of the levels l-1 .. l-depth (same arithmetic as the host's LDS check, pyr_regions())
-    __shared__ PyrRegion reg[PYR_GROUP + 1];
-    __shared__ int regoff[PYR_GROUP + 1];
-    if (tid == 0) pyr_regions(P, tabs, l, depth, sbox[0], sbox[1], sbox[2], sbox[3], reg, regoff);
-    __syncthreads();
+    const PyrRegion* reg = sregs.reg;
+    const int* regoff = sregs.off;
     // Mapping of the region loops and of the tile: lane = column (two columns per lane for regions wider than 64), wave =
     // every fourth row.  What depends on the column alone -- its resize-table entry, the clamped neighbour, the byte offset in
     // the image -- is made ONCE per lane instead of once per sample, what depends on the row alone is wave-uniform (scalar
@@ -269,8 +250,13 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrBase B, uint8_t* __restrict_
 // ------------------------------------------------------------------------------------------------ FAST + NMS
 #define FT_W 64
 #define FT_H 16
-#define FT_PW 72  // tile + 4-px halo each side, bytes per LDS row (18 dwords)
-#define FT_PH (FT_H + 8)
+// The staged patch: the tile plus what its survivors read around them -- 15 rows above / below (the intensity-centroid disc), 16
+// columns left / right (a dword-aligned start; the disc needs 15) --, so that the whole survivor phase (7 x 7 Harris block, disc)
+// works on LDS: no global round trip per survivor (the waves of this kernel spent two thirds of their cycles waiting).
+#define FT_HX 16
+#define FT_HY 15
+#define FT_PW (FT_W + 2 * FT_HX)  // bytes per LDS row (24 dwords)
+#define FT_PH (FT_H + 2 * FT_HY)
 #define FT_SW (FT_W + 2)
 #define FT_SH (FT_H + 2)
 
@@ -460,10 +446,11 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     const int tx = t % L.tiles_x, ty = t / L.tiles_x;
     const int x0 = tx * FT_W, y0 = ty * FT_H;
     const uint8_t* base = raw + L.off;
-    // stage (FT_H+8) x 72 bytes; row/col origin = (y0-4, x0-4) in interior coordinates
+    // stage FT_PH x FT_PW bytes; row/col origin = (y0 - FT_HY, x0 - FT_HX) in interior coordinates (inside the level's 32-px
+    // frame and its 64-byte row stride for every tile)
     for (int i = tid; i < FT_PH * (FT_PW / 4); i += 256) {
         int r = i / (FT_PW / 4), c = i - r * (FT_PW / 4);
-        const uint8_t* p = base + (size_t)(y0 - 4 + r + MVO_BORDER) * L.stride + (x0 - 4 + MVO_BORDER) + 4 * c;
+        const uint8_t* p = base + (size_t)(y0 - FT_HY + r + MVO_BORDER) * L.stride + (x0 - FT_HX + MVO_BORDER) + 4 * c;
         pix[i] = *reinterpret_cast<const uint32_t*>(p);
     }
     __syncthreads();
@@ -484,7 +471,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         bool pass = false;
         if (i < FT_SH * FT_SW) {
             int sr = i / FT_SW, scx = i - sr * FT_SW;
-            const uint8_t* c = pb + (sr + 3) * FT_PW + (scx + 3);  // (ly, lx) = (sr-1, scx-1); +4 halo
+            const uint8_t* c = pb + (sr - 1 + FT_HY) * FT_PW + (scx - 1 + FT_HX);  // (ly, lx) = (sr-1, scx-1)
             int v = c[0];
             int d[16];
 #pragma unroll
@@ -504,7 +491,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     for (int q = tid; q < fq_n; q += 256) {
         const int i = fq[q];
         int sr = i / FT_SW, scx = i - sr * FT_SW;
-        const uint8_t* c = pb + (sr + 3) * FT_PW + (scx + 3);
+        const uint8_t* c = pb + (sr - 1 + FT_HY) * FT_PW + (scx - 1 + FT_HX);
         int v = c[0];
         int d[16];
 #pragma unroll
@@ -515,7 +502,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
 #else
     for (int i = tid; i < FT_SH * FT_SW; i += 256) {
         int sr = i / FT_SW, scx = i - sr * FT_SW;
-        const uint8_t* c = pb + (sr + 3) * FT_PW + (scx + 3);  // (ly, lx) = (sr-1, scx-1); +4 halo
+        const uint8_t* c = pb + (sr - 1 + FT_HY) * FT_PW + (scx - 1 + FT_HX);  // (ly, lx) = (sr-1, scx-1)
         int v = c[0];
         int d[16];
 #pragma unroll
@@ -557,7 +544,6 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     __syncthreads();
     const int total = rowstart[FT_H];
     u64* out = order_rows ? dslots + (size_t)blockIdx.x * FT_TILE_CAP * 2 : reinterpret_cast<u64*>(rows + (size_t)blockIdx.x * FT_TILE_CAP);
-    const int step = L.stride;
     const int ndisc = c_disc_n;
     // this lane's pixels of the intensity-centroid disc (k = lane, lane + 64, ...): offsets and (u, v) once per workgroup,
     // not once per survivor
@@ -571,7 +557,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         const int u = k < ndisc ? c_disc[2 * k] : 0, v = k < ndisc ? c_disc[2 * k + 1] : 0;
         duv[q] = (unsigned)(u + 15) | ((unsigned)(v + 15) << 8);  // (a padded lane: u = v = 0 -- it re-reads the centre with weight 0)
     }
-    const unsigned hb = lane < 49 ? (unsigned)(lane / 7 + 12) * (unsigned)step + (unsigned)(lane % 7 + 12) : 0u;  // this lane's Harris block position
+    const unsigned hb = lane < 49 ? (unsigned)(lane / 7 + FT_HY - 3) * FT_PW + (unsigned)(lane % 7 + FT_HX - 3) : 0u;  // this lane's Harris block position
     for (int i = wave; i < total; i += 4) {
         // survivor i -> (row, i-th set bit of the row's mask)
         int r = 0;
@@ -582,19 +568,16 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         const u64 m = rowmask[r];
         const int kth = i - rowstart[r];
         const bool me = ((m >> lane) & 1) && (int)__popcll(m & ((1ull << lane) - 1)) == kth;
-        // (one survivor per wave: its position is wave-uniform -- said to the compiler, so that the ~20 byte loads below take ONE
-        // scalar base + a 32-bit lane offset each instead of a 64-bit address per load: the kernel's register peak was here)
+        // (one survivor per wave: its position is wave-uniform)
         const int lx = __builtin_amdgcn_readfirstlane(__ffsll((long long)__ballot(me)) - 1);
         const int gx = x0 + lx, gy = y0 + r;
-        const uint8_t* lo = base + (size_t)(gy + MVO_BORDER - 15) * step + (MVO_BORDER + gx - 15);  // patch corner (scalar)
+        const uint8_t* lo = pb + r * FT_PW + lx;  // corner (gx - FT_HX, gy - FT_HY) of the survivor's patch in the staged bytes
         // HarrisResponses, blockSize 7: lanes 0..48 take one block position each
         int a = 0, b = 0, c = 0;
         if (lane < 49) {
-            unsigned o = hb;
-            MVO_OPAQUE(o);
-            const unsigned st = (unsigned)step;
-            const int p_l = lo[o - 1], p_r = lo[o + 1], p_u = lo[o - st], p_d = lo[o + st];
-            const int p_ul = lo[o - st - 1], p_ur = lo[o - st + 1], p_dl = lo[o + st - 1], p_dr = lo[o + st + 1];
+            const uint8_t* q = lo + hb;
+            const int p_l = q[-1], p_r = q[1], p_u = q[-FT_PW], p_d = q[FT_PW];
+            const int p_ul = q[-FT_PW - 1], p_ur = q[-FT_PW + 1], p_dl = q[FT_PW - 1], p_dr = q[FT_PW + 1];
             int Ix = (p_r - p_l) * 2 + (p_ur - p_ul) + (p_dr - p_dl);
             int Iy = (p_d - p_u) * 2 + (p_dl - p_ul) + (p_dr - p_ur);
             a = Ix * Ix;
@@ -609,11 +592,11 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
 #pragma unroll
         for (int q = 0; q < DISC_IT; ++q) {
             unsigned e = duv[q];
-            MVO_OPAQUE(e);
-            const unsigned ub = e & 0xffu, vb = (e >> 8) & 0xffu;
-            const int val = lo[vb * (unsigned)step + ub];
-            m10 += ((int)ub - 15) * val;
-            m01 += ((int)vb - 15) * val;
+            MVO_OPAQUE(e);  // (unpacked per survivor: hoisted, the twelve entries become three dozen live registers)
+            const int du = (int)(e & 0xffu) - 15, dv = (int)((e >> 8) & 0xffu) - 15;
+            const int val = lo[(dv + FT_HY) * FT_PW + (du + FT_HX)];
+            m10 += du * val;
+            m01 += dv * val;
         }
         m10 = wave_sum(m10);
         m01 = wave_sum(m01);
@@ -737,7 +720,7 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
 __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ raw, uint8_t* __restrict__ blur,
                                               PyrInfo P, int nlevels_active) {
     __shared__ uint32_t pix[22 * 18];
-    __shared__ uint16_t hb[22 * 64];
+    __shared__ __attribute__((aligned(8))) uint16_t hb[22 * 64];
     const int tid = threadIdx.x;
     const int lvl = find_level_by(P, blockIdx.x, 2);
     if (lvl >= nlevels_active) return;
@@ -756,6 +739,47 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ raw, u
     __syncthreads();
     const uint8_t* pb = reinterpret_cast<const uint8_t*>(pix);
     constexpr int G[7] = {18, 34, 48, 56, 48, 34, 18};
+#ifndef MVO_KERNEL_SIM
+    // Horizontal pass: one thread = four consecutive outputs of a row from THREE dword reads (the 10 bytes they share) -- every
+    // 7-tap sum is two v_dot4_u32_u8 over a byte window shifted into place by v_alignbyte.  Vertical pass: four outputs from seven
+    // 8-byte reads.  (One byte / one u16 per LDS instruction, this kernel's waves spent a third of their cycles queueing for the LDS.)
+    uint32_t* hb32 = reinterpret_cast<uint32_t*>(hb);  // row pitch 32 dwords (64 u16)
+    constexpr uint32_t GLO = 18u | 34u << 8 | 48u << 16 | 56u << 24, GHI = 48u | 34u << 8 | 18u << 16;
+    for (int item = tid; item < 22 * 16; item += 256) {
+        const int r = item >> 4, g = item & 15;
+        const uint32_t w0 = pix[r * 18 + g], w1 = pix[r * 18 + g + 1], w2 = pix[r * 18 + g + 2];
+        // output c = 4 g + j reads the row bytes 4 g + j + 1 .. 4 g + j + 7 (p[k - 3], p = row + c + 4)
+        const uint32_t a0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 1), GHI, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 1), GLO, 0u, false), false);
+        const uint32_t a1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 2), GHI, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 2), GLO, 0u, false), false);
+        const uint32_t a2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w2, w1, 3), GHI, __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(w1, w0, 3), GLO, 0u, false), false);
+        const uint32_t a3 = __builtin_amdgcn_udot4(w2, GHI, __builtin_amdgcn_udot4(w1, GLO, 0u, false), false);
+        hb32[r * 32 + 2 * g] = a0 | a1 << 16;  // (each sum <= 255 * 256 fits 16 bits)
+        hb32[r * 32 + 2 * g + 1] = a2 | a3 << 16;
+    }
+    __syncthreads();
+    const int r = tid >> 4, c4 = (tid & 15) * 4;
+    const int by = by0 + r;
+    if (by >= rows || bx0 + c4 >= L.stride) return;
+    uint32_t acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const uint2 h = *reinterpret_cast<const uint2*>(hb32 + (r + j) * 32 + 2 * (tid & 15));
+        acc0 += (uint32_t)G[j] * (h.x & 0xffffu);
+        acc1 += (uint32_t)G[j] * (h.x >> 16);
+        acc2 += (uint32_t)G[j] * (h.y & 0xffffu);
+        acc3 += (uint32_t)G[j] * (h.y >> 16);
+    }
+    const uint32_t accs[4] = {acc0, acc1, acc2, acc3};
+    uint32_t out = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 + k;
+        const int gx = bx0 + c - MVO_BORDER, gy = by - MVO_BORDER;
+        const uint32_t v = (gx >= 0 && gx < L.w && gy >= 0 && gy < L.h) ? (accs[k] + 32768u) >> 16 : (uint32_t)pb[(r + 3) * 72 + c + 4];
+        out |= v << (8 * k);
+    }
+    *reinterpret_cast<uint32_t*>(blur + L.off + (size_t)by * L.stride + bx0 + c4) = out;
+#else
     for (int i = tid; i < 22 * 64; i += 256) {
         int r = i >> 6, c = i & 63;
         const uint8_t* p = pb + r * 72 + c + 4;
@@ -781,6 +805,7 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ raw, u
         out |= v << (8 * k);
     }
     *reinterpret_cast<uint32_t*>(blur + L.off + (size_t)by * L.stride + bx0 + c4) = out;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ rBRIEF
@@ -988,7 +1013,7 @@ int orb_launch_pyramid(mvo_ctx* ctx, const uint8_t* d_img, int stride, int chann
         ProfScope ps(ctx, tiled ? "k_pyramid" : "k_pyramid_chain");
         if (tiled)
             hipLaunchKernelGGL(k_pyramid, dim3(nblk), dim3(256), g_pyr_full_pool ? PYR_LDS_BYTES : ctx->pyr_group_lds[l0 / PYR_GROUP],
-                               ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
+                               ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact, ctx->d_pyr_regs);
         else
             hipLaunchKernelGGL(k_pyramid_chain, dim3(nblk), dim3(256), 0, ctx->stream, B, ctx->d_raw, P, ctx->d_tabs, l0, nl, exact);
     }
