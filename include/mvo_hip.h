@@ -172,8 +172,8 @@ int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* s
  * workgroup (the 5-keyframe window of the benchmark: 28 CUs of one XCD, shortest solve) and solved by a launch of its own;
  * the detection kernel also puts its candidates in order on the device.
  * THROUGHPUT: many sequences are in flight on this GPU -- CU time counts, not latency.  While the offered load keeps it
- * busy (128 submissions in a row at a rate x solve time of >= 8 of its 16 slots; it leaves after 80 ms below 7), 5-keyframe windows are cut into ~720 observations
- * per workgroup (13 CUs) and go to the resident solver service: a grid that stays on the device (2 x 13 CUs of every XCD)
+ * busy (128 submissions in a row at a rate x solve time of >= 8 of its 16 slots; it leaves after 80 ms below 7), 5-keyframe windows are cut into ~670 observations
+ * per workgroup (14 CUs) and go to the resident solver service: a grid that stays on the device (2 x 14 CUs of every XCD)
  * and pulls windows from pinned mailboxes, no launch per window.  With less load the windows take the LATENCY cut on the
  * launch path and the CUs stay with whoever has work.  Detection leaves the interleaving of a tile row's candidates to the
  * calling thread (~75 us of host time per frame instead of ~8 us of kernel time), and descriptors are sampled from whole
@@ -208,7 +208,7 @@ int mvo_set_extract_concurrency(int n);
  * depend on them except through the summation plan of a BA window, which mvo_debug_get_ba_plan always reports:
  *   MVO_EXTRACT_CONCURRENCY [8]   start-up value of mvo_set_extract_concurrency
  *   MVO_BA_SERVICE [1]            resident solver service: 0 never, 1 by offered load (mvo_ba_set_mode), 2 always
- *   MVO_BA_XCD_RESERVE [4]        CUs per XCD a BA window leaves to other kernels (THROUGHPUT adds 2: 2 x 13 workgroups per XCD)
+ *   MVO_BA_XCD_RESERVE [4]        CUs per XCD a BA window leaves to other kernels (28 workgroups of a LATENCY window, 2 x 14 of THROUGHPUT windows)
  *   MVO_BA_WGS, MVO_BA_NSPLIT     force the workgroups / Schur column pieces of a window (= the debug keys ba_wgs, ...)
  *   MVO_BA_CU_SHARE [all]         CUs one launch-path grid may take
  *   MVO_BA_GROUPS [1], MVO_BA_ALIAS_SL [1], MVO_BA_BLOCK_SOLVER [0]   A/B switches of DESIGN.md 4.3 (grouped Schur exchange,

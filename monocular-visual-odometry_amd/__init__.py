@@ -333,7 +333,7 @@ class Context:
                 for i, k in enumerate(keeps)]
 
     def ba_set_mode(self, mode):
-        """mvo_ba_set_mode: "latency" (default, ~300 observations per workgroup), "throughput" (~720, resident grid under load) or
+        """mvo_ba_set_mode: "latency" (default, ~300 observations per workgroup), "throughput" (~670, resident grid under load) or
         "shared" (the throughput cut on the launch path only)."""
         self._chk(self.lib.mvo_ba_set_mode(self.h, {"latency": 0, "throughput": 1, "shared": 2}[mode]))
 

@@ -170,7 +170,7 @@ struct BaService {
     unsigned long long slot_seq[BA_SERVICE_SLOTS] = {0};
     BaJob* slot_job[BA_SERVICE_SLOTS] = {nullptr};
     int slots_busy = 0;
-    std::atomic<int> wgs_per_slot{13};  // workgroups per slot the NEXT grid gets (raised by planners, read by the scheduler)
+    std::atomic<int> wgs_per_slot{14};  // workgroups per slot the NEXT grid gets (raised by planners, read by the scheduler)
     int wgs_launched = 0;               // what the grid on the device was launched with (scheduler thread only)
     int next_slot = 0;                  // slot assignment rotates: no slot sits idle for long while others work
     unsigned long long beat = 0;        // heartbeat written to every mailbox while the grid is resident (scheduler thread only)
@@ -185,7 +185,7 @@ struct BaService {
     long long resident_jobs = 0, resident_starts = 0;
     double resident_cycles = 0;  // shader cycles of the windows the resident grid solved (sum; with `ms`: the clock under load)
     // Offered load of service-class windows = submission rate (over the last 32) x nominal solve time, in slots.  The
-    // resident grid holds 2 x 13 CUs of every XCD whether its slots have work or not: it only pays while most slots are
+    // resident grid holds 2 x 14 CUs of every XCD whether its slots have work or not: it only pays while most slots are
     // busy (24 sequences x [extraction + BA]: ~14 of 16); with less demand (tracking rows in the loop, few sequences) the
     // windows take the launch path with the latency cut and the CUs go to whoever has work.  Coming: 128 submissions in a row
     // at a rate that fills 10 slots; going: the 40-ms average below 8 slots for 80 ms in a row (BaService::wanted).
@@ -777,7 +777,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     // matching) cannot finish before it got CUs on EVERY XCD.  A solver workgroup owns its CU, so a window never takes a
     // whole XCD: `ba_xcd_reserve` CUs (default 4 of 32) stay free on each.  Latency mode (default): one window per XCD,
     // up to 28 workgroups for the 5-keyframe window of the benchmark (~330 edges each); throughput mode: two windows per
-    // XCD, up to 13 (~720 edges each, 6 CUs of an XCD left free), half the CUs per window at some 40 % more time per solve.  Larger windows get more
+    // XCD, up to 14 (~670 edges each, 4 CUs of an XCD left free), half the CUs per window at some 40 % more time per solve.  Larger windows get more
     // workgroups: a range holds at most 1024 edges and must fit the LDS.
     static const bool plan_trace = std::getenv("MVO_BA_PLAN_TRACE") != nullptr;  // development aid: the planner's LDS fits
     static const int env_reserve = std::getenv("MVO_BA_XCD_RESERVE") ? std::atoi(std::getenv("MVO_BA_XCD_RESERVE")) : -1;
@@ -790,7 +790,11 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     const bool svc_class = throughput && !p->fix_points && !g_ba_profile && !g_ba_block_solver && P.runnable && ba_solver_class(n) == 32;
     const bool svc = svc_class && !ctx->ba_never_resident && service_for(ctx->device).wanted();
     if (svc_class && !svc && g_ba_service == 1 && !ctx->ba_never_resident) throughput = false;
-    const int reserve = env_reserve >= 0 ? env_reserve : (throughput ? g_ba_xcd_reserve + 2 : g_ba_xcd_reserve);
+    // (round 5: the same reserve in both modes -- throughput mode = 2 x 14 workgroups per XCD.  Up to round 4 it left two CUs more
+    // (2 x 13): the frame kernels of 32 sequences did not fit the 4 CUs per XCD that 2 x 14 leave -- 3150 frames/s in round 3, 5125 vs
+    // 5063 in round 4; with the round-5 frame kernels: 5700 at 2 x 14 (solver slots 98 % busy, window 2.75 ms) vs 5060 at 2 x 13
+    // (3.10 ms); 2 x 15 starves the extraction for good (1800))
+    const int reserve = env_reserve >= 0 ? env_reserve : g_ba_xcd_reserve;
     const int per_xcd = std::max(8, 32 - std::max(0, std::min(reserve, 16)));
     const int g_cap = throughput ? per_xcd / 2 : per_xcd;
     if (throughput) {  // (monotonic: the grid is relaunched by its scheduler when a window needs more than it has)

@@ -53,7 +53,7 @@ def test_concurrent_contexts_reproduce_the_serial_results(mvo):
 
 def test_throughput_mode_follows_the_load(mvo, O):
     """mvo_ba_set_mode(THROUGHPUT) = "many sequences share this GPU": a lone caller's windows keep the launch path and the
-    latency cut (the resident grid would hold 2 x 13 CUs of every XCD for nothing); 24 callers submitting back to back
+    latency cut (the resident grid would hold 2 x 14 CUs of every XCD for nothing); 24 callers submitting back to back
     bring the resident solver service up, and their windows move to its slots.  Whatever the route, a result equals the ORACLE's
     result for one of the two cuts bit for bit."""
     pb = mvo.synth.ba_problem(5, 2000, 7)
@@ -67,7 +67,7 @@ def test_throughput_mode_follows_the_load(mvo, O):
     try:
         svc = ref.bundle_adjustment(*args, fix_points=False)
         plan_svc = ref.ba_plan()
-        assert plan_svc["wgs"] == 13
+        assert plan_svc["wgs"] == 14
     finally:
         mvo.debug_set("ba_service", 1)
     # what a result may be is said by the ORACLE (its blocked twin with the plan of either cut), not by an earlier GPU run
@@ -102,7 +102,7 @@ def test_throughput_mode_follows_the_load(mvo, O):
         t.join()
     assert not errors, errors[:3]
     stats = ref.ba_launch_stats()
-    assert stats["resident_windows"] > 200 and routes.count(13) > 200, (stats, routes.count(13), routes.count(28))
+    assert stats["resident_windows"] > 200 and routes.count(14) > 200, (stats, routes.count(14), routes.count(28))
     ref.close()
 
 
