@@ -43,7 +43,8 @@ int g_ba_xcd_reserve = 4;  // CUs per XCD a window leaves to other kernels
 int g_ba_service = 1;     // throughput-mode windows of the 5-pose class and the resident solver service: 0 = never, 1 = while the
                           // offered load fills most of its slots (BaService::wanted), 2 = always
 int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
-int g_ba_uv_global = 1;     // 0 = measurements always in LDS (the form before the second half of round 3)
+int g_ba_uv_global = std::getenv("MVO_BA_UV_GLOBAL") ? std::atoi(std::getenv("MVO_BA_UV_GLOBAL")) : 1;     // 0 = measurements always in LDS (the form before the second half of round 3)
+int g_ba_npar = std::getenv("MVO_BA_NPAR") ? std::atoi(std::getenv("MVO_BA_NPAR")) : 0;  // > 0: column pieces per chunk of the Schur chains (0 = one per idle wave)
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 int g_ba_groups = std::getenv("MVO_BA_GROUPS") ? std::atoi(std::getenv("MVO_BA_GROUPS")) : 1;  // 0 = one flat Schur exchange whatever the window's size (A/B)
@@ -866,6 +867,9 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 // (pieces side by side in every chunk: the chains of a chunk are half as long, the idle waves take the other half)
                 npar = do_schur ? std::max(1, BA_WAVES / npair) : 1;
                 if (q > 1 && g_ba_chunk_pieces == 1) npar = 1;
+                // (A/B: more pieces than idle waves -- a wave then carries two chains, the four SIMDs are loaded evenly: six chains
+                // on eight waves leave two SIMDs with two chains and two with one)
+                if (do_schur && g_ba_npar > 0 && npair * g_ba_npar <= 2 * BA_WAVES) npar = g_ba_npar;
                 if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
                 nsplit = nseq * npar;
                 const int msplit = (msteps + nsplit - 1) / nsplit;

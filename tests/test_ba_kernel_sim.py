@@ -263,3 +263,27 @@ def test_windows_of_changing_shape_on_one_context(mvo, O, simctx):
         _bitwise(mvo, O, simctx, mvo.synth.ba_problem(F, L, seed), fix_points=False, max_iterations=3)
     _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=True, max_iterations=3)
 
+
+
+def test_four_column_pieces_per_chunk_and_measurements_in_lds(mvo, O, simctx, simlib, monkeypatch):
+    """Plan variants of the throughput cut (A/B knobs): four column pieces per chunk -- twelve Schur chains on eight waves, a wave
+    carries two, the pieces of a pair meet behind one barrier and are added in piece order (the plan reports nsplit = 8, the blocked
+    oracle follows) --, and the measurements of a > 512-edge range kept in LDS instead of device memory.  Same bits as the oracle,
+    also under a shuffled thread order."""
+    simctx.ba_set_mode("throughput")
+    simlib.mvo_debug_set(b"ba_service", 2)
+    try:
+        simlib.mvo_debug_set(b"ba_npar", 4)
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=25)
+        assert plan["wgs"] == 14 and plan["nsplit"] == 8 and st["trials"] > st["iterations"]
+        monkeypatch.setenv("EMU_ORDER", "shuffle")
+        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 8), fix_points=False, max_iterations=6)
+        monkeypatch.delenv("EMU_ORDER")
+        simlib.mvo_debug_set(b"ba_npar", 0)
+        simlib.mvo_debug_set(b"ba_uv_global", 0)
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=12)
+        assert plan["wgs"] == 14
+    finally:
+        simlib.mvo_debug_set(b"ba_npar", 0)
+        simlib.mvo_debug_set(b"ba_uv_global", 1)
+        simlib.mvo_debug_set(b"ba_service", 1)
