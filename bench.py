@@ -419,6 +419,28 @@ def pmc_mfma_busy(kernel, pattern="r[0-9]*_pmc_mfma_busy.txt"):
     return best
 
 
+def pmc_grid_busy(pattern="r[0-9]*_pmc_grid_mfma_busy.txt"):
+    """The resident solver grid's matrix-core counters from the newest committed PMC pass ON THE GRID (profiles/r*_pmc_grid_mfma_busy.txt,
+    tools/pmc_summary.py grid: SQ_VALU_MFMA_BUSY_CYCLES summed over the grid's dispatches, the windows it solved in that pass, the
+    shader cycles they were resident and their workgroups).  dict or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+        try:
+            cols = None
+            for line in open(path):
+                if line.startswith("#"):
+                    continue
+                f = [x.strip() for x in line.split(",")]
+                if cols is None:
+                    cols = f
+                    continue
+                if f[0] == "k_ba_service":
+                    best = dict(zip(cols[1:], [float(x) for x in f[1:]]), source=os.path.relpath(path, ROOT))
+        except (OSError, ValueError, IndexError):
+            pass
+    return best
+
+
 def rank_cpu_slice(cpus, local_rank, local_world, gpu_numa=None, cpu_numa=None):
     """CPUs the threads of local rank `local_rank` are confined to when `local_world` ranks share one host (one
     rank per GPU, each with ~26 threads -- 24 sequence shards, the solver's scheduler, its completion thread).  Without it the
@@ -609,6 +631,7 @@ def main(argv=None, env=None):
         print(json.dumps(result))
     elif rank == 0:
         # ---- parity of what the timed loop produced (oracle = the checker; outside the timing)
+        plan_wgs = int(s0.ctx_ba.ba_plan()["wgs"]) if args.ba_mode == "rebuild" else 0   # (workgroups of the last timed window of shard 0)
         parity = None if args.no_parity else parity_check(args, shards, R["nframes"])
         trials = sum(a.ba_trials - b.ba_trials for a, b in zip(st_after, st_before))
         solves = sum(a.ba_solves - b.ba_solves for a, b in zip(st_after, st_before))
@@ -635,6 +658,8 @@ def main(argv=None, env=None):
                             shader_clock_ghz_under_load=round(launch.get("resident_cycles", 0.0) / max(launch["ms"] * 1e6, 1e-9), 3),
                             avg_window_kcycles=round(launch.get("resident_cycles", 0.0) / max(launch["windows"], 1) / 1e3, 1),
                             algorithmic_per_launch=flops, trials_per_solve=trials / max(solves, 1),
+                            resident_windows=launch.get("resident_windows", 0), resident_cycles=launch.get("resident_cycles", 0.0),
+                            workgroups_per_window=plan_wgs,
                             launch_thread_ms=launch.get("service_ms"), timed_region_ms=round(launch.get("elapsed_ms", 0.0), 2),
                             note="the resident grid is launched once and spans the timed region: duration = the region, work = the "
                                  "windows its 16 slots solved in it; avg_window_ms = mean solve time of a window on the device clock")
@@ -671,7 +696,15 @@ def main(argv=None, env=None):
             cls = 32 if args.ba_poses <= 5 else (64 if args.ba_poses <= 10 else 0)
             roof["resources"] = kernel_resources("k_ba_service<32,2>" if resident else ("k_ba_lm<false,64,2>" if config4 else "k_ba_lm<false,%d,1>" % cls))
             mb = pmc_mfma_busy("k_ba_lm", "r[0-9]*_config4_pmc_mfma_busy.txt") if config4 else (pmc_mfma_busy("k_ba_lm") if cls == 32 and not fix else None)
-            if mb:
+            gb = pmc_grid_busy() if resident else None
+            if gb and gb.get("resident_cycles", 0) > 0:
+                # the kernel this block names: matrix-core busy cycles of the resident grid per SIMD-cycle of the CUs its windows occupied
+                # in the PMC pass (windows x their shader cycles x workgroups x 4 SIMDs)
+                simd_cycles = gb["resident_cycles"] * max(gb.get("workgroups_per_window", 0), 1) * 4
+                roof["mfma_busy"] = round(gb.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / simd_cycles, 4)
+                roof["mfma_busy_source"] = gb["source"] + (" (k_ba_service: SQ_VALU_MFMA_BUSY_CYCLES / (resident cycles of its %d windows x %d workgroups x 4 SIMDs))"
+                                                          % (int(gb.get("windows", 0)), int(gb.get("workgroups_per_window", 0))))
+            elif mb and not resident:
                 # GRBM_GUI_ACTIVE is summed over the 8 XCDs (the launch's duration in cycles = an eighth of it); the profiled
                 # launches: one window of 28 workgroups (latency cut), or ~3.9 BA10 windows of 56
                 cus = 3.93 * 56 if config4 else 28

@@ -44,7 +44,6 @@ int g_ba_service = 1;     // throughput-mode windows of the 5-pose class and the
                           // offered load fills most of its slots (BaService::wanted), 2 = always
 int g_ba_edge_rows = -1;   // -1 = automatic, 0 = Jacobian rows in LDS only (or fail), 1 = first 512 edges of a range in registers
 int g_ba_uv_global = std::getenv("MVO_BA_UV_GLOBAL") ? std::atoi(std::getenv("MVO_BA_UV_GLOBAL")) : 1;     // 0 = measurements always in LDS (the form before the second half of round 3)
-int g_ba_npar = std::getenv("MVO_BA_NPAR") ? std::atoi(std::getenv("MVO_BA_NPAR")) : 0;  // > 0: column pieces per chunk of the Schur chains (0 = one per idle wave)
 int g_ba_chunk_pieces = 0;  // 1 = one column piece per chunk when the Schur operands take several chunks (the round-2 form)
 int g_ba_block_solver = 0;  // 1 = windows of <= 5 free poses use the workgroup-wide block LDL^T too
 int g_ba_groups = std::getenv("MVO_BA_GROUPS") ? std::atoi(std::getenv("MVO_BA_GROUPS")) : 1;  // 0 = one flat Schur exchange whatever the window's size (A/B)
@@ -867,9 +866,6 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 // (pieces side by side in every chunk: the chains of a chunk are half as long, the idle waves take the other half)
                 npar = do_schur ? std::max(1, BA_WAVES / npair) : 1;
                 if (q > 1 && g_ba_chunk_pieces == 1) npar = 1;
-                // (A/B: more pieces than idle waves -- a wave then carries two chains, the four SIMDs are loaded evenly: six chains
-                // on eight waves leave two SIMDs with two chains and two with one)
-                if (do_schur && g_ba_npar > 0 && npair * g_ba_npar <= 2 * BA_WAVES) npar = g_ba_npar;
                 if (env_nsplit && q == 1) npar = std::min(npar, env_nsplit);
                 nsplit = nseq * npar;
                 const int msplit = (msteps + nsplit - 1) / nsplit;
@@ -891,15 +887,19 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
                 P.npt = p->fix_points ? 1 : npt;
                 P.panel = (n + 1 > 32 || g_ba_block_solver) ? 1 : 0;
                 uarea = ba_uarea_doubles(do_schur ? 4 * npar * msplit : 0, ldu, pt_edges, maxEpose, nhp, G, p->fix_points);
-                // ranges of more than 512 edges (the throughput cut) keep their measurements in device memory: read once or
-                // twice per trial from L2, and 16 bytes per edge of LDS go to the U chunks instead (BA5 on 13 workgroups: two
-                // chunks where three were needed)
-                P.uv_global = (!all_lds && maxEg > BA_THREADS && g_ba_uv_global) ? 1 : 0;
-                // one column piece per chunk (no split tiles while U is live): the reduced system can live in the U area
-                P.alias_sl = (do_schur && npar == 1 && g_ba_alias_sl && uarea >= ba_solver_matrix_doubles(n, nlow + nhp, G, npair, npar)) ? 1 : 0;
-                P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel, P.uv_global,
-                                     P.alias_sl);
-                fits = P.lds <= BA_LDS_BUDGET;
+                // ranges of more than 512 edges (the throughput cut) MAY keep their measurements in device memory (read once or twice
+                // per trial from L2): 16 bytes per edge of LDS then go to the U chunks instead (BA5 on 13 workgroups: two chunks where
+                // three were needed).  Tried only when the LDS form does not fit this number of chunks (BA5 on 14 workgroups has the
+                // room for both: window 2.76 vs 2.79 ms with the measurements in LDS).
+                const bool uv_may_be_global = !all_lds && maxEg > BA_THREADS && g_ba_uv_global;
+                for (int uvg = 0; uvg <= (uv_may_be_global ? 1 : 0) && !fits; ++uvg) {
+                    P.uv_global = uvg;
+                    // one column piece per chunk (no split tiles while U is live): the reduced system can live in the U area
+                    P.alias_sl = (do_schur && npar == 1 && g_ba_alias_sl && uarea >= ba_solver_matrix_doubles(n, nlow + nhp, G, npair, npar)) ? 1 : 0;
+                    P.lds = ba_lds_bytes(F, n, nlow, nhp, G, npair, npar, nfree, maxEg, maxLg, p->fix_points, uarea, P.e2_edges, P.panel, P.uv_global,
+                                         P.alias_sl);
+                    fits = P.lds <= BA_LDS_BUDGET;
+                }
                 if (plan_trace)
                     std::fprintf(stderr, "[mvo plan] G %d rows_in_lds %d chunks %d pieces %d pt_passes %d maxEg %d maxLg %d uarea %zu B lds %zu B (budget %d) %s\n",
                                  G, all_lds, nseq, npar, P.npt, maxEg, maxLg, uarea * 8, P.lds, BA_LDS_BUDGET, fits ? "fits" : "-");

@@ -1197,34 +1197,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     const int st0 = ch * npar * msplit;  // first MFMA step of the chunk
                     const bool last = ch == nch - 1;
                     if (batch.use_mfma) {
-                        // chain a = (tile pair a % npair, column piece a / npair) runs on wave a % 8 (a wave carries up to two
-                        // chains: npair x npar <= 16); the piece-0 chain of a pair collects the other pieces of its pair from the
-                        // staging tiles behind ONE barrier and adds them in piece order
                         const int nchain = B.npair * npar;
-                        v4d acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-// adds this chunk's sum of pair `pr` (piece 0 in `acc`, the other pieces from the staging tiles, in piece order) to the running sum
-// of the wave's chain number `ai` and publishes it after the last chunk
-#define BA_SCHUR_COMBINE(acc, pr, a, ai)                                                                              \
-    {                                                                                                                 \
-        v4d r = (ai) == 0 ? run0 : run1;                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) r[j] = ch == 0 ? acc[j] : r[j] + acc[j];                        \
-        for (int s2 = 1; s2 < npar; ++s2) {                                                                           \
-            const double* src = split_stage + ((size_t)(pr) * (npar - 1) + (s2 - 1)) * 256;                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) r[j] += src[lane * 4 + j];                                  \
-        }                                                                                                             \
-        if ((ai) == 0) run0 = r;                                                                                      \
-        else if ((ai) == 1) run1 = r;                                                                                 \
-        if (last) {                                                                                                   \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
-                const int rr = (lane >> 4) + 4 * j, c = lane & 15;                                                    \
-                const int pk = (a) == wave ? pk4[j] : pkt_g[(pr) * 256 + rr * 16 + c];                                \
-                if (pk >= 0) {                                                                                        \
-                    if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], grp_l2);                \
-                    else W.Rl[pk] = r[j];                                                                             \
-                }                                                                                                     \
-            }                                                                                                         \
-        }                                                                                                             \
-    }
                         int ai = 0;
                         for (int a = wave; a < nchain; a += BA_WAVES, ++ai) {
                             const int pr = a % B.npair, sp = a / B.npair;
@@ -1234,31 +1207,40 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                                 ++ti;
                             }
                             const int m0 = min(st0 + sp * msplit, msteps) - st0, m1 = min(st0 + (sp + 1) * msplit, msteps) - st0;
-                            const v4d acc = schur_chain(W.U, ldu, ti, ti + rem, m0, m1, lane);
+                            v4d acc = schur_chain(W.U, ldu, ti, ti + rem, m0, m1, lane);
                             STAMP(4);
-                            if (npar == 1) {  // (no other piece to wait for; windows of many tile pairs carry three chains per wave)
-                                BA_SCHUR_COMBINE(acc, pr, a, ai)
-                            } else if (sp > 0) {
+                            if (sp > 0) {
                                 double* dst = split_stage + ((size_t)pr * (npar - 1) + (sp - 1)) * 256;
 #pragma unroll
                                 for (int j = 0; j < 4; ++j) dst[lane * 4 + j] = acc[j];
-                            } else if (ai == 0) {
-                                acc0 = acc;
-                            } else {
-                                acc1 = acc;
+                            }
+                            if (npar > 1) __syncthreads();  // (uniform: npair x npar <= 8, every wave makes exactly one trip)
+                            if (sp == 0) {
+                                v4d r = ai == 0 ? run0 : run1;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) r[j] = ch == 0 ? acc[j] : r[j] + acc[j];
+                                for (int s2 = 1; s2 < npar; ++s2) {
+                                    const double* src = split_stage + ((size_t)pr * (npar - 1) + (s2 - 1)) * 256;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) r[j] += src[lane * 4 + j];
+                                }
+                                if (ai == 0) run0 = r;
+                                else if (ai == 1) run1 = r;
+                                if (last) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        const int rr = (lane >> 4) + 4 * j, c = lane & 15;
+                                        const int pk = a == wave ? pk4[j] : pkt_g[pr * 256 + rr * 16 + c];
+                                        if (pk >= 0) {
+                                            if (G > 1) gstore_d(B.xP + 2 * ((size_t)g * npk + pk), tag0 + tagA, r[j], grp_l2);
+                                            else W.Rl[pk] = r[j];
+                                        }
+                                    }
+                                }
                             }
                         }
-                        if (npar > 1) {
-                            __syncthreads();  // (uniform; npair x npar <= 16: a wave carries at most two chains)
-                            ai = 0;
-                            for (int a = wave; a < nchain; a += BA_WAVES, ++ai) {
-                                const int pr = a % B.npair;
-                                if (a / B.npair != 0) continue;
-                                if (ai == 0) BA_SCHUR_COMBINE(acc0, pr, a, ai)
-                                else BA_SCHUR_COMBINE(acc1, pr, a, ai)
-                            }
-                        }
-#undef BA_SCHUR_COMBINE
+                        // waves without a chain still meet the barrier of the split combination
+                        if (npar > 1 && wave >= nchain) __syncthreads();
                     } else {  // validation path: the same chains, one packed entry per thread and pass
                         for (int pk = tid; pk < nlow; pk += BA_THREADS) {
                             int i, j;

@@ -7,7 +7,7 @@
 #include "mvo_internal.h"
 
 int ba_demand_replay(const double* times, int n, unsigned char* decisions);  // ba_host.cpp
-extern int g_ba_use_mfma, g_ba_wgs, g_ba_same_l2, g_ba_profile, g_ba_block_solver, g_ba_cu_share, g_ba_xcd_reserve, g_ba_edge_rows, g_ba_service, g_ba_chunk_pieces, g_ba_uv_global, g_ba_npar;  // ba_host.cpp
+extern int g_ba_use_mfma, g_ba_wgs, g_ba_same_l2, g_ba_profile, g_ba_block_solver, g_ba_cu_share, g_ba_xcd_reserve, g_ba_edge_rows, g_ba_service, g_ba_chunk_pieces, g_ba_uv_global;  // ba_host.cpp
 // mvo_debug_set("ba_*", v): validation paths and planner overrides the tests compare
 int ba_debug_set(const char* key, int value) {
     if (!std::strcmp(key, "ba_mfma")) g_ba_use_mfma = value;
@@ -21,7 +21,6 @@ int ba_debug_set(const char* key, int value) {
     else if (!std::strcmp(key, "ba_service")) g_ba_service = value;
     else if (!std::strcmp(key, "ba_chunk_pieces")) g_ba_chunk_pieces = value;
     else if (!std::strcmp(key, "ba_uv_global")) g_ba_uv_global = value;
-    else if (!std::strcmp(key, "ba_npar")) g_ba_npar = value;
     else return MVO_ERR_INVALID;
     return MVO_OK;
 }

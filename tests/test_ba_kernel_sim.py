@@ -265,25 +265,22 @@ def test_windows_of_changing_shape_on_one_context(mvo, O, simctx):
 
 
 
-def test_four_column_pieces_per_chunk_and_measurements_in_lds(mvo, O, simctx, simlib, monkeypatch):
-    """Plan variants of the throughput cut (A/B knobs): four column pieces per chunk -- twelve Schur chains on eight waves, a wave
-    carries two, the pieces of a pair meet behind one barrier and are added in piece order (the plan reports nsplit = 8, the blocked
-    oracle follows) --, and the measurements of a > 512-edge range kept in LDS instead of device memory.  Same bits as the oracle,
-    also under a shuffled thread order."""
+def test_measurements_in_lds_or_device_memory(mvo, O, simctx, simlib):
+    """A > 512-edge range keeps its measurements in LDS when that costs no extra chunk of U (BA5 on 14 workgroups), in device
+    memory otherwise (forced here with the A/B knob on 13 workgroups, where the LDS form needs three chunks): the oracle's bits
+    either way."""
     simctx.ba_set_mode("throughput")
     simlib.mvo_debug_set(b"ba_service", 2)
     try:
-        simlib.mvo_debug_set(b"ba_npar", 4)
-        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=25)
-        assert plan["wgs"] == 14 and plan["nsplit"] == 8 and st["trials"] > st["iterations"]
-        monkeypatch.setenv("EMU_ORDER", "shuffle")
-        _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 8), fix_points=False, max_iterations=6)
-        monkeypatch.delenv("EMU_ORDER")
-        simlib.mvo_debug_set(b"ba_npar", 0)
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=12)
+        assert plan["wgs"] == 14 and plan["nsplit"] == 4
+        simlib.mvo_debug_set(b"ba_wgs", 13)
+        st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=12)
+        assert plan["wgs"] == 13 and plan["nsplit"] == 4
         simlib.mvo_debug_set(b"ba_uv_global", 0)
         st, plan = _bitwise(mvo, O, simctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False, max_iterations=12)
-        assert plan["wgs"] == 14
+        assert plan["wgs"] == 13 and plan["nsplit"] == 6      # (three chunks of two pieces)
     finally:
-        simlib.mvo_debug_set(b"ba_npar", 0)
+        simlib.mvo_debug_set(b"ba_wgs", 0)
         simlib.mvo_debug_set(b"ba_uv_global", 1)
         simlib.mvo_debug_set(b"ba_service", 1)

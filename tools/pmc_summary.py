@@ -4,6 +4,9 @@ bench.py reads (profiles/rNN_pmc_fetch_write_size_per_kernel.csv) or into a plai
   python tools/pmc_summary.py fetch_write <fetch_counter_collection.csv> <write_counter_collection.csv> <out.csv> "<command>" [windows]
       (windows = BA windows the profiled command solved: adds the row k_ba_service_per_window = the resident grid's totals / windows)
   python tools/pmc_summary.py table <counter_collection.csv> <out.txt> "<command>"
+  python tools/pmc_summary.py grid <counter_collection.csv> <log with the bench JSON line of that pass> <out.txt> "<command>"
+      (the resident solver grid: its counters summed over its dispatches next to the windows it solved, their workgroups and the
+      shader cycles they were resident -- what bench.py's roofline.mfma_busy divides by)
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KB per dispatch; the summary keeps them as reported (the gfx950
 correction -- FETCH_SIZE counts a wide coalesced read at half its bytes -- is applied by the reader, per access pattern)."""
@@ -45,6 +48,21 @@ def main():
                 if k == "k_ba_service" and windows > 0:
                     # the resident grid is a handful of dispatches that span the run: per window = its totals / the windows solved
                     o.write("k_ba_service_per_window,%d,%.2f,%.2f\n" % (windows, sum(fv) / windows, sum(wv) / windows))
+    elif mode == "grid":
+        import json
+        src, log, out, cmd = sys.argv[2:6]
+        A = collect(src)
+        line = [ln for ln in open(log, errors="replace").read().splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+        r = json.loads(line)["roofline"]
+        names = sorted({c for c in A.get("k_ba_service", {})})
+        with open(out, "w") as o:
+            o.write("# rocprofv3 --pmc %s --kernel-trace, %s\n" % (" ".join(names), cmd))
+            o.write("# k_ba_service: counters SUMMED over its dispatches of the pass; windows / resident_cycles / workgroups_per_window from the "
+                    "JSON line of the same pass (roofline.resident_windows, .resident_cycles, .workgroups_per_window)\n")
+            o.write("kernel,dispatches," + ",".join(names) + ",windows,resident_cycles,workgroups_per_window\n")
+            g = A.get("k_ba_service", {})
+            o.write("k_ba_service,%d,%s,%d,%.0f,%d\n" % (max([len(v) for v in g.values()] or [0]), ",".join("%.1f" % sum(g[c]) for c in names),
+                                                     int(r.get("resident_windows", 0)), float(r.get("resident_cycles", 0)), int(r.get("workgroups_per_window", 0))))
     else:
         src, out, cmd = sys.argv[2:5]
         A = collect(src)
