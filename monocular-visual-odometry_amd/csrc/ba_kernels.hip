@@ -770,25 +770,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     if (nslot > 1 && have1) BA_EDGE_FROM_LDS(BODY, tid + BA_THREADS)         \
     if (nslot == 0)                                                          \
         for (int el0_ = tid; el0_ < Eg; el0_ += BA_THREADS) BA_EDGE_FROM_LDS(BODY, el0_)
-// the same without the second edge of a thread (SLOTS = 2): the phases that spell their own pass over the edges behind 512 -- their rows
-// live in LDS, so ANY thread can work on them: (edge, landmark coordinate) items over all 512 threads instead of whole edges on the
-// first Eg - 512 threads while the others wait (a range of the 2 x 14 cut has ~160 of them: the pass costs a third of an edge)
-#define BA_EDGES_NOT_SECOND(BODY)                                            \
-    if (nslot > 0 && have0) do { BODY(tid, er, e0_l, e0_sl, ee0) } while (0); \
-    if (nslot == 0)                                                          \
-        for (int el0_ = tid; el0_ < Eg; el0_ += BA_THREADS) BA_EDGE_FROM_LDS(BODY, el0_)
-// Y[k], Y[3 + k] of an LDS-resident edge (rows at q_: a0 | a1 | x | e~) exactly as edge_Y spells them
-#define BA_E2_YK(q_, cc_, k_, yk_, y3k_)                                                        \
-    if ((k_) == 0) {                                                                            \
-        yk_ = (q_)[12] * (cc_)[0] + (q_)[13] * (cc_)[1] + (q_)[14] * (cc_)[3];                   \
-        y3k_ = (q_)[15] * (cc_)[0] + (q_)[16] * (cc_)[1] + (q_)[17] * (cc_)[3];                  \
-    } else if ((k_) == 1) {                                                                     \
-        yk_ = (q_)[13] * (cc_)[2] + (q_)[14] * (cc_)[4];                                         \
-        y3k_ = (q_)[16] * (cc_)[2] + (q_)[17] * (cc_)[4];                                        \
-    } else {                                                                                    \
-        yk_ = (q_)[14] * (cc_)[5];                                                              \
-        y3k_ = (q_)[17] * (cc_)[5];                                                             \
-    }
 
     // ---- pose-block chains: how the rows [A~ | e~] are staged (constant for the whole solve, made once).  Pass q of
     // `hp_npass` holds slice q of EVERY pose: edges [s_p + q h_p, min(e_p, s_p + (q + 1) h_p)), h_p = ceil(n_p / npass) rounded up
@@ -1206,26 +1187,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                         const bool has_dups = B.max_dup > 0;
                         const bool whole = c0 == 0 && c1 >= ncol;  // (every landmark column lies inside the chunk)
                         for (int rank = 0; rank <= B.max_dup; ++rank) {
-                            BA_EDGES_NOT_SECOND(BA_BODY_UFILL)
-                            if (nslot > 1) {  // the edges behind 512, one (edge, landmark coordinate) per item
-                                for (int it = tid; it < 3 * (Eg - BA_THREADS); it += BA_THREADS) {
-                                    const int e2 = it / 3, k = it - 3 * e2, el = BA_THREADS + e2;
-                                    const int l = W.ept[el], sl = sSlot[W.epose[el]];
-                                    const int colg = 3 * l + k;
-                                    if (sl < 0 || colg < c0 || colg >= c1 || (has_dups && W.dup[el] != rank)) continue;
-                                    const double* q = W.E2 + BA_E2S * e2;
-                                    const double* cc = W.Cc + BA_XS * l;
-                                    double yk, y3k;
-                                    BA_E2_YK(q, cc, k, yk, y3k)
-                                    double* u = W.U + u_index(colg - c0, 6 * sl, ldu);
-#pragma unroll
-                                    for (int c = 0; c < 6; ++c) {
-                                        const double v = q[c] * yk + q[6 + c] * y3k;
-                                        if (has_dups && rank > 0) u[c] = u[c] + v;
-                                        else u[c] = 0.0 + v;
-                                    }
-                                }
-                            }
+                            BA_EDGES(BA_BODY_UFILL)
                             __syncthreads();
                         }
                     }
@@ -1493,29 +1455,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         _Pragma("unroll") for (int k = 0; k < 3; ++k) t3[k] = Y[k] * s0 + Y[3 + k] * s1; \
     }                                                                          \
     _Pragma("unroll") for (int k = 0; k < 3; ++k) W.U[3 * (el) + k] = t3[k];
-                BA_EDGES_NOT_SECOND(BA_BODY_BACKSUB)
-                if (nslot > 1) {
-                    for (int it = tid; it < 3 * (Eg - BA_THREADS); it += BA_THREADS) {
-                        const int e2 = it / 3, k = it - 3 * e2, el = BA_THREADS + e2;
-                        const int sl = sSlot[W.epose[el]];
-                        double t = 0.0;
-                        if (sl >= 0) {
-                            const double* q = W.E2 + BA_E2S * e2;
-                            const double* sx = sSol + 6 * sl;
-                            double s0 = 0, s1 = 0;
-#pragma unroll
-                            for (int c = 0; c < 6; ++c) {
-                                s0 = __builtin_fma(q[c], sx[c], s0);
-                                s1 = __builtin_fma(q[6 + c], sx[c], s1);
-                            }
-                            const double* cc = W.Cc + BA_XS * W.ept[el];
-                            double yk, y3k;
-                            BA_E2_YK(q, cc, k, yk, y3k)
-                            t = yk * s0 + y3k * s1;
-                        }
-                        W.U[3 * el + k] = t;
-                    }
-                }
+                BA_EDGES(BA_BODY_BACKSUB)
             }
             STAMP(14);
             __syncthreads();
