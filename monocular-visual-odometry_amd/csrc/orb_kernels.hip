@@ -7,18 +7,20 @@
 // work bounded by HBM/L2 traffic (in practice by latency); three launches per frame:
 //   k_pyramid       every level of a group of up to four levels in ONE launch: workgroup = one 64x16 tile of one level;
 //                   the tile's footprint is traced down the bilinear chain to the group's base (the BGR image, or the
-//                   last level of the previous group), the base region is converted once into LDS, every intermediate
-//                   level's region is built in LDS, the tile is written from the region one level below.  No level
-//                   waits for another one: no inter-workgroup dependency, no launch per level.  k_pyramid_chain (every
+//                   last level of the previous group) -- the regions come from a per-tile table the host makes once per image
+//                   geometry --, the base region is converted once into LDS, every intermediate level's region is built in
+//                   LDS, the tile is written from the region one level below (lane = column, wave = every fourth row).  No
+//                   level waits for another one: no inter-workgroup dependency, no launch per level.  k_pyramid_chain (every
 //                   pixel walks the chain itself, 4^depth base samples) is the fallback when the regions do not fit LDS
-//   k_fast_harris   FAST-9/16 score + 3x3 NMS + 31-px border on a 64x16 tile (one 64-bit survivor mask per tile row via
-//                   wave ballot), then ONE WAVE per survivor of the tile: 7x7 Harris (49 lanes) + IC angle over the
-//                   749-px disc, wave shuffle reductions; the finished 16-byte records go into the tile's slot of a
-//                   pinned host buffer (no candidate compaction on the device, no copy dispatch)
+//   k_fast_harris   the 64x16 tile plus a 15-row / 16-column apron staged in LDS; FAST-9/16 quick test on every pixel, the few
+//                   that pass are queued and scored densely; 3x3 NMS + 31-px border (one 64-bit survivor mask per tile row
+//                   via wave ballot); then ONE WAVE per survivor of the tile, entirely on the staged bytes: 7x7 Harris (49
+//                   lanes) + IC angle over the 749-px disc, wave sums by DPP row shifts; the finished 16-byte records go into
+//                   the tile's slot of a pinned host buffer (no candidate compaction on the device, no copy dispatch)
 //   k_brief         one WAVE per keypoint: the 45x56 raw window is staged in LDS, blurred there (separable 7x7
 //                   fixed-point Gaussian, the keypoint's window only) and sampled: 512 rotated taps, 4 ballots = 256 bits
-//   k_blur          whole-level blur + k_brief_sample: the same descriptors for a ctx in throughput mode (a sixth of the
-//                   instructions per frame); also behind mvo_debug_get_level(blurred)
+//   k_blur          whole-level blur (dword LDS reads, 7-tap sums as two v_dot4_u32_u8) + k_brief_sample: the same descriptors
+//                   for a ctx in throughput mode (a sixth of the instructions per frame); also behind mvo_debug_get_level(blurred)
 // Compiled with -ffp-contract=off: the float expressions (Harris response, fastAtan2, tap rotation) are
 // canonical arithmetic and must round exactly like the oracle.
 #include "mvo_internal.h"
@@ -272,31 +274,6 @@ __device__ __forceinline__ int find_level_by(const PyrInfo& P, int idx, int whic
     return l;
 }
 
-// A/B switches of k_fast_harris (csrc/Makefile `alt` target; defaults = the shipped form)
-#ifndef MVO_FH_COMPACT
-#define MVO_FH_COMPACT 1  // 1: pixels that pass the FAST quick test are queued and scored densely; 0: scored in place (round 4)
-#endif
-#ifndef MVO_FH_DPP
-#define MVO_FH_DPP 1      // 1: wave sums of the survivor phase by DPP row shifts; 0: by ds_bpermute shuffles (round 4)
-#endif
-#ifndef MVO_FH_PACKED
-#define MVO_FH_PACKED 0   // 1: the sliding min / max of the score on packed int16 pairs
-#endif
-#if defined(MVO_KERNEL_SIM)
-#undef MVO_FH_DPP
-#define MVO_FH_DPP 0
-#undef MVO_FH_PACKED
-#define MVO_FH_PACKED 0
-#endif
-#if MVO_FH_PACKED
-typedef short mvo_s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mvo_s16x2, a), __builtin_bit_cast(mvo_s16x2, b)));
-}
-__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
-    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(mvo_s16x2, a), __builtin_bit_cast(mvo_s16x2, b)));
-}
-#endif
 // cornerScore<16> in two halves.  d[k] = centre - circle[k].
 // fast_quick_test: can the pixel be a FAST-9 corner at threshold thr at all?  (bit masks of the circle pixels darker / brighter
 // than the centre by more than thr; nine consecutive set bits in either)
@@ -319,33 +296,6 @@ __device__ __forceinline__ bool fast_quick_test(const int (&d)[16], int thr) {
 // fast_score_full: the largest threshold for which the pixel is still a FAST-9 corner (for a pixel that passed the quick test):
 // max over the 16 arcs of 9 consecutive circle pixels of min(d) and of min(-d), by a sliding minimum / maximum with doubling.
 __device__ __forceinline__ int fast_score_full(const int (&d)[16], int thr) {
-#if MVO_FH_PACKED
-    // two differences per register (|d| <= 255 fits int16): P[j] = (d[2j], d[2j+1]); every level of the doubling is one
-    // v_pk_min_i16 / v_pk_max_i16 per pair (Q = the pairs shifted by one element; shifts by 2 / 4 / 8 elements are whole registers)
-    uint32_t P[8], mn[8], mx[8], t[8], u[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) P[j] = ((uint32_t)d[2 * j] & 0xffffu) | ((uint32_t)d[2 * j + 1] << 16);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const uint32_t Q = __builtin_amdgcn_alignbit(P[(j + 1) & 7], P[j], 16);  // (d[2j+1], d[2j+2])
-        mn[j] = pk_min_i16(P[j], Q);
-        mx[j] = pk_max_i16(P[j], Q);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = pk_min_i16(mn[j], mn[(j + 1) & 7]), u[j] = pk_max_i16(mx[j], mx[(j + 1) & 7]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mn[j] = pk_min_i16(t[j], t[(j + 2) & 7]), mx[j] = pk_max_i16(u[j], u[(j + 2) & 7]);
-    uint32_t a = pk_min_i16(mn[0], P[4]), b = pk_max_i16(mx[0], P[4]);
-#pragma unroll
-    for (int j = 1; j < 8; ++j) {
-        a = pk_max_i16(a, pk_min_i16(mn[j], P[(j + 4) & 7]));  // max over k of min(d[k .. k+8])
-        b = pk_min_i16(b, pk_max_i16(mx[j], P[(j + 4) & 7]));  // min over k of max(d[k .. k+8])
-    }
-    const int A = max((int)(int16_t)(a & 0xffffu), (int)(int16_t)(a >> 16));
-    const int Bn = min((int)(int16_t)(b & 0xffffu), (int)(int16_t)(b >> 16));
-    const int best = max(A, -Bn);
-    return best > thr ? best - 1 : 0;
-#else
     int mn2[16], mx2[16], mn4[16], mx4[16], mn8[16], mx8[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -370,7 +320,6 @@ __device__ __forceinline__ int fast_score_full(const int (&d)[16], int thr) {
     }
     int best = max(A, B);
     return best > thr ? best - 1 : 0;
-#endif
 }
 
 // cv::fastAtan2 (degrees)
@@ -396,7 +345,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 __device__ __forceinline__ int wave_sum(int v) {
-#if MVO_FH_DPP
+#ifndef MVO_KERNEL_SIM
     // Inclusive scan inside each row of 16 lanes by DPP row shifts (a lane outside the row contributes 0), then the row totals
     // are carried over by the two row broadcasts: lane 63 holds the sum of the wave and is read back as a scalar.  Six VALU
     // instructions instead of six ds_bpermute round trips (each ~60 cycles of dependent latency: five sums per survivor were the
@@ -416,11 +365,13 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 // k_fast_harris: one 64 x 16 tile per workgroup, everything cv::ORB::detect computes per corner in ONE launch:
-//   1. FAST-9/16 score of the tile + 1-px ring (LDS), 3x3 non-maximum suppression, 31-px image border: one 64-bit
-//      survivor mask per tile row via wave ballot;
+//   1. FAST-9/16 score of the tile + 1-px ring (from the staged patch in LDS: quick test everywhere, the pixels that pass are
+//      queued and scored densely), 3x3 non-maximum suppression, 31-px image border: one 64-bit survivor mask per tile row
+//      via wave ballot;
 //   2. the tile's survivors, row-major (= the order cv::FAST emits inside the tile), one WAVE per survivor round-robin:
-//      7x7 Harris response (49 lanes, Sobel sums) and the intensity-centroid angle over the 749-px disc, wave shuffle
-//      reductions -- the same integer sums and float expressions as the stand-alone form had;
+//      7x7 Harris response (49 lanes, Sobel sums) and the intensity-centroid angle over the 749-px disc, both read from
+//      the staged patch (its apron covers the disc), wave sums by DPP -- the same integer sums and float expressions as
+//      the stand-alone form had;
 //   3. the finished 16-byte records go into the tile's slot in device memory, the 16 line counts beside them;
 //   4. the workgroup that arrives LAST for its tile row (arrival counter per row, self re-arming) puts the row in order:
 //      the global order (level, row, column) = the order cv::FAST emits interleaves the tiles of a tile row line by line
@@ -458,7 +409,6 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
     // FAST circle (x, y), same enumeration as the oracle
     constexpr int CX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
     constexpr int CY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
-#if MVO_FH_COMPACT
     // The quick test decides for every pixel of the tile + ring; the few that pass (a few per cent even on busy images) are
     // queued and scored DENSELY afterwards: scored in place, nearly every wave would walk the whole sliding-minimum code for
     // a handful of live lanes (that code was ~40 % of the kernel's instructions).
@@ -499,18 +449,6 @@ __global__ __launch_bounds__(256) void k_fast_harris(const uint8_t* __restrict__
         sc[sr * 68 + scx] = (uint8_t)fast_score_full(d, thr);
     }
     __syncthreads();
-#else
-    for (int i = tid; i < FT_SH * FT_SW; i += 256) {
-        int sr = i / FT_SW, scx = i - sr * FT_SW;
-        const uint8_t* c = pb + (sr - 1 + FT_HY) * FT_PW + (scx - 1 + FT_HX);  // (ly, lx) = (sr-1, scx-1)
-        int v = c[0];
-        int d[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) d[k] = v - (int)c[CX[k] + CY[k] * FT_PW];
-        sc[sr * 68 + scx] = (uint8_t)(fast_quick_test(d, thr) ? fast_score_full(d, thr) : 0);
-    }
-    __syncthreads();
-#endif
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the survivor loop below works on scalar addresses)
     for (int ly = wave; ly < FT_H; ly += 4) {
         const int gx = x0 + lane, gy = y0 + ly;
