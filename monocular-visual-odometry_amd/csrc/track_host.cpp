@@ -360,7 +360,16 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     uint8_t* h_mask = ctx->h_pin + o_mask;
     const TrackCamera cam{fx, fy, cx, cy};
     const float thr2 = (float)((double)reprojection_error * (double)reprojection_error);
-    if ((r = track_launch_pnp_hypotheses(ctx, d_p3, d_p2, n, d_subsets, n_hyp, cam, thr2, s->d_models, s->d_counts, s->d_masks,
+    // How many hypotheses go first.  The sequential loop of RANSACPointSetRegistrator::run shortens itself as soon as a good model
+    // turns up (three quarters of the pairs inliers: ~27 of the 100 iterations) -- a lone sequence evaluates all `iterations`
+    // hypotheses at once anyway (they run side by side: the price of one), but where many sequences share the GPU a hypothesis is
+    // 200 us of a CU: contexts in THROUGHPUT / SHARED mode evaluate the first 32, let the replay of the loop's bookkeeping say
+    // whether the loop would have gone on, and only then launch the rest (one more round trip in that case).  The result is what
+    // the sequential loop produces either way.  MVO_PNP_CHUNK: 0 = never, n > 0 = first n for every ctx (A/B).
+    static const int env_chunk = std::getenv("MVO_PNP_CHUNK") ? std::atoi(std::getenv("MVO_PNP_CHUNK")) : -1;
+    const bool chunked = n != kModel && n_hyp > 48 && (env_chunk >= 0 ? env_chunk > 0 : ctx->ba_throughput_mode != 0);
+    const int first = chunked ? std::min(n_hyp, env_chunk > 0 ? env_chunk : 32) : n_hyp;
+    if ((r = track_launch_pnp_hypotheses(ctx, d_p3, d_p2, n, d_subsets, first, cam, thr2, s->d_models, s->d_counts, s->d_masks,
                                          reinterpret_cast<double*>(h_models), reinterpret_cast<int32_t*>(h_counts))))
         return r;
     // The refinement kernel replays the sequential bookkeeping of RANSACPointSetRegistrator::run over the counts and
@@ -368,7 +377,7 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     // the result and only launches again if it disagrees -- one host round trip per call.
     const int mode = n == kModel ? 1 : 0;
     const double dev_conf = g_pnp_replay_skew ? 0.5 : confidence;
-    if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp, dev_conf,
+    if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, first, dev_conf,
                                      mode == 1 ? 0 : -1, mode, s->d_Mg, s->d_mg, h_mask, reinterpret_cast<double*>(h_out))))
         return r;
     auto fetch = [&]() -> int {
@@ -376,32 +385,49 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
         return MVO_OK;
     };
     if ((r = fetch())) return r;
-    s->counts.assign(reinterpret_cast<int32_t*>(h_counts), reinterpret_cast<int32_t*>(h_counts) + n_hyp);
-    s->models.resize((size_t)n_hyp * 12);
-    std::memcpy(s->models.data(), h_models, (size_t)n_hyp * 96);
-    s->info[5] = n_hyp;
+    int evaluated = first;
     int best = -1;
     if (mode == 1) {  // "model_points == npoints": the kernel result is the answer and every pair an inlier
         best = 0;
         s->info[1] = 1;
     } else {
+        // the loop's bookkeeping with its own bound (n_hyp), over the counts that exist so far
+        const int32_t* cnts = reinterpret_cast<const int32_t*>(h_counts);
         int niters = n_hyp, max_good = 0, it = 0;
-        for (; it < niters; ++it) {
-            const int good = s->counts[it];
-            if (good > std::max(max_good, kModel - 1)) {
-                max_good = good;
-                best = it;
-                niters = update_num_iters(confidence, (double)(n - good) / n, kModel, niters);
+        for (;;) {
+            for (; it < niters && it < evaluated; ++it) {
+                const int good = cnts[it];
+                if (good > std::max(max_good, kModel - 1)) {
+                    max_good = good;
+                    best = it;
+                    niters = update_num_iters(confidence, (double)(n - good) / n, kModel, niters);
+                }
             }
+            if (it >= niters || evaluated >= n_hyp) break;
+            // the sequential loop goes on behind the first chunk: the remaining hypotheses, then the refinement over all counts
+            if ((r = track_launch_pnp_hypotheses(ctx, d_p3, d_p2, n, d_subsets + (size_t)kModel * evaluated, n_hyp - evaluated, cam, thr2,
+                                                 s->d_models + 12 * (size_t)evaluated, s->d_counts + evaluated, s->d_masks + (size_t)evaluated * n,
+                                                 reinterpret_cast<double*>(h_models) + 12 * (size_t)evaluated,
+                                                 reinterpret_cast<int32_t*>(h_counts) + evaluated)))
+                return r;
+            if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp, dev_conf, -1, mode,
+                                             s->d_Mg, s->d_mg, h_mask, reinterpret_cast<double*>(h_out))))
+                return r;
+            if ((r = fetch())) return r;
+            evaluated = n_hyp;
         }
         s->info[1] = it;
     }
+    s->counts.assign(reinterpret_cast<int32_t*>(h_counts), reinterpret_cast<int32_t*>(h_counts) + evaluated);
+    s->models.resize((size_t)evaluated * 12);
+    std::memcpy(s->models.data(), h_models, (size_t)evaluated * 96);
+    s->info[5] = evaluated;
     s->info[0] = best;
     double out[12];
     std::memcpy(out, h_out, sizeof(out));
     if (best >= 0 && (int)out[10] != best) {  // the device's replay chose differently: refine the right hypothesis
-        s->info[5] = -n_hyp;                  // (visible to tests through mvo_debug_get_pnp)
-        if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, n_hyp,
+        s->info[5] = -evaluated;              // (visible to tests through mvo_debug_get_pnp)
+        if ((r = track_launch_pnp_refine(ctx, d_p3, d_p2, s->d_masks, n, cam, s->d_models, s->d_counts, evaluated,
                                          confidence, best, mode, s->d_Mg, s->d_mg, h_mask, reinterpret_cast<double*>(h_out))))
             return r;
         if ((r = fetch())) return r;

@@ -91,6 +91,34 @@ def test_solve_pnp_ransac_matches_the_oracle(mvo, O, ctx, seed, kw):
         assert np.abs(got["tvec"] - Tcw[:3, 3]).max() < 5e-3
 
 
+@pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(outlier_frac=0.5)), (13, dict(outlier_frac=0.0)), (19, dict(outlier_frac=0.8)),
+                                     (16, dict(n_map=400, pix_noise=0.0))])
+def test_solve_pnp_ransac_in_chunks_matches_the_oracle(mvo, O, seed, kw):
+    """Contexts that share the GPU (THROUGHPUT / SHARED mode) evaluate the first 32 hypotheses, replay the loop's bookkeeping and
+    launch the other 68 only if the sequential loop would have gone on (vo.cpp:326-329: same model, same inliers, same loop
+    length as cv::solvePnPRansac's loop either way -- here: the oracle's)."""
+    pr = mvo.synth.tracking_problem(seed=seed, **kw)
+    p3, p2, K = pr["pts3d"], pr["pts2d"], pr["K"]
+    ref = O.solve_pnp_ransac(p3, p2, K)
+    c = mvo.Context(0)
+    try:
+        c.ba_set_mode("shared")
+        for _ in range(2):
+            got = c.solve_pnp_ransac(p3, p2, K)
+            dbg = c.debug_pnp()
+            run = ref["iters_run"]
+            assert got["ok"] == ref["ok"] and dbg["iters_run"] == run and dbg["best_iter"] == ref["best_iter"]
+            assert dbg["n_hyp"] == (32 if run <= 32 else 100), (dbg["n_hyp"], run)          # (positive: the device's choice stood)
+            assert np.array_equal(dbg["counts"][:run], ref["counts"][:run])
+            assert _same_models(dbg["models"][:run], ref["models"][:run])
+            assert np.array_equal(got["inliers"], ref["inliers"])
+            if ref["ok"]:
+                assert dbg["dlt"] == ref["dlt"] and dbg["lm_iters"] == ref["lm_iters"]
+                assert np.abs(got["rvec"] - ref["rvec"]).max() < 1e-8 and np.abs(got["tvec"] - ref["tvec"]).max() < 1e-8
+    finally:
+        c.close()
+
+
 def test_all_hypotheses_bit_exact(mvo, O, ctx):
     """Beyond the sequential stopping point: every one of the 100 hypotheses equals the oracle's EPnP + score."""
     pr = mvo.synth.tracking_problem(seed=21, outlier_frac=0.35)

@@ -122,6 +122,9 @@ def test_solve_pnp_ransac(simmvo, O, simctx):
     T_track.test_all_hypotheses_bit_exact(simmvo, O, simctx)
     T_track.test_solve_pnp_ransac_edge_cases(simmvo, O, simctx)
     T_track.test_host_corrects_a_wrong_device_choice(simmvo, O, simctx)
+    # contexts that share the GPU: the first 32 hypotheses, the rest only when the sequential loop goes on (one chunk / two chunks)
+    T_track.test_solve_pnp_ransac_in_chunks_matches_the_oracle(simmvo, O, 11, {})
+    T_track.test_solve_pnp_ransac_in_chunks_matches_the_oracle(simmvo, O, 19, dict(outlier_frac=0.8))
 
 
 def test_tracking_step(simmvo, O, simctx):
