@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument("--track", action="store_true",
                     help="also run the tracking rows every frame (map points in view -> match against the map -> "
                          "solvePnPRansac, vo.cpp:270-357); off by default: BASELINE.json's metric is extract+match+BA")
+    ap.add_argument("--chain", action="store_true",
+                    help="the chained loop as the headline workload (what secondary.chained_fps measures): every frame runs solvePnPRansac on "
+                         "the new frame's own 3D-2D pairs and ONLY its inliers become the window's edges of that frame (vo.cpp:304-357)")
     ap.add_argument("--keyframe-every", type=int, default=10,
                     help="with --track: run the keyframe row (findEssentialMat inlier filter + triangulation + culling, "
                          "vo_addFrame.cpp:93-118) on every N-th frame")
@@ -549,7 +552,8 @@ def run_benchmark(args, env):
         import torch.distributed as dist
         env.init_process_group(dist)
     pipeline = args.pipeline == 1
-    shards = [env.make_shard(sid, args, args.ba_mode, pipeline) for sid in shard_ids(rank, args.streams)]
+    kw = {"chain": True} if getattr(args, "chain", False) else {}
+    shards = [env.make_shard(sid, args, args.ba_mode, pipeline, **kw) for sid in shard_ids(rank, args.streams)]
     env.sync()
 
     def barrier():
@@ -886,7 +890,7 @@ def parity_check(args, shards, nframes, max_windows=32):
       are compared with the oracle's on the same two images (feature_match.cpp:11-49, 126-260)."""
     O = graft.load_oracle()
     out = {"checked_by": "oracle/ (blocked BA oracle with the device's summation plan; ORB / matcher oracle)"}
-    if args.ba_mode == "rebuild" and not args.track:
+    if args.ba_mode == "rebuild" and not args.track and not getattr(args, "chain", False):
         bad, cuts, n_checked = [], set(), 0
         fix = args.ba == "pose_only"
         for s in shards[:max_windows]:

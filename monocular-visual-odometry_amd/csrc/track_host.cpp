@@ -25,6 +25,7 @@ struct mvo_track_state {
     int32_t* d_counts = nullptr;
     int cap_h = 0;
     uint8_t* d_masks = nullptr;
+    int last_loop_len = 0;  // iterations the RANSAC loop of the previous mvo_solve_pnp_ransac on this ctx ran (0: none yet)
     size_t cap_masks = 0;
     // record of the last solve (mvo_debug_get_pnp)
     std::vector<double> models;
@@ -366,8 +367,13 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
     // 200 us of a CU: contexts in THROUGHPUT / SHARED mode evaluate the first 32, let the replay of the loop's bookkeeping say
     // whether the loop would have gone on, and only then launch the rest (one more round trip in that case).  The result is what
     // the sequential loop produces either way.  MVO_PNP_CHUNK: 0 = never, n > 0 = first n for every ctx (A/B).
+    // A sequence whose loop ran long last time (few inliers among its pairs: the loop needs all its iterations) gets all hypotheses
+    // at once again -- two chunks would only add a round trip and a second refinement; the inlier ratio of a sequence changes slowly
+    // from frame to frame.  (Measured with 32 sequences: +8 % frames/s where the loop stops after ~27 iterations, -23 % where it
+    // always needs 100 and the chunks were used blindly.)
     static const int env_chunk = std::getenv("MVO_PNP_CHUNK") ? std::atoi(std::getenv("MVO_PNP_CHUNK")) : -1;
-    const bool chunked = n != kModel && n_hyp > 48 && (env_chunk >= 0 ? env_chunk > 0 : ctx->ba_throughput_mode != 0);
+    const bool chunked = n != kModel && n_hyp > 48 &&
+                         (env_chunk >= 0 ? env_chunk > 0 : (ctx->ba_throughput_mode != 0 && s->last_loop_len > 0 && s->last_loop_len <= 28));
     const int first = chunked ? std::min(n_hyp, env_chunk > 0 ? env_chunk : 32) : n_hyp;
     if ((r = track_launch_pnp_hypotheses(ctx, d_p3, d_p2, n, d_subsets, first, cam, thr2, s->d_models, s->d_counts, s->d_masks,
                                          reinterpret_cast<double*>(h_models), reinterpret_cast<int32_t*>(h_counts))))
@@ -417,6 +423,7 @@ int mvo_solve_pnp_ransac(mvo_ctx* ctx, const float* pts3d, const float* pts2d, i
             evaluated = n_hyp;
         }
         s->info[1] = it;
+        s->last_loop_len = it;
     }
     s->counts.assign(reinterpret_cast<int32_t*>(h_counts), reinterpret_cast<int32_t*>(h_counts) + evaluated);
     s->models.resize((size_t)evaluated * 12);

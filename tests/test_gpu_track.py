@@ -94,27 +94,39 @@ def test_solve_pnp_ransac_matches_the_oracle(mvo, O, ctx, seed, kw):
 @pytest.mark.parametrize("seed,kw", [(11, {}), (12, dict(outlier_frac=0.5)), (13, dict(outlier_frac=0.0)), (19, dict(outlier_frac=0.8)),
                                      (16, dict(n_map=400, pix_noise=0.0))])
 def test_solve_pnp_ransac_in_chunks_matches_the_oracle(mvo, O, seed, kw):
-    """Contexts that share the GPU (THROUGHPUT / SHARED mode) evaluate the first 32 hypotheses, replay the loop's bookkeeping and
-    launch the other 68 only if the sequential loop would have gone on (vo.cpp:326-329: same model, same inliers, same loop
-    length as cv::solvePnPRansac's loop either way -- here: the oracle's)."""
+    """Contexts that share the GPU (THROUGHPUT / SHARED mode) whose last RANSAC loop was short evaluate the first 32 hypotheses,
+    replay the loop's bookkeeping and launch the other 68 only if the sequential loop would have gone on (vo.cpp:326-329: same
+    model, same inliers, same loop length as cv::solvePnPRansac's loop either way -- here: the oracle's)."""
     pr = mvo.synth.tracking_problem(seed=seed, **kw)
     p3, p2, K = pr["pts3d"], pr["pts2d"], pr["K"]
     ref = O.solve_pnp_ransac(p3, p2, K)
     c = mvo.Context(0)
     try:
         c.ba_set_mode("shared")
-        for _ in range(2):
+        for rep in range(3):
             got = c.solve_pnp_ransac(p3, p2, K)
             dbg = c.debug_pnp()
             run = ref["iters_run"]
             assert got["ok"] == ref["ok"] and dbg["iters_run"] == run and dbg["best_iter"] == ref["best_iter"]
-            assert dbg["n_hyp"] == (32 if run <= 32 else 100), (dbg["n_hyp"], run)          # (positive: the device's choice stood)
+            # the first call of a ctx evaluates everything; after a short loop (<= 28 iterations) the next call starts with 32
+            assert dbg["n_hyp"] == (32 if (rep > 0 and run <= 28) else 100), (rep, dbg["n_hyp"], run)   # (positive: the device's choice stood)
             assert np.array_equal(dbg["counts"][:run], ref["counts"][:run])
             assert _same_models(dbg["models"][:run], ref["models"][:run])
             assert np.array_equal(got["inliers"], ref["inliers"])
             if ref["ok"]:
                 assert dbg["dlt"] == ref["dlt"] and dbg["lm_iters"] == ref["lm_iters"]
                 assert np.abs(got["rvec"] - ref["rvec"]).max() < 1e-8 and np.abs(got["tvec"] - ref["tvec"]).max() < 1e-8
+        if ref["iters_run"] <= 28:
+            # ... and a frame whose loop then needs every iteration: the first 32 are not enough, the other 68 follow (two chunks)
+            hard = mvo.synth.tracking_problem(seed=19, outlier_frac=0.8)
+            refh = O.solve_pnp_ransac(hard["pts3d"], hard["pts2d"], hard["K"])
+            assert refh["iters_run"] > 32
+            goth = c.solve_pnp_ransac(hard["pts3d"], hard["pts2d"], hard["K"])
+            dbg = c.debug_pnp()
+            assert dbg["n_hyp"] == 100 and dbg["iters_run"] == refh["iters_run"] and dbg["best_iter"] == refh["best_iter"]
+            assert np.array_equal(dbg["counts"][:refh["iters_run"]], refh["counts"][:refh["iters_run"]])
+            assert np.array_equal(goth["inliers"], refh["inliers"])
+            assert np.abs(goth["rvec"] - refh["rvec"]).max() < 1e-8 and np.abs(goth["tvec"] - refh["tvec"]).max() < 1e-8
     finally:
         c.close()
 
