@@ -54,6 +54,11 @@ timeout 200 python bench.py --width 1242 --height 375 --max-kp 4000 --ba-poses 1
 # the frame kernels by SQ counters (instructions, wave cycles, where the waves wait), headline mode, no solver on the device
 bash tools/pmc_extract.sh $TAG/frame_kernels > $OUT/frame_kernels.log 2>&1
 timeout 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1
+# gpurun merges at most 64 MiB back: the raw per-dispatch tables (kernel traces / counter collections of ~40 k dispatches per
+# pass) are summarised above -- only the summaries, the *_kernel_stats.csv and the logs travel
+find $OUT -name "*_kernel_trace.csv" -delete; find $OUT -name "*_counter_collection.csv" -delete; find $OUT -name "*_agent_info.csv" -delete
+find $OUT -name ".shipped.so" -delete
+du -sh $OUT
 ls -la $OUT | head -30
 cat $OUT/pmc_fetch_write_size_per_kernel.csv $OUT/pmc_streams1_fetch_write_size.csv $OUT/pmc_mfma_busy.txt $OUT/config4_pmc_fetch_write_size_per_kernel.csv $OUT/config4_pmc_mfma_busy.txt 2>/dev/null
 for d in prof_default prof_default_launches prof_streams1 prof_config4 prof_track1; do f=$(find $OUT/$d -name "*kernel_stats.csv" 2>/dev/null | head -1); echo "== $d"; [ -n "$f" ] && cut -c1-160 "$f" | head -8; done < /dev/null

@@ -42,7 +42,7 @@ for rep in $(seq 1 $REPS); do
     for kv in $envs; do case $kv in LIB=*) alt=${kv#LIB=};; esac; done
     if [ -n "$alt" ]; then cp $SO $O/.shipped.so && cp "$alt" $SO; fi
     env $envs timeout 400 $B > $f.json 2> $f.err
-    if [ -n "$alt" ]; then cp $O/.shipped.so $SO; fi
+    if [ -n "$alt" ]; then cp $O/.shipped.so $SO && rm -f $O/.shipped.so; fi
     show $f.json "${label}_$rep"
   done
 done

@@ -13,4 +13,5 @@ timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST
 timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_sq2 -o bench -- $CMD > $O/pmc_sq2.log 2>&1
 if [ -n "$ALT" ]; then cp $O/.shipped.so $SO; fi
 for d in pmc_sq pmc_sq2; do f=$(find $O/$d -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python tools/pmc_summary.py table $f $O/$d.txt "$CMD" && cat $O/$d.txt; done
+find $O -name "*_kernel_trace.csv" -delete; find $O -name "*_counter_collection.csv" -delete; find $O -name ".shipped.so" -delete
 tail -3 $O/pmc_sq.log
