@@ -24,6 +24,7 @@ import ctypes as C
 import glob
 import json
 import os
+import re
 import sys
 
 # one HIP stream per sequence shard (+ one per shard for uploads): lift the runtime's default of 4 hardware queues
@@ -682,8 +683,18 @@ def main(argv=None, env=None):
             config4 = args.ba_poses == 10 and args.width == 1242 and args.ba_points == 4000
             wpl = launch["windows"] / max(launch["launches"], 1)
             if resident:
-                # the resident grid: bytes per WINDOW of the profiled run (its dispatches span the run) x the windows of this one
-                trw = pmc_traffic("k_ba_service_per_window")
+                # the resident grid: bytes per WINDOW of the profiled run (its dispatches span the run) x the windows of this one.
+                # Round 5: the WRITE_SIZE pass next to the never-ending grid hung (three attempts, killed by its bound) -- the newest
+                # round's figure is then the launch-path form of the SAME cut and kernel flavour (tools/pmc_grid_traffic.sh):
+                # whichever of the two files belongs to the later round is used, and the source says which
+                def round_of(t):
+                    m = re.search(r"r(\d+)_", os.path.basename(t[1])) if t else None
+                    return int(m.group(1)) if m else -1
+                trg = pmc_traffic("k_ba_service_per_window")
+                trl = pmc_traffic("k_ba_lm_per_window", "r[0-9]*_pmc_launch_path_fetch_write_size.csv")
+                trw = trl if round_of(trl) > round_of(trg) else trg
+                if trw is trl and trl:
+                    trw = (trl[0], trl[1] + " (k_ba_lm<false,32,2> per window: the throughput cut on the launch path under the headline load)")
                 tr = (trw[0] * launch["windows"], trw[1]) if trw else None
             elif config4:
                 # BASELINE configs[3]: the profiled launches of the same command hold ~3.9 BA10 windows like the ones timed here
