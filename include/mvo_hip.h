@@ -214,6 +214,9 @@ int mvo_set_extract_concurrency(int n);
  *   MVO_BA_GROUPS [1], MVO_BA_ALIAS_SL [1], MVO_BA_BLOCK_SOLVER [0]   A/B switches of DESIGN.md 4.3 (grouped Schur exchange,
  *                                 reduced system inside the U area, block LDL^T for the 5-pose class)
  *   MVO_BRIEF_LEVEL_BLUR [by mode] 1 = descriptors from whole blurred levels (k_blur + k_brief_sample), 0 = per-keypoint windows
+ *   MVO_BA_UV_GLOBAL [1]          0 = the measurements of a > 512-observation range never leave LDS (1: device memory when LDS would cost a chunk)
+ *   MVO_PNP_CHUNK [by mode]       0 = solvePnPRansac always evaluates all hypotheses at once, n = the first n for every ctx
+ *                                 (default: the first 32 for a THROUGHPUT / SHARED ctx whose previous RANSAC loop was short)
  *   MVO_BRIEF_WAVES [4], MVO_MATCH_SLICE [256], MVO_PYR_FULL_POOL [0], MVO_PNP_OCC [by mode]   kernel shape A/Bs
  *   MVO_BA_PLAN_TRACE, MVO_HOST_TIMING   development output on stderr
  * mvo_debug_set(key, value) (bottom of this file) sets the same switches at run time for the tests. */

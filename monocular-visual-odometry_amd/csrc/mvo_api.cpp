@@ -60,7 +60,7 @@ void mvo_prof_collect(mvo_ctx* c) {
 
 int ba_debug_set(const char* key, int value);  // mvo_api_ba.cpp: the "ba_*" knobs
 // ---- admission gate (mvo_internal.h)
-int g_extract_concurrency = std::getenv("MVO_EXTRACT_CONCURRENCY") ? std::atoi(std::getenv("MVO_EXTRACT_CONCURRENCY")) : 8;
+std::atomic<int> g_extract_concurrency{std::getenv("MVO_EXTRACT_CONCURRENCY") ? std::atoi(std::getenv("MVO_EXTRACT_CONCURRENCY")) : 8};  // (read by waiting threads, set by mvo_set_extract_concurrency)
 namespace {
 struct GateState {
     std::mutex m;
@@ -70,12 +70,16 @@ struct GateState {
 GateState* g_gates = new GateState[16];  // (never destroyed: contexts may outlive static destruction order)
 }  // namespace
 ExtractGate::ExtractGate(const mvo_ctx* ctx) {
-    const int cap = g_extract_concurrency;
+    const int cap = g_extract_concurrency.load(std::memory_order_relaxed);
     if (!ctx || !ctx->ba_throughput_mode || cap <= 0) return;
     device = ctx->device & 15;
     GateState& g = g_gates[device];
     std::unique_lock<std::mutex> lk(g.m);
-    g.cv.wait(lk, [&] { return g.in_flight < std::max(1, g_extract_concurrency); });
+    // (a limit raised meanwhile lets the section in; 0 = gate switched off while waiting)
+    g.cv.wait(lk, [&] {
+        const int lim = g_extract_concurrency.load(std::memory_order_relaxed);
+        return lim <= 0 || g.in_flight < lim;
+    });
     ++g.in_flight;
 }
 void ExtractGate::release() {
@@ -136,8 +140,7 @@ int mvo_set_wait_policy(int device, int policy) {
 }
 
 int mvo_set_extract_concurrency(int n) {
-    const int prev = g_extract_concurrency;
-    g_extract_concurrency = n < 0 ? 0 : n;
+    const int prev = g_extract_concurrency.exchange(n < 0 ? 0 : n);
     for (int d = 0; d < 16; ++d) g_gates[d].cv.notify_all();  // (a raised limit lets waiting sections in)
     return prev;
 }

@@ -151,7 +151,7 @@ struct ProfEntry {
 // `g_extract_concurrency` such launch-and-wait sections are in flight per device (0 = no limit).  The kernels of a frame run on
 // the CUs the resident solver grid leaves free; their combined throughput DROPS when too many frames interleave there
 // (round 4: 14 frames at once -> 3400 frames/s of extraction, 8-9 at once -> 4600), so the excess waits at the door.
-extern int g_extract_concurrency;
+extern std::atomic<int> g_extract_concurrency;
 struct mvo_ctx;
 struct ExtractGate {
     int device = -1;
