@@ -772,7 +772,9 @@ def main(argv=None, env=None):
         # ---- secondary numbers: one sequence alone (extraction of frame i+1 overlapped with the BA of frame i), and the
         # round-1 style "resident window" rate (kernel-side upper bound: nothing is marshalled or uploaded per frame)
         secondary = {}
-        if not args.no_secondary and args.ba_mode == "rebuild":
+        # (N > 1: the other ranks wait in the final barrier while rank 0 reports -- the single-GPU side measurements and the CPU
+        # baseline belong to the N = 1 run, as the bench contract says)
+        if not args.no_secondary and args.ba_mode == "rebuild" and world == 1:
             frames0 = (s0.host_frames, s0.dev_frames)
             one = env.make_shard(shard_ids(rank, args.streams)[0], args, "rebuild", True, frames=frames0, pool=s0.pool, ba_cut="latency")
             one.run(max(5, args.warmup))
@@ -840,10 +842,11 @@ def main(argv=None, env=None):
                      for a, b in zip(st_after, st_before)]
         secondary["headline_shard_busy_ms"] = {"min": round(min(per_shard), 1), "mean": round(sum(per_shard) / len(per_shard), 1),
                                                "max": round(max(per_shard), 1), "timed_region_ms": round(elapsed * 1e3, 1)}
-        cpu = None if args.no_cpu_baseline else cpu_baseline(args, shards[0])
+        skip_cpu = args.no_cpu_baseline or world > 1
+        cpu = None if skip_cpu else cpu_baseline(args, shards[0])
         cpu_mt = None
         nthr = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
-        if not args.no_cpu_baseline and nthr > 1:
+        if not skip_cpu and nthr > 1:
             cpu_mt = cpu_baseline_threads(args, shards[0], nthr)
         st = st_after[0]
         result = {
