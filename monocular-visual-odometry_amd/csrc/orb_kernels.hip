@@ -4,7 +4,7 @@
 // Data layout in HBM: ONE byte buffer for the raw gray pyramid (a second one for whole-level blur, filled on debug
 // request only), every level stored with its 32-px BORDER_REFLECT_101 frame, row stride rounded up to 64 B so that every
 // tile row starts dword-aligned and a 64-lane wave reads one aligned 64-B segment per row.  All kernels are integer/byte
-// work bounded by HBM/L2 traffic (in practice by latency); three launches per frame:
+// work bounded by HBM/L2 traffic (in practice by latency: the time a wave stays resident); four or five launches per frame:
 //   k_pyramid       every level of a group of up to four levels in ONE launch: workgroup = one 64x16 tile of one level;
 //                   the tile's footprint is traced down the bilinear chain to the group's base (the BGR image, or the
 //                   last level of the previous group) -- the regions come from a per-tile table the host makes once per image
