@@ -51,3 +51,20 @@ def test_algorithmic_work_table_names_the_kernels_of_a_frame():
     assert work["k_knn2"] == ("valu", 16.0 * 2000 * 2000)
     # BA5 is 11.2 MFLOP per LM trial
     assert abs(bench.ba_trial_flops(9386, 2000, 5, False) / 1e6 - 11.2) < 0.3
+
+
+def test_roofline_side_figures_come_from_the_newest_rounds_profile_files():
+    """What bench.py's roofline block reads for the resident solver grid: the matrix-core counters measured ON the grid
+    (profiles/r05_pmc_grid_mfma_busy.txt), the HBM-side bytes per window of the newest round (round 5: the launch-path form of the same
+    cut -- the WRITE_SIZE pass next to the resident grid hung), the compiler's register report of the shipped build."""
+    import bench
+    gb = bench.pmc_grid_busy()
+    assert gb and gb["source"].startswith("profiles/r") and gb["workgroups_per_window"] == 14 and gb["windows"] >= 1000
+    busy = gb["SQ_VALU_MFMA_BUSY_CYCLES"] / (gb["resident_cycles"] * gb["workgroups_per_window"] * 4)
+    assert 0.03 < busy < 0.3, busy
+    lp = bench.pmc_traffic("k_ba_lm_per_window", "r[0-9]*_pmc_launch_path_fetch_write_size.csv")
+    assert lp and 1e5 < lp[0] < 1e8
+    res = bench.kernel_resources("k_ba_service<32,2>")
+    assert res and res["vgpr"] == 256 and res["source"].startswith("profiles/r05")
+    fh = bench.kernel_resources("k_fast_harris")
+    assert fh["vgpr"] <= 64 and fh["scratch_bytes_per_lane"] == 0 and fh["occupancy"] == 8
