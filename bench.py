@@ -43,6 +43,10 @@ METRIC = "frames/sec (extract+match+5-kf BA), 640x480 / 2000 kp, 1->8 MI355X"
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # FP64 vector = matrix peak: 256 CU x 4 SIMD x 32 flop/clk x 2.4 GHz; one
 #                                v_mfma_f64_16x16x4_f64 (2048 flop) issues every 64 cycles per SIMD (tools/probes/mfma_probe.hip)
+FP64_NOTE = ("fp64: the peak is MI355X's FP64 rate, the same 78.6 TFLOP/s for the vector ALU and the matrix cores; of the counted flops "
+             "only the Gram chains (pose blocks, Schur complement, the block solver's updates) run on v_mfma_f64_16x16x4_f64 -- their "
+             "share of the time is mfma_busy --, the rest is vector-ALU f64 work")
+I8_MFMA_PEAK_TOPS = 3944.0     # MI355X_MICROARCH.md: dense I8 matrix peak (>= 3944 TOPS, 16x16x64)
 VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz lane-ops/s = 7.86e13
 
 
@@ -111,7 +115,7 @@ class FrameLoopState(C.Structure):
     _fields_ = [("frame_no", C.c_int32), ("n_kp", C.c_int32), ("n_match", C.c_int32), ("n_inliers", C.c_int32),
                 ("n_tri", C.c_int32), ("ba_trials", C.c_int64), ("ba_iterations", C.c_int64), ("ba_solves", C.c_int64),
                 ("ba_edges", C.c_int64), ("ns_extract", C.c_int64), ("ns_restore", C.c_int64), ("ns_build", C.c_int64),
-                ("ns_begin", C.c_int64), ("ns_end", C.c_int64)]
+                ("ns_begin", C.c_int64), ("ns_end", C.c_int64), ("ba_failed_solves", C.c_int64), ("ba_stale_steps", C.c_int64)]
 
 
 _frame_loop = None
@@ -333,10 +337,22 @@ def timed_run(shards, steps, sync):
 
 
 def ba_trial_flops(E, L, F, fix_points):
-    """Algorithmic flops of one LM trial: linearize + pose blocks, landmark blocks + Schur, reduced
+    """Algorithmic flops of one FULL LM trial (SURVEY.md 8d's F_trial): linearize + pose blocks, landmark blocks + Schur, reduced
     solve, back-substitution, chi2."""
     n = E / max(L, 1)
     return 330 * E + (0 if fix_points else L * (40 + 144 * n + 216 * n * (n + 1) / 2) + 200 * L) + (6 * F) ** 3 / 3 + 60 * E
+
+
+def ba_solve_flops(E, L, F, fix_points, iterations, trials, applied):
+    """Algorithmic flops of LM solves, counted by what each stage actually runs (the terms are SURVEY.md 8d's F_trial, split):
+    once per ITERATION the linearisation + pose blocks (330 E; g2o does not re-linearise for a retry either); once per TRIAL the
+    landmark blocks' inverses + the Schur complement (L (40 + 144 n + 216 n (n + 1) / 2)) and the factorisation ((6 F)^3 / 3);
+    only for the trials whose step is APPLIED -- all but the ones that end at a failed factorisation with nothing to apply --
+    the landmark back-substitution (200 L) and the robust chi2 (60 E)."""
+    n = E / max(L, 1)
+    per_trial = (0 if fix_points else L * (40 + 144 * n + 216 * n * (n + 1) / 2)) + (6 * F) ** 3 / 3
+    per_applied = (0 if fix_points else 200 * L) + 60 * E
+    return iterations * 330 * E + trials * per_trial + applied * per_applied
 
 
 def algorithmic_work(args):
@@ -353,7 +369,8 @@ def algorithmic_work(args):
         "k_brief": ("hbm", (45 * 56 + 32 + 16) * K),                   # raw window in, descriptor out
         "k_blur": ("hbm", 2 * P),                                      # every level in, its blurred copy out (throughput mode)
         "k_brief_sample": ("hbm", (512 + 32 + 16) * K),                # 512 taps of the blurred level in, descriptor out
-        "k_knn2": ("valu", 16.0 * K * K),
+        "k_knn2": ("valu", 16.0 * K * K),                                # the vector-ALU form (xor + bcnt): 16 lane-ops per pair
+        "k_knn2_mfma": ("mfma_i8", 2.0 * 256 * K * K),                   # the form that runs: i8 Gram of the +-1 bit vectors, 2 x 256 ops per pair
     }
 
 
@@ -515,7 +532,7 @@ class GpuEnv:
             raise SystemExit("bench.py needs a GPU (no CPU fallback)")
         # N > 1 ranks on one host: every rank keeps to its own CPUs (those of its GPU's NUMA node when sysfs tells), and blocks
         # on an interrupt instead of spinning when its threads outnumber its CPUs.  Measured for ONE rank confined like a rank of
-        # an 8-GPU node (32 of 256 CPUs, tools/gpu_r04_s.sh): block 5029, yield 4955, spin 4904 frames/s vs 5054 unconfined; the
+        # an 8-GPU node (32 of 256 CPUs; a round-4 one-off run under `taskset`, MVO_BENCH_WAIT_POLICY=<p> -- its script went when tools/gpu_ab.sh replaced the one-offs): block 5029, yield 4955, spin 4904 frames/s vs 5054 unconfined; the
         # N > 1 run itself is the driver's; the control flow is exercised on CPU by tests/test_distributed_gloo.py
         # (no LOCAL_WORLD_SIZE -- a launcher that does not say how many ranks share this host: no confinement rather than a
         # slice of 1/WORLD_SIZE of the CPUs on a multi-node job)
@@ -585,29 +602,49 @@ def run_benchmark(args, env):
 
 def spawn_ranks(args, argv):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, torch.distributed.run on this node,
-    rendezvous on 127.0.0.1 at a free port), pass the command line through, relay rank 0's JSON line and return it parsed.
+    --standalone: the launcher itself picks the rendezvous port on 127.0.0.1 -- no bind-close-reuse race), pass the command line
+    through, relay the ranks' other output line by line as it comes (a hung rank is visible, and the whole run is bounded:
+    MVO_BENCH_SPAWN_TIMEOUT seconds, default 3600), and return the LAST line that parses as the contract's JSON object.
     MVO_BENCH_RANK_SCRIPT names the script the ranks run (default: this file; tests/ substitute a CPU stand-in that calls
     bench.main with a gloo environment)."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import threading
     script = os.environ.get("MVO_BENCH_RANK_SCRIPT", os.path.abspath(__file__))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script] + list(sys.argv[1:] if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), script] + list(sys.argv[1:] if argv is None else argv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "1")
-    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    result = None
-    for line in proc.stdout.splitlines():
-        if line.startswith("{") and '"metric"' in line:
-            result = json.loads(line)
-            print(line)
-        elif line.strip():
-            print(line, file=sys.stderr)
-    if proc.returncode != 0 or result is None:
-        raise SystemExit("bench.py: the %d-rank run failed (exit code %d)" % (args.gpus, proc.returncode))
+    limit = float(os.environ.get("MVO_BENCH_SPAWN_TIMEOUT", "3600"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    found = []
+
+    def relay():
+        for line in proc.stdout:
+            line = line.rstrip("\n")
+            parsed = None
+            if line.startswith("{"):
+                try:
+                    parsed = json.loads(line)
+                except ValueError:
+                    parsed = None
+            if isinstance(parsed, dict) and parsed.get("metric") == METRIC and "value" in parsed:
+                found.append((parsed, line))
+            elif line.strip():
+                print(line, file=sys.stderr, flush=True)
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        proc.kill()          # (the launcher's own process: its ranks go with it)
+        proc.wait()
+        raise SystemExit("bench.py: the %d-rank run did not finish within %.0f s" % (args.gpus, limit))
+    th.join(timeout=10)
+    if rc != 0 or not found:
+        raise SystemExit("bench.py: the %d-rank run failed (exit code %d)" % (args.gpus, rc))
+    result, line = found[-1]
+    print(line)
     return result
 
 
@@ -635,31 +672,35 @@ def main(argv=None, env=None):
         result = contract_line(args, R)
         print(json.dumps(result))
     elif rank == 0:
-        # ---- parity of what the timed loop produced (oracle = the checker; outside the timing)
         plan_wgs = int(s0.ctx_ba.ba_plan()["wgs"]) if args.ba_mode == "rebuild" else 0   # (workgroups of the last timed window of shard 0)
-        parity = None
-        if not args.no_parity:
-            try:
-                parity = parity_check(args, shards, R["nframes"])
-            except Exception as e:  # noqa: BLE001  (the checker must never cost the measurement its line)
-                parity = {"error": "parity check did not complete: %r" % (e,)}
         trials = sum(a.ba_trials - b.ba_trials for a, b in zip(st_after, st_before))
+        iters = sum(a.ba_iterations - b.ba_iterations for a, b in zip(st_after, st_before))
+        failed = sum(a.ba_failed_solves - b.ba_failed_solves for a, b in zip(st_after, st_before))
+        stale = sum(a.ba_stale_steps - b.ba_stale_steps for a, b in zip(st_after, st_before))
         solves = sum(a.ba_solves - b.ba_solves for a, b in zip(st_after, st_before))
         edges = sum(a.ba_edges - b.ba_edges for a, b in zip(st_after, st_before))
         E_avg = edges / max(solves, 1)
         fix = args.ba == "pose_only"
         # ---- dominant kernel: k_ba_lm.  Duration = HIP events around every launch on the stream it is launched on
-        # (the library's launch thread); algorithmic flops = trials solved in the timed region x flops per trial.
+        # (the library's launch thread); algorithmic flops = what the LM stages of the windows solved in the timed region ran
+        # (ba_solve_flops: a trial that ends at the failed factorisation is NOT credited with a back-substitution or a chi2,
+        # the linearisation is credited once per iteration).  Bound: FP64 -- most of these flops are vector-ALU f64 work, the matrix
+        # cores run the Gram chains (their share: mfma_busy); on MI355X the FP64 vector and matrix peaks are the same figure.
         per_kernel = {}
         if solves:
-            flops = trials * ba_trial_flops(E_avg, args.ba_points, args.ba_poses, fix)
+            applied = trials - (failed - stale)
+            flops = ba_solve_flops(E_avg, args.ba_points, args.ba_poses, fix, iters, trials, applied)
+            lm_counts = dict(iterations_per_solve=iters / max(solves, 1), trials_per_solve=trials / max(solves, 1),
+                             failed_solves_per_solve=failed / max(solves, 1), stale_steps_per_solve=stale / max(solves, 1),
+                             flops_per_solve=flops / max(solves, 1),
+                             flops_if_every_trial_were_full=trials * ba_trial_flops(E_avg, args.ba_points, args.ba_poses, fix) / max(solves, 1))
             resident = launch.get("resident_windows", 0) > 0.5 * max(launch["windows"], 1)
             if resident:
                 # resident solver service: ONE grid (k_ba_service) stays on the device for the whole timed region and its slots
                 # pull windows; the kernel's duration is the region, its work the windows solved in it.  Per window: the
                 # device-clock duration of its solve (launch["ms"] sums them, launches == windows).
                 busy_ms = launch.get("elapsed_ms", elapsed * 1e3)
-                roof = dict(bound="mfma", achieved=flops / (busy_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+                roof = dict(bound="mfma", bound_note=FP64_NOTE, achieved=flops / (busy_ms * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
                 roof["frac"] = roof["achieved"] / roof["peak"]
                 avg_ms = launch["ms"] / max(launch["windows"], 1)
                 roof.update(kernel="k_ba_service (resident k_ba_lm body)", avg_launch_ms=busy_ms, launches=max(1, launch.get("resident_grid_starts", 1)),
@@ -675,7 +716,7 @@ def main(argv=None, env=None):
                                  "windows its 16 slots solved in it; avg_window_ms = mean solve time of a window on the device clock")
             else:
                 avg_ms = launch["ms"] / max(launch["launches"], 1)
-                roof = dict(bound="mfma", achieved=flops / (launch["ms"] * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+                roof = dict(bound="mfma", bound_note=FP64_NOTE, achieved=flops / (launch["ms"] * 1e-3) / 1e12, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
                 roof["frac"] = roof["achieved"] / roof["peak"]
                 roof.update(kernel="k_ba_lm", avg_launch_ms=avg_ms, launches=launch["launches"],
                             windows_per_launch=launch["windows"] / max(launch["launches"], 1),
@@ -711,6 +752,12 @@ def main(argv=None, env=None):
             else:
                 tr = None  # (no PMC pass of this window shape has been committed)
             roof["traffic"], roof["traffic_source"] = (tr[0], tr[1]) if tr else (None, None)
+            # `traffic` and `mfma_busy` are NOT measured by this run: they are read from the committed PMC passes under profiles/
+            # (counters cannot be collected from inside the process).  traffic_is_proxy: the bytes are those of ANOTHER kernel flavour
+            # than the one this block names (the launch-path form of the same cut standing in for the resident grid)
+            roof["traffic_is_proxy"] = bool(resident and tr and "k_ba_lm<" in tr[1])
+            roof["counters_from"] = "committed rocprofv3 --pmc passes under profiles/ (see traffic_source / mfma_busy_source), not this run"
+            roof["lm"] = lm_counts
             # what the compiler gave the dominant kernel (build remarks of the shipped sources) and how busy its matrix cores
             # were in the PMC pass of that kernel (SQ_VALU_MFMA_BUSY_CYCLES per SIMD-cycle of the CUs its windows occupy)
             cls = 32 if args.ba_poses <= 5 else (64 if args.ba_poses <= 10 else 0)
@@ -764,7 +811,7 @@ def main(argv=None, env=None):
             avg = ms / max(n_, 1)
             kern[k] = dict(avg_launch_us=round(avg * 1e3, 2), launches_per_frame=round(n_ / nprof, 2),
                            frac=round((amount / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if kind == "hbm" else
-                                      (amount / (avg * 1e-3) / 1e12 / VALU_PEAK_TOPS), 5), bound=kind)
+                                      (amount / (avg * 1e-3) / 1e12 / (I8_MFMA_PEAK_TOPS if kind == "mfma_i8" else VALU_PEAK_TOPS)), 5), bound=kind)
         if roof is None and per_kernel:
             dom = max(per_kernel, key=per_kernel.get)
             roof = dict(kernel=dom, **kern.get(dom, {}))
@@ -848,6 +895,15 @@ def main(argv=None, env=None):
         nthr = (os.cpu_count() or 1) if args.cpu_threads < 0 else args.cpu_threads
         if not skip_cpu and nthr > 1:
             cpu_mt = cpu_baseline_threads(args, shards[0], nthr)
+        # ---- parity of what the timed loop produced (oracle = the checker; outside the timing).  LAST of the side measurements: the
+        # check restores a window of every measured shard and advances shard 0 by two frames -- nothing that reads the shards'
+        # state runs after it
+        parity = None
+        if not args.no_parity:
+            try:
+                parity = parity_check(args, shards, R["nframes"])
+            except Exception as e:  # noqa: BLE001  (the checker must never cost the measurement its line)
+                parity = {"error": "parity check did not complete: %r" % (e,)}
         st = st_after[0]
         result = {
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,

@@ -161,7 +161,10 @@ typedef struct {
 
 typedef struct {
     int32_t iterations, trials, terminated;
+    int32_t failed_solves;     /* trials whose reduced system was "not positive" for Eigen::LDLT (g2o: solve() returns false) */
     double chi2_initial, chi2_final, lambda_final;
+    int32_t stale_steps;       /* of those: g2o applied the solver's previous x and accepted it (negative predicted decrease) */
+    int32_t reserved_;
 } mvo_ba_stats;
 
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317; caller VisualOdometry::callBundleAdjustment_,

@@ -45,8 +45,9 @@ class BaProblem(C.Structure):
 
 
 class BaStats(C.Structure):
-    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32),
-                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double)]
+    _fields_ = [("iterations", C.c_int32), ("trials", C.c_int32), ("terminated", C.c_int32), ("failed_solves", C.c_int32),
+                ("chi2_initial", C.c_double), ("chi2_final", C.c_double), ("lambda_final", C.c_double),
+                ("stale_steps", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class KernelTime(C.Structure):

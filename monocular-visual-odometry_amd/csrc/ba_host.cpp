@@ -81,7 +81,7 @@ struct BaPlan {
     // device block layout
     size_t o_desc = 0, o_pin = 0, o_ptsin = 0, o_wpt = 0, o_wed = 0, o_wps = 0, o_ep = 0, o_el = 0, o_uv = 0, o_ptstart = 0,
            o_ptl = 0, o_eof = 0, o_dup = 0, o_slot = 0, o_sp = 0, o_pkt = 0, upload_end = 0, x_end = 0;
-    size_t o_uvd = 0, o_stats = 0, o_pout = 0, o_pts = 0, o_xp = 0, o_xr = 0, o_xh = 0, o_xc = 0, total = 0;
+    size_t o_uvd = 0, o_dxl = 0, o_stats = 0, o_pout = 0, o_pts = 0, o_xp = 0, o_xr = 0, o_xh = 0, o_xc = 0, total = 0;
     // pinned mirror layout (behind the upload staging)
     size_t m_stats = 0, m_poses = 0, m_pts = 0, m_trace = 0, pin_total = 0;
     bool runnable = true;  // false: nothing to optimise (no free vertex)
@@ -98,10 +98,18 @@ struct BaWorkspace {
     hipEvent_t ready = nullptr;
     BaPlan plan;
     bool in_flight = false;
+    bool poisoned = false;  // a resident grid that never left may still write into these blocks: never reuse or free them
 };
 
 int ws_reserve(mvo_ctx* ctx, BaWorkspace& ws, size_t dev_bytes, size_t pin_bytes) {
     ws.device = ctx->device;
+    if (ws.poisoned) {  // (leaked on purpose, see BaService::stop_resident)
+        ws.dev = ws.pin = nullptr;
+        ws.dev_cap = ws.pin_cap = 0;
+        ws.seq = 0;
+        std::memset(ws.x_sig, 0, sizeof ws.x_sig);
+        ws.poisoned = false;
+    }
     if (!ws.ready) MVO_HIP(hipEventCreateWithFlags(&ws.ready, hipEventDisableTiming));
     if (dev_bytes > ws.dev_cap) {
         MVO_HIP(hipStreamSynchronize(ctx->stream));
@@ -128,8 +136,8 @@ int ws_reserve(mvo_ctx* ctx, BaWorkspace& ws, size_t dev_bytes, size_t pin_bytes
     return MVO_OK;
 }
 void ws_free(BaWorkspace& ws) {
-    if (ws.dev) ba_service_free(ws.device, ws.dev, false);
-    if (ws.pin) ba_service_free(ws.device, ws.pin, true);
+    if (ws.dev && !ws.poisoned) ba_service_free(ws.device, ws.dev, false);
+    if (ws.pin && !ws.poisoned) ba_service_free(ws.device, ws.pin, true);
     if (ws.ready) (void)hipEventDestroy(ws.ready);
     ws = BaWorkspace();
 }
@@ -164,6 +172,7 @@ struct BaService {
     // resident solver service (k_ba_service): BA_SERVICE_SLOTS slots of `wgs_per_slot` workgroups stay on the device and
     // pull windows from their mailboxes; the launch thread only assigns slots
     bool resident = false;               // the grid is on the device
+    bool wedged = false;                 // a grid of this service never left the device (stop_resident): do not start another one
     BaMail* mail = nullptr;              // pinned host memory
     ba_u64* d_cmd = nullptr;             // device memory: 8 words per slot + one arrival counter per slot
     hipStream_t resident_stream = nullptr;
@@ -486,6 +495,7 @@ void BaService::heartbeat() {
         for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&mail[sl].beat, (ba_u64)beat, __ATOMIC_RELAXED);
 }
 int BaService::start_resident() {
+    if (wedged) return -1;
     // (called with the service mutex held; everything here is quick)
     if (!mail) {
         if (hipHostMalloc((void**)&mail, sizeof(BaMail) * BA_SERVICE_SLOTS, hipHostMallocDefault) != hipSuccess) return -1;
@@ -542,8 +552,30 @@ void BaService::stop_resident(std::unique_lock<std::mutex>& lk) {
         }
     for (int sl = 0; sl < BA_SERVICE_SLOTS; ++sl) __atomic_store_n(&mail[sl].stop, (ba_u64)1, __ATOMIC_RELEASE);
     lk.unlock();
-    (void)hipStreamSynchronize(resident_stream);
+    // the grid leaves within microseconds of seeing `stop` -- unless a slot is truly wedged (then a plain synchronize would never
+    // return and the stuck clients would wait for ever): poll with a deadline of its own
+    bool left = false;
+    const auto t1 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(resident_stream);
+        if (q != hipErrorNotReady) {  // hipSuccess, or an error the stream will keep reporting: nothing left to wait for
+            left = true;
+            if (q != hipSuccess) (void)hipGetLastError();
+            break;
+        }
+        if (std::chrono::steady_clock::now() - t1 > std::chrono::seconds(nstuck ? 10 : 30)) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
     lk.lock();
+    if (!left) {
+        // the grid is still on the device and may still write into the workspaces of the jobs it never finished: those blocks
+        // are leaked (never reused, never freed), the service stays down for this process (windows take the launch path)
+        std::fprintf(stderr, "[mvo] resident solver grid did not leave within its deadline (%d unfinished window(s)): their workspaces are "
+                             "abandoned, the service is disabled\n", nstuck);
+        for (int i = 0; i < nstuck; ++i)
+            if (stuck[i]->ws) stuck[i]->ws->poisoned = true;
+        wedged = true;
+    }
     for (int i = 0; i < nstuck; ++i) {
         stuck[i]->err = hipErrorUnknown;
         stuck[i]->done = true;
@@ -1033,6 +1065,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     P.o_pout = cv.take((size_t)F * 128);
     P.o_pts = cv.take((size_t)L * 24);
     P.o_uvd = cv.take((size_t)E * 16 + 16);
+    P.o_dxl = cv.take((size_t)L * 24 + 16);
     P.total = cv.off;
     Carver pc;
     pc.off = P.upload_end;
@@ -1101,6 +1134,7 @@ int ba_stage(mvo_ctx* ctx, const mvo_ba_problem* p, BaWorkspace& ws, bool want_t
     B.alias_sl = P.alias_sl;
     B.groups = P.groups;
     B.uv_dev = (double*)(D + P.o_uvd);
+    B.dxl_dev = (double*)(D + P.o_dxl);
     B.npt = P.npt;
     B.panel = P.panel;
     B.slots = P.slots;
@@ -1181,6 +1215,8 @@ int ba_collect(mvo_ctx* ctx, BaWorkspace& ws, const BaJob& job, double* poses, d
         st->iterations = s->iterations;
         st->trials = s->trials;
         st->terminated = s->terminated;
+        st->failed_solves = s->failed_solves;
+        st->stale_steps = s->stale_steps;
         st->chi2_initial = s->chi2_initial;
         st->chi2_final = s->chi2_final;
         st->lambda_final = s->lambda_final;

@@ -337,6 +337,72 @@ __device__ __forceinline__ unsigned ba_xcc_id() {
 #endif
 }
 
+// Minimum of a 32-bit value over the wave, in every lane.
+__device__ __forceinline__ int wave_min_i(int v) {
+#ifndef MVO_KERNEL_SIM
+    const int big = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x118, 0xf, 0xf, false));  // row_shr:8   -> lane 15 of every row
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 into rows 1 and 3
+    v = min(v, __builtin_amdgcn_update_dpp(big, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 into rows 2 and 3 -> lane 63
+    return __builtin_amdgcn_readlane(v, 63);
+#else
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+#endif
+}
+
+// The pivot order of Eigen::LDLT (g2o's LinearSolverDense, g2o_ba.cpp:196-197), run by ONE wave.  Eigen's factorisation
+// (LDLT.h, ldlt_inplace<Lower>::unblocked) swaps, at step k, the largest |diagonal entry| among the positions k .. n-1 --
+// the FIRST maximum -- to position k; it is left-looking, so the entries behind k still hold the INPUT diagonal when they are
+// compared: the order is a function of diag(S) alone.  ab[0 .. n) = |diag S| (LDS, n <= 128: position lane and lane + 64 per
+// lane); perm[k] = row of S that ends up at position k.  Without equal entries that is the descending order (ranks by
+// counting); with equal entries -- the rule in pose-only windows: the x and y translation entries of a pose block are the
+// same sums -- the swap sequence itself is replayed on integer keys (dense rank << 7 | position: the wave minimum is the
+// first maximum).  A NaN on the diagonal: identity (the factorisation then stops at that pivot).
+__device__ __forceinline__ void ba_pivot_order(const double* ab, int n, short* perm, int lane) {
+    const int p0 = lane, p1 = lane + 64;
+    const double a0 = p0 < n ? ab[p0] : -1.0, a1 = p1 < n ? ab[p1] : -1.0;
+    int r0 = 0, r1 = 0;
+    bool tie = false;
+    for (int j = 0; j < n; ++j) {
+        const double b = ab[j];
+        r0 += b > a0 ? 1 : 0;
+        r1 += b > a1 ? 1 : 0;
+        tie = tie || (b == a0 && j != p0) || (b == a1 && j != p1);
+    }
+    const bool isnan_ = (p0 < n && a0 != a0) || (p1 < n && a1 != a1);
+    if (__ballot(isnan_) != 0) {
+        if (p0 < n) perm[p0] = (short)p0;
+        if (p1 < n) perm[p1] = (short)p1;
+        return;
+    }
+    if (__ballot(tie) == 0) {
+        if (p0 < n) perm[r0] = (short)p0;
+        if (p1 < n) perm[r1] = (short)p1;
+        return;
+    }
+    const int done = 0x7fffffff;
+    int k0 = p0 < n ? (r0 << 7) | p0 : done, k1 = p1 < n ? (r1 << 7) | p1 : done;
+    int e0 = p0, e1 = p1;
+    for (int k = 0; k < n; ++k) {
+        const int big = wave_min_i(min(k0, k1)) & 127;  // position of the first maximum among k .. n-1
+        const int ek = k < 64 ? __builtin_amdgcn_readlane(e0, k) : __builtin_amdgcn_readlane(e1, k - 64);
+        const int kk = k < 64 ? __builtin_amdgcn_readlane(k0, k) : __builtin_amdgcn_readlane(k1, k - 64);
+        const int eb = big < 64 ? __builtin_amdgcn_readlane(e0, big) : __builtin_amdgcn_readlane(e1, big - 64);
+        const int kmoved = (kk & ~127) | big;  // what sat at position k goes to position `big`
+        if (p0 == big) e0 = ek, k0 = kmoved;
+        if (p1 == big) e1 = ek, k1 = kmoved;
+        if (p0 == k) e0 = eb, k0 = done;
+        if (p1 == k) e1 = eb, k1 = done;
+    }
+    if (p0 < n) perm[p0] = (short)e0;
+    if (p1 < n) perm[p1] = (short)e1;
+}
+
 #include "ba_solve.h"  // readlane_d, ba_rcp_pivot, the one-wave solver of the 5-pose class (solve_wave_32), the block solver (solve_block)
 
 // the same arithmetic for more than 63 unknowns (> 10 free poses): one wave, matrix in LDS (row pitch n + 2)
@@ -408,6 +474,8 @@ struct WgLds {
     double* bl;     // maxLg x 3
     double* Cc;     // maxLg x 6 (pitch BA_XS)   Cholesky factor of (H_ll + lambda I)^-1
     double* cl;     // maxLg x 3   C^T b_l
+    double* dxl;    // Lg x 3 in DEVICE memory (BaDev::dxl_dev, this range's part): landmark part of the solver's x = the step of
+                    // the last SUCCESSFUL solve (g2o keeps it when a solve fails); element l is only ever touched by thread l % 512
     double* U;      // `uarea` doubles: see above
     double* E2;     // rows [a0 | a1 | x | e~] (pitch BA_E2S) of the edges that do not keep them in registers: all edges
                     // (SLOTS = 0) or the edges 512 .. Eg - 1
@@ -584,6 +652,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ short sSlc[3][BA_HP_PASSES][BA_MAX_POSES];  // pose-block chains: slices of the staging passes (below)
     __shared__ int sFlag[4];
+    __shared__ double sStale[BA_WAVES + 2];  // wave partials of the stale step's predicted decrease; [8]: rho of a failed solve
+    __shared__ short sPerm[6 * BA_MAX_POSES];  // Eigen's pivot order of the trial's reduced system
     __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
     if (threadIdx.x == 0) sFlag[2] = 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -626,6 +696,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         d += full * B.maxLg * BA_XS;
         W.cl = d;
         d += full * B.maxLg * 3;
+        W.dxl = B.dxl_dev + 3 * (size_t)pt_lo;
         W.U = d;
         stage = d;
         if (B.alias_sl) W.SL = d;  // (the matrix shares the U area: alive only between the last chain and the back-substitution)
@@ -666,6 +737,9 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         }
     }
     for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = B.pts_in[3 * (size_t)pt_lo + i];
+    if (!B.fix_points)
+        for (int l = tid; l < Lg; l += BA_THREADS) W.dxl[3 * l] = W.dxl[3 * l + 1] = W.dxl[3 * l + 2] = 0.0;  // (the solver's x before the first solve)
+    if (tid < 6 * B.F) sDx[tid] = 0.0;
     for (int i = tid; i <= Lg; i += BA_THREADS) W.pts0[i] = (short)(B.pt_edge_start[pt_lo + i] - e_lo);
     for (int i = tid; i < Lg * nfree; i += BA_THREADS) W.eof[i] = B.eof[(size_t)pt_lo * nfree + i];
     if (tid < B.F) {  // T_w_c.inv() -> SE3Quat(R, t)  (g2o_ba.cpp:185-190, 208-215)
@@ -684,7 +758,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     __syncthreads();
 
     double lambda = 0, ni = 2;
-    int it = 0, trials = 0, terminated = 0, error = 0;
+    int it = 0, trials = 0, terminated = 0, error = 0, failed_solves = 0, stale_steps = 0;
     long long ph[PROF ? BA_NPHASE : 1] = {0};
     const long long ph_start = (long long)__builtin_amdgcn_s_memtime();
     // ---- initial robust chi2: all-to-all through the chi2 slots (tag 1 of the B series)
@@ -721,7 +795,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     const double chi0 = currentChi;
     const bool any_free = nfree > 0 || !B.fix_points;
     const bool do_schur = !B.fix_points && n > 0;
-    const int slice = B.slice;
     // ---- the Schur chains of this workgroup: `nsplit` consecutive column pieces of `msplit` MFMA steps each, `npar` of
     // them side by side (on different waves) per chunk of the U area, `nseq` chunks one after the other
     const int npar = B.npar, nseq = B.nseq;
@@ -1098,8 +1171,15 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         do {
             STAMP(0);
             // ============= T1: (H_ll + lambda I)^-1 = C C^T and C^T b_l of the own landmarks
+            double stale_l = 0;
+            int ist = nlow;  // where the summed stale-scale entry ends up in Rl
             if (!B.fix_points) {
                 for (int l = tid; l < Lg; l += BA_THREADS) {
+                    double xs[3] = {0, 0, 0};  // (device memory: fetched first, used last)
+                    if (do_schur) {
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) xs[c] = W.dxl[3 * l + c];
+                    }
                     const double* h = W.Hll + BA_XS * l;
                     const double D[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
                     double Di[9];
@@ -1118,6 +1198,14 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     W.cl[3 * l] = c00 * b[0] + c10 * b[1] + c20 * b[2];
                     W.cl[3 * l + 1] = c11 * b[1] + c21 * b[2];
                     W.cl[3 * l + 2] = c22 * b[2];
+                    if (do_schur) {  // computeScale() of the x the solver holds NOW, landmark part (needed if this trial's solve fails)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) stale_l += xs[c] * (lambda * xs[c] + b[c]);
+                    }
+                }
+                if (do_schur) {
+                    stale_l = wave_sum_d(stale_l);
+                    if (lane == 0) sStale[wave] = stale_l;
                 }
                 __syncthreads();
             }
@@ -1261,6 +1349,13 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 }
                 STAMP(5);
                 PH_END(4);
+                if (tid == 0) {  // this range's partial (the 8 wave sums in order) rides along as one more packed entry
+                    double sv = 0;
+#pragma unroll
+                    for (int w = 0; w < BA_WAVES; ++w) sv += sStale[w];
+                    stale_l = sv;
+                    if (G == 1) W.Rl[nlow] = sv;
+                }
                 if (G > 1) {
                     __syncthreads();
                     STAMP(6);
@@ -1273,9 +1368,11 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     // (K > 1: the group sums alternate between two buffers -- a trial that ends at the failed factorisation
                     // has no all-to-all behind it, and a slice owner only knows that its OWN group has left the last trial)
                     u64* xR = B.xR + (K > 1 ? 2 * (size_t)(tagA & 1) * K * npk : 0);
-                    const int nhpx = hp_pending ? B.nhp - 1 : 0, nlowx = nlow + nhpx;
-                    const int slicex = hp_pending ? (nlowx + Gk - 1) / Gk : slice;
+                    const int nhpx = hp_pending ? B.nhp - 1 : 0, nlowx = nlow + nhpx + 1;
+                    const int slicex = (nlowx + Gk - 1) / Gk;
+                    ist = nlow + nhpx;
                     for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(B.xP + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], grp_l2);
+                    if (tid == 0) gstore_d(B.xP + 2 * ((size_t)g * npk + ist), tag0 + tagA, stale_l, grp_l2);
                     const int sl0 = gj * slicex, sln = max(0, min(slicex, nlowx - sl0));
                     if (sln > 0) {
                         // item q = (w, el): partial of the group's workgroup w (= workgroup w K + gk), entry sl0 + el
@@ -1338,7 +1435,18 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             }
             STAMP(11);
             PH_END(5);
-            // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n] and solves it
+            // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n] -- rows and columns in the
+            // pivot order Eigen::LDLT would choose for it (sPerm, from |diag S|) -- and solves it
+            if (wave == 0 && n > 0) {
+                double* ab = W.colbuf;  // (192 doubles, free until the solve)
+                for (int i = lane; i < n; i += 64) {
+                    const double gsum = do_schur ? W.Rl[i * (i + 1) / 2 + i] : 0.0;
+                    ab[i] = fabs((sHpp[36 * sSlotPose[i / 6] + 7 * (i % 6)] + lambda) - gsum);
+                }
+                __builtin_amdgcn_wave_barrier();
+                ba_pivot_order(ab, n, sPerm, lane);
+            }
+            __syncthreads();
             if (NR != 0) {
                 // register solvers: the system embedded into NR rows (identity rows behind n, the rhs as row NR - 1)
                 constexpr int NRR = NR ? (NR < 0 ? -NR : NR) : 32, RR = NRR - 1, PP = NRR + 1;
@@ -1348,15 +1456,17 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     if (i < n) {
                         v = 0.0;
                         if (k <= i) {
-                            const double gsum = do_schur ? W.Rl[i * (i + 1) / 2 + k] : 0.0;
-                            const int pi = sSlotPose[i / 6], pj = sSlotPose[k / 6];
-                            v = ((pi == pj) ? sHpp[36 * pi + 6 * (i % 6) + (k % 6)] + (i == k ? lambda : 0.0) : 0.0) - gsum;
+                            const int a_ = sPerm[i], b_ = sPerm[k], hi = max(a_, b_), lo = min(a_, b_);  // entry (hi, lo) of S
+                            const double gsum = do_schur ? W.Rl[hi * (hi + 1) / 2 + lo] : 0.0;
+                            const int pi = sSlotPose[hi / 6], pj = sSlotPose[lo / 6];
+                            v = ((pi == pj) ? sHpp[36 * pi + 6 * (hi % 6) + (lo % 6)] + (hi == lo ? lambda : 0.0) : 0.0) - gsum;
                         }
                     } else if (i == RR) {
                         v = 0.0;
                         if (k < n) {
-                            const double gsum = do_schur ? W.Rl[n * (n + 1) / 2 + k] : 0.0;
-                            v = sBp[6 * sSlotPose[k / 6] + k % 6] - gsum;
+                            const int kk = sPerm[k];
+                            const double gsum = do_schur ? W.Rl[n * (n + 1) / 2 + kk] : 0.0;
+                            v = sBp[6 * sSlotPose[kk / 6] + kk % 6] - gsum;
                         }
                     } else {
                         v = k == i ? 1.0 : 0.0;
@@ -1367,14 +1477,16 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 for (int idx = tid; idx < nlow; idx += BA_THREADS) {
                     int i, j;
                     packed_ij(idx, n, i, j);  // j <= i < n, or i == n (rhs row)
-                    const double gsum = do_schur ? W.Rl[idx] : 0.0;
                     const int pitch = n + 2;
                     if (i == n) {
-                        const int pj = sSlotPose[j / 6];
-                        W.SL[n * pitch + j] = sBp[6 * pj + j % 6] - gsum;
+                        const int kk = sPerm[j];
+                        const double gsum = do_schur ? W.Rl[n * (n + 1) / 2 + kk] : 0.0;
+                        W.SL[n * pitch + j] = sBp[6 * sSlotPose[kk / 6] + kk % 6] - gsum;
                     } else {
-                        const int pi = sSlotPose[i / 6], pj = sSlotPose[j / 6];
-                        W.SL[i * pitch + j] = ((pi == pj) ? sHpp[36 * pi + 6 * (i % 6) + (j % 6)] + (i == j ? lambda : 0.0) : 0.0) - gsum;
+                        const int a_ = sPerm[i], b_ = sPerm[j], hi = max(a_, b_), lo = min(a_, b_);
+                        const double gsum = do_schur ? W.Rl[hi * (hi + 1) / 2 + lo] : 0.0;
+                        const int pi = sSlotPose[hi / 6], pj = sSlotPose[lo / 6];
+                        W.SL[i * pitch + j] = ((pi == pj) ? sHpp[36 * pi + 6 * (hi % 6) + (lo % 6)] + (hi == lo ? lambda : 0.0) : 0.0) - gsum;
                     }
                 }
             }
@@ -1387,15 +1499,15 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     // workgroup-wide block factorisation (all waves take part: barriers inside)
                     const int ok = solve_block<(NR == 64 ? 64 : 32)>(sl_off, (int)(W.pan - dyn), cb_off + 128, n, tid);
                     if (tid == 0) sFlag[0] = ok;
-                    if (tid < n) sSol[tid] = W.colbuf[128 + tid];
+                    if (ok && tid < n) sSol[sPerm[tid]] = W.colbuf[128 + tid];  // x = P^T x'; a failed solve leaves x what it was
                 } else if (wave == 0 && n > 0) {
                     int ok;
                     if (NR == 32) {
                         ok = solve_wave_32(sl_off, cb_off, n, lane);
-                        if (lane < n) sSol[lane] = W.colbuf[128 + lane];
+                        if (ok && lane < n) sSol[sPerm[lane]] = W.colbuf[128 + lane];  // x = P^T x'; a failed solve leaves x what it was
                     } else {
                         ok = solve_lds(sl_off, cb_off, n, lane);
-                        for (int j = lane; j < n; j += 64) sSol[j] = W.colbuf[j];
+                        for (int j = lane; ok && j < n; j += 64) sSol[sPerm[j]] = W.colbuf[j];
                     }
                     if (lane == 0) sFlag[0] = ok;
                 } else if (n == 0 && tid == 0) {
@@ -1404,40 +1516,60 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             }
             __syncthreads();
             const int ok2 = sFlag[0];
-            if (tid < 6 * B.F) {
+            if (ok2 && tid < 6 * B.F) {
                 const int sl = sSlot[tid / 6];
-                sDx[tid] = (ok2 && sl >= 0) ? sSol[6 * sl + tid % 6] : 0.0;
+                sDx[tid] = sl >= 0 ? sSol[6 * sl + tid % 6] : 0.0;
             }
             __syncthreads();
             STAMP(13);
             PH_END(7);
             const double lambda_used = lambda;
             ++trials;
+            double stale_rho = 0;
             if (!ok2) {
-                // The factorisation met a pivot that is not usable (g2o: LDLT "not positive" -> solve() fails, the trial
-                // counts as rejected with an infinite chi2; on the gauge-free window of the benchmark EVERY rejection is of
-                // this kind: lambda shrinks by 1/3 per accepted step until the reduced system stops being numerically
-                // positive definite, then bounces).  Every workgroup solved the same system with the same bits, so all of them
-                // know it at the same time and without an exchange: nothing was applied, nothing needs to be evaluated or
-                // restored -- the trial ends here with exactly the values the long way round would have produced (dx = 0,
-                // chi2 = DBL_MAX, rho = -inf).  The Schur exchange of the next trial is safe without the chi2 all-to-all in
-                // between: a workgroup that holds all summed entries knows that every workgroup has finished reading the
-                // partials (stage 1 precedes the republished slices), and nobody republishes a slice of the next trial before
-                // everybody has published its partials of that trial, i.e. has left this one.
-                rho = -__builtin_inf();
-                if (B.trace && g == 0 && tid == 0 && trials <= BA_TRACE_MAX) {
-                    BaTraceRow tr = {lambda_used, 1.7976931348623157e308, rho, 0.0};
-                    B.trace[trials - 1] = tr;
+                // The factorisation met a pivot that is not usable (g2o: LDLT "not positive" -> LinearSolverDense::solve returns
+                // false WITHOUT touching x, BlockSolver::solve returns before the landmark part).  OptimizationAlgorithmLevenberg
+                // applies the solver's x all the same -- still the PREVIOUS solution: sDx / dxl here --, sets tempChi = DBL_MAX and
+                // scores the step with computeScale() of that stale x.  DBL_MAX is finite, so the sign of the stale scale decides:
+                // positive (the rule) -> rho < 0, rejected; negative -> rho > 0 and the stale step is ACCEPTED (lambda / 3).  Every
+                // workgroup solved the same system with the same bits and holds the same summed stale scale (its landmark part rode
+                // along with the Schur exchange), so all of them know the outcome at the same time and without another exchange.  On
+                // the gauge-free window of the benchmark every rejection is of this kind: lambda shrinks by 1/3 per accepted step
+                // until the reduced system stops being numerically positive definite, then bounces.
+                if (wave == 0) {
+                    double ps = 0;
+                    for (int t = lane; t < 6 * B.F; t += 64)
+                        if (sSlot[t / 6] >= 0) ps += sDx[t] * (lambda * sDx[t] + sBp[t]);
+                    ps = wave_sum_d(ps);
+                    double sc = (do_schur ? W.Rl[ist] : 0.0) + ps;
+                    sc += 1e-3;
+                    if (lane == 0) sStale[BA_WAVES] = (currentChi - 1.7976931348623157e308) / sc;
                 }
-                lambda *= ni;
-                ni *= 2;
-                ++qmax;
-                continue;
+                __syncthreads();
+                stale_rho = sStale[BA_WAVES];
+                ++failed_solves;
+                if (stale_rho > 0) ++stale_steps;
+                if (!(stale_rho > 0)) {
+                    // rejected: push / update / pop leave the state as it was -- nothing is applied, evaluated or restored.  The Schur
+                    // exchange of the next trial is safe without the chi2 all-to-all in between: a workgroup that holds all summed
+                    // entries knows that every workgroup has finished reading the partials (stage 1 precedes the republished
+                    // slices), and nobody republishes a slice of the next trial before everybody has published its partials of that
+                    // trial, i.e. has left this one.
+                    rho = stale_rho;
+                    if (B.trace && g == 0 && tid == 0 && trials <= BA_TRACE_MAX) {
+                        BaTraceRow tr = {lambda_used, 1.7976931348623157e308, rho, 0.0};
+                        B.trace[trials - 1] = tr;
+                    }
+                    lambda *= ni;
+                    ni *= 2;
+                    ++qmax;
+                    continue;
+                }
             }
             // ============= T4/T5: back-substitute the own landmarks, computeScale, push + apply the update
             double scale = 0;
             if (g == 0 && tid < 6 * B.F && sSlot[tid / 6] >= 0) scale += sDx[tid] * (lambda * sDx[tid] + sBp[tid]);
-            if (!B.fix_points && do_schur) {
+            if (!B.fix_points && do_schur && ok2) {
                 // r = C^T (b_l - W^T dx_p) = C^T b_l - sum over the landmark's observations (ascending edge order) of
                 // Y^T (A~ dx_pose): every edge thread leaves its three terms in the (now free) U area (zeros for an
                 // observation from a fixed pose)
@@ -1474,7 +1606,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             if (!B.fix_points) {
                 for (int l = tid; l < Lg; l += BA_THREADS) {
                     double r[3] = {W.cl[3 * l], W.cl[3 * l + 1], W.cl[3 * l + 2]};
-                    if (do_schur) {
+                    if (do_schur && ok2) {
                         const int k1 = W.pts0[l + 1];
                         for (int k = W.pts0[l]; k < k1; k += 4) {  // (indices, then terms, fetched four edges at a time)
                             int e4[4];
@@ -1495,10 +1627,14 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     }
                     const double* cc = W.Cc + BA_XS * l;
                     double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
-                    if (!ok2) d[0] = d[1] = d[2] = 0;
+                    if (!ok2) {  // (the stale step)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) d[c] = W.dxl[3 * l + c];
+                    }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         scale += d[c] * (lambda * d[c] + W.bl[3 * l + c]);
+                        W.dxl[3 * l + c] = d[c];
                         W.bak[3 * l + c] = W.pts[3 * l + c];
                         W.pts[3 * l + c] += d[c];
                     }
@@ -1550,8 +1686,9 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             }
             STAMP(22);
             scale += 1e-3;
+            const double chi_at_state = tempChi;  // (what the next iteration's computeActiveErrors sees)
             if (!ok2) tempChi = 1.7976931348623157e308;
-            rho = (currentChi - tempChi) / scale;
+            rho = ok2 ? (currentChi - tempChi) / scale : stale_rho;
             const bool accept = rho > 0 && isfinite(tempChi);
             if (B.trace && g == 0 && tid == 0 && trials <= BA_TRACE_MAX) {
                 BaTraceRow tr = {lambda_used, tempChi, rho, accept ? 1.0 : 0.0};
@@ -1562,7 +1699,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 alpha = fmin(alpha, 2. / 3.);
                 lambda *= fmax(1. / 3., alpha);
                 ni = 2;
-                currentChi = tempChi;
+                currentChi = chi_at_state;
             } else {
                 lambda *= ni;
                 ni *= 2;
@@ -1618,6 +1755,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         st.trials = trials;
         st.terminated = terminated;
         st.error = error;
+        st.failed_solves = failed_solves;
+        st.stale_steps = stale_steps;
         st.chi2_initial = chi0;
         st.chi2_final = currentChi;
         st.lambda_final = lambda;

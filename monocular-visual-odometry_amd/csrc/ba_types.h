@@ -39,6 +39,8 @@ typedef unsigned long long ba_u64;
 
 struct BaStatsDev {
     int iterations, trials, terminated, error;
+    int failed_solves;  // trials whose factorisation was "not positive" (g2o: the linear solve fails)
+    int stale_steps;    // of those: the solver's stale x was applied and ACCEPTED (negative predicted decrease, see ba_window)
     double chi2_initial, chi2_final, lambda_final;
     long long phase[BA_NPHASE];  // shader-clock cycles per phase as seen by thread 0 of workgroup 0
     long long solve_ticks;       // duration of the solve on the 100 MHz clock (workgroup 0, load to write-back)
@@ -70,6 +72,7 @@ struct BaDev {
     int alias_sl;   // 1: the reduced system (SL) lives in the U area (ba_solver_doubles)
     int uv_global;  // 1: the measurements (u, v) of a range stay in device memory (read once per trial) instead of LDS
     double* uv_dev;  // their device copy (E x 2; a window of the resident service has its inputs in pinned host memory)
+    double* dxl_dev;  // L x 3 in device memory: the landmark part of the solver's x (the last successful solve's step)
     int slots;   // kernel flavour the plan was made for: 0 = all rows in LDS, 1 / 2 = first 512 edges in registers
     int ldu;     // rows of the U buffer = 16 NT
     int nhp;     // pose-block exchange entries per workgroup = BA_HP nfree + 1 (last: max |diag H_ll|)

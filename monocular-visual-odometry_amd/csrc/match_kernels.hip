@@ -301,7 +301,6 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
     // MK_GROUPS x nq 16-byte partials live behind the nq x 4 int32 result block
     u64* d_part = reinterpret_cast<u64*>(d_out + 4 * (size_t)nq);
     int32_t* dst = final_out ? final_out : d_out;
-    ProfScope ps(ctx, "k_knn2");
     if (g_match_mfma && nt > 0 && nt < 65536) {
         // slices of <= MM_TS trains, at most 64 of them (the partial area holds 64 x nq x 16 B)
         const int ts = ctx->ba_throughput_mode ? std::max(16, std::min(MM_TS, g_match_slice_throughput & ~15)) : MM_TS;
@@ -309,6 +308,7 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
         if (nsl > 64) nsl = 64;
         int slice = ((nt + nsl - 1) / nsl + 15) & ~15;
         if (slice <= MM_TS) {
+            ProfScope ps(ctx, "k_knn2_mfma");
             static const int lds_ok = hipFuncSetAttribute((const void*)k_knn2_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, MM_TS * MM_PITCH);
             (void)lds_ok;
             nsl = (nt + slice - 1) / slice;
@@ -318,6 +318,7 @@ int match_launch_knn2(mvo_ctx* ctx, const uint8_t* d_q, int nq, const uint8_t* d
             return MVO_OK;
         }
     }
+    ProfScope ps(ctx, "k_knn2");
     hipLaunchKernelGGL(k_knn2, dim3((nq + 63) / 64, MK_GROUPS), dim3(256), 0, ctx->stream, (const uint4*)d_q, nq,
                        (const uint4*)d_t, nt, d_part, ctx->d_marrive, dst, dst + 2 * (size_t)nq);
     MVO_HIP(hipGetLastError());

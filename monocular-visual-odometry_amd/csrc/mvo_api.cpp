@@ -141,7 +141,12 @@ int mvo_set_wait_policy(int device, int policy) {
 
 int mvo_set_extract_concurrency(int n) {
     const int prev = g_extract_concurrency.exchange(n < 0 ? 0 : n);
-    for (int d = 0; d < 16; ++d) g_gates[d].cv.notify_all();  // (a raised limit lets waiting sections in)
+    // a raised limit (or 0 = gate off) lets waiting sections in.  The notification is made under each gate's mutex: a waiter that
+    // has evaluated its predicate with the old limit still holds that mutex until it blocks, so it cannot miss this wake-up
+    for (int d = 0; d < 16; ++d) {
+        std::lock_guard<std::mutex> lk(g_gates[d].m);
+        g_gates[d].cv.notify_all();
+    }
     return prev;
 }
 
@@ -542,7 +547,7 @@ int mvo_match_features_dev(mvo_ctx* ctx, const void* d_d1, int n1, const void* d
 int mvo_debug_set(const char* key, int value) {
     if (key && !std::strncmp(key, "ba_", 3)) return ba_debug_set(key, value);
     if (key && !std::strcmp(key, "extract_concurrency")) {
-        g_extract_concurrency = value;
+        (void)mvo_set_extract_concurrency(value);  // (the one setter: it also wakes the sections waiting at the gate)
         return MVO_OK;
     }
     if (key && !std::strcmp(key, "match_host_out")) {

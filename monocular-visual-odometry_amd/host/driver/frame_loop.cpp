@@ -61,6 +61,7 @@ struct frame_loop_state {  // progress counters, read back by the caller
     // window marshalling (buildBundleAdjustmentWindow), job.begin (flatten + plan + upload + submit), job.end (wait for
     // the solve + scatter); in pipeline mode the extraction of frame i+1 sits between begin and end
     int64_t ns_extract, ns_restore, ns_build, ns_begin, ns_end;
+    int64_t ba_failed_solves, ba_stale_steps;  // LM trials that ended at a failed factorisation / whose stale step was applied
 };
 
 }  // extern "C"
@@ -392,6 +393,8 @@ int frame_loop_run(void* h, int steps, double* traj) {
                     st.ba_edges += w.E;
                 }
                 st.ba_trials += bs.trials;
+                st.ba_failed_solves += bs.failed_solves;
+                st.ba_stale_steps += bs.stale_steps;
                 st.ba_iterations += bs.iterations;
                 st.ba_solves += 1;
                 // trajectory row of the newest frame of the window: x y z, then R column by column

@@ -17,8 +17,12 @@
 //   * scalar sums (chi2, predicted decrease): per-"thread" partials (index mod 512), a 64-lane xor butterfly, 8 waves in
 //     order, ranges in order;
 //   * whitened formulation (Omega = Lc^T Lc folded into the Jacobians), (H_ll + lambda I)^-1 = C C^T, reduced system by
-//     right-looking LDL^T with r = 1 / d, l = c r, fma updates; landmark back-substitution per observation
-//     (C^T b_l - sum_e Y_e^T (A~_e dx), edges in ascending order);
+//     right-looking LDL^T with r = 1 / d, l = c r, fma updates -- on the matrix PERMUTED the way Eigen::LDLT permutes it
+//     (g2o's LinearSolverDense; the pivot order depends on the input diagonal only, see eigenPivotOrder); landmark
+//     back-substitution per observation (C^T b_l - sum_e Y_e^T (A~_e dx), edges in ascending order);
+//   * a failed factorisation leaves the solver's x what it was (g2o applies and scores that STALE step: see the trial loop);
+//     its predicted decrease: landmark part per range at the START of the trial (per-"thread" partials, block sum) riding
+//     along with the Schur exchange (added like its entries), pose part as one 64-lane butterfly, then + 1e-3;
 //   * sin / cos by the fixed polynomial below instead of libm.
 // PARITY UNPINNED like the rest of the oracle (oracle.h).
 #include <algorithm>
@@ -184,6 +188,38 @@ double blockSum(const double* part) {
     return s;
 }
 
+// Eigen::LDLT's pivot order (LDLT.h, ldlt_inplace<Lower>::unblocked): at step k the position of the largest |diagonal
+// entry| among k .. n-1 -- FIRST maximum -- is swapped with k.  The factorisation is left-looking: the entries behind k
+// still hold the INPUT diagonal when they are compared, so the order is a function of diag(S) alone: perm[k] = index (in S)
+// of the row that ends up at position k.  A NaN on the diagonal: identity (the factorisation then fails at that pivot).
+void eigenPivotOrder(const double* diag, int n, int* perm) {
+    std::vector<double> a(n);
+    bool nan = false;
+    for (int i = 0; i < n; ++i) {
+        perm[i] = i;
+        a[i] = std::fabs(diag[i]);
+        nan = nan || a[i] != a[i];
+    }
+    if (nan) return;
+    for (int k = 0; k < n; ++k) {
+        int big = k;
+        for (int i = k + 1; i < n; ++i)
+            if (a[i] > a[big]) big = i;
+        std::swap(a[k], a[big]);
+        std::swap(perm[k], perm[big]);
+    }
+}
+// one wave's xor butterfly over 64 per-lane values (the device's wave_sum_d)
+double waveSum(const double* part) {
+    double v[64], t[64];
+    std::memcpy(v, part, sizeof(v));
+    for (int o = 32; o > 0; o >>= 1) {
+        for (int i = 0; i < 64; ++i) t[i] = v[i] + v[i ^ o];
+        std::memcpy(v, t, sizeof(v));
+    }
+    return v[0];
+}
+
 struct Range {  // one landmark range ("workgroup") of the plan
     int pt_lo = 0, Lg = 0, e_lo = 0, Eg = 0;
     std::vector<int> pose_start;  // F + 1 local offsets: edges of pose p inside the range
@@ -250,6 +286,12 @@ struct Blocked {
 }  // namespace
 
 extern "C" {
+
+void orc_eigen_pivot_order(const double* diag, int n, int32_t* perm) {
+    std::vector<int> p(n);
+    eigenPivotOrder(diag, n, p.data());
+    for (int i = 0; i < n; ++i) perm[i] = p[i];
+}
 
 // wg_pt_start: G + 1 landmark range starts (the device's plan); trace (may be NULL): trace_cap rows {lambda, chi2, rho,
 // accepted} per trial.  Same problem struct, same outputs as orc_bundle_adjustment.
@@ -364,6 +406,10 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
     const int nlow = n * (n + 1) / 2 + n;
     std::vector<double> Gsum(std::max(nlow, 1), 0);
     std::vector<double> S((size_t)(n + 1) * (n + 1), 0), sol(std::max(n, 1), 0), dx(6 * (size_t)std::max(F, 1), 0);
+    // the solver's x as g2o keeps it: it lives across trials and iterations and is only overwritten by a SUCCESSFUL solve
+    // (sol / dx: pose part, xl: landmark part; zero before the first one)
+    std::vector<double> xl(3 * (size_t)std::max(L, 1), 0), solNew(std::max(n, 1), 0);
+    std::vector<int> perm(std::max(n, 1), 0);
 
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, terminated = 0, ntrace = 0;
@@ -520,6 +566,29 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                         }
                     }
             }
+            // ---- predicted decrease of the step the solver's x holds BEFORE this trial's solve, landmark part (needed if the
+            // solve fails): per range, per-"thread" partials + block sum, then added over the ranges like a Schur entry
+            double staleL = 0;
+            if (do_schur) {
+                const int K = B.groups;
+                double total = 0;
+                for (int k = 0; k < K; ++k) {
+                    double sum = 0;
+                    for (int g = k; g < G; g += K) {
+                        const Range& r = B.rg[g];
+                        double part[kThreads] = {0};
+                        for (int ll = 0; ll < r.Lg; ++ll) {
+                            const int l = r.pt_lo + ll;
+                            for (int c = 0; c < 3; ++c)
+                                part[ll % kThreads] += xl[3 * (size_t)l + c] * (lambda * xl[3 * (size_t)l + c] + B.bl[3 * (size_t)l + c]);
+                        }
+                        const double tot = blockSum(part);
+                        sum = G == 1 ? tot : sum + tot;
+                    }
+                    total = K == 1 ? sum : total + sum;
+                }
+                staleL = total;
+            }
             // ---- partial Schur systems: fma chains over the columns of a range (nsplit consecutive pieces), ranges in order
             if (do_schur) {
                 for (int idx = 0; idx < nlow; ++idx) {
@@ -556,24 +625,33 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                     Gsum[idx] = total;
                 }
             }
-            // ---- reduced system (lower triangle + rhs row n), right-looking LDL^T, back-substitution
+            // ---- reduced system (lower triangle + rhs row n) in Eigen's pivot order, right-looking LDL^T, back-substitution
             int ok2 = 1;
             if (n > 0) {
                 const int ld = n + 1;
+                auto entry = [&](int i, int k) {  // S[i][k], k <= i < n
+                    const double gsum = do_schur ? Gsum[i * (i + 1) / 2 + k] : 0.0;
+                    const int pi = B.slot_pose[i / 6], pk = B.slot_pose[k / 6];
+                    return ((pi == pk) ? B.Hpp[36 * pi + 6 * (i % 6) + (k % 6)] + (i == k ? lambda : 0.0) : 0.0) - gsum;
+                };
+                {
+                    std::vector<double> diag(n);
+                    for (int i = 0; i < n; ++i) diag[i] = entry(i, i);
+                    eigenPivotOrder(diag.data(), n, perm.data());
+                }
                 std::fill(S.begin(), S.end(), 0.0);
                 for (int i = 0; i < n; ++i)
-                    for (int k = 0; k <= i; ++k) {
-                        const double gsum = do_schur ? Gsum[i * (i + 1) / 2 + k] : 0.0;
-                        const int pi = B.slot_pose[i / 6], pk = B.slot_pose[k / 6];
-                        S[(size_t)i * ld + k] = ((pi == pk) ? B.Hpp[36 * pi + 6 * (i % 6) + (k % 6)] + (i == k ? lambda : 0.0) : 0.0) - gsum;
-                    }
+                    for (int k = 0; k <= i; ++k) S[(size_t)i * ld + k] = entry(std::max(perm[i], perm[k]), std::min(perm[i], perm[k]));
                 for (int k = 0; k < n; ++k) {
-                    const double gsum = do_schur ? Gsum[n * (n + 1) / 2 + k] : 0.0;
-                    S[(size_t)n * ld + k] = B.bp[6 * B.slot_pose[k / 6] + k % 6] - gsum;
+                    const int pk = perm[k];
+                    const double gsum = do_schur ? Gsum[n * (n + 1) / 2 + pk] : 0.0;
+                    S[(size_t)n * ld + k] = B.bp[6 * B.slot_pose[pk / 6] + pk % 6] - gsum;
                 }
                 for (int j = 0; j < n && ok2; ++j) {
                     const double d = S[(size_t)j * ld + j];
-                    if (!((d >= 0x1p-500) && (d <= 0x1p+500))) {  // a usable pivot (the device's reciprocal chain is exact there)
+                    // Eigen: "not positive" = some pivot < 0.  (A pivot in [0, 2^-500) or beyond 2^500, or a NaN, is not usable by the
+                    // device's reciprocal chain either and fails the solve as well -- Eigen would carry on with it; unreachable here.)
+                    if (!((d >= 0x1p-500) && (d <= 0x1p+500))) {
                         ok2 = 0;
                         break;
                     }
@@ -588,15 +666,46 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                     for (int i = j + 1; i <= n; ++i) S[(size_t)i * ld + j] = S[(size_t)i * ld + n];
                 }
                 if (ok2) {
-                    for (int j = 0; j < n; ++j) sol[j] = S[(size_t)n * ld + j];  // z = D^-1 L^-1 g
+                    for (int j = 0; j < n; ++j) solNew[j] = S[(size_t)n * ld + j];  // z = D^-1 L^-1 g
                     for (int i = n - 1; i >= 1; --i)
-                        for (int j = 0; j < i; ++j) sol[j] = std::fma(-S[(size_t)i * ld + j], sol[i], sol[j]);
+                        for (int j = 0; j < i; ++j) solNew[j] = std::fma(-S[(size_t)i * ld + j], solNew[i], solNew[j]);
+                    for (int k = 0; k < n; ++k) sol[perm[k]] = solNew[k];  // x = P^T x'
                 }
             }
-            for (int p = 0; p < F; ++p)
-                for (int c = 0; c < 6; ++c) dx[6 * p + c] = (ok2 && B.pose_slot[p] >= 0) ? sol[6 * B.pose_slot[p] + c] : 0.0;
+            if (ok2)
+                for (int p = 0; p < F; ++p)
+                    for (int c = 0; c < 6; ++c) dx[6 * p + c] = B.pose_slot[p] >= 0 ? sol[6 * B.pose_slot[p] + c] : 0.0;
             const double lambda_used = lambda;
             ++trials;
+            // ---- a failed solve: OptimizationAlgorithmLevenberg::solve applies _solver->x() all the same -- still the PREVIOUS
+            // solution (LinearSolverDense::solve leaves x alone when LDLT is "not positive", BlockSolver::solve returns before the
+            // landmark part) --, sets tempChi = DBL_MAX and scores the step with computeScale() of that stale x.  DBL_MAX is
+            // finite: whenever the stale scale is negative, rho is positive and the stale step is ACCEPTED (lambda / 3).
+            double staleRho = 0;
+            bool staleApply = false;
+            if (!ok2) {
+                double part[64] = {0};
+                for (int t = 0; t < 6 * F; ++t)
+                    if (B.pose_slot[t / 6] >= 0) part[t % 64] += dx[t] * (lambda * dx[t] + B.bp[t]);
+                double sc = staleL + waveSum(part);
+                sc += 1e-3;
+                staleRho = (currentChi - 1.7976931348623157e308) / sc;
+                staleApply = staleRho > 0;
+                if (!staleApply) {  // rejected: nothing to apply (push / update / pop leaves the state as it was)
+                    rho = staleRho;
+                    if (trace && ntrace < trace_cap) {
+                        trace[4 * ntrace] = lambda_used;
+                        trace[4 * ntrace + 1] = 1.7976931348623157e308;
+                        trace[4 * ntrace + 2] = rho;
+                        trace[4 * ntrace + 3] = 0.0;
+                    }
+                    ++ntrace;
+                    lambda *= ni;
+                    ni *= 2;
+                    ++qmax;
+                    continue;
+                }
+            }
             // ---- back-substitution of the landmarks, computeScale, push + apply
             double scale_r[256];
             if (G > 256) return -3;
@@ -609,7 +718,7 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                 if (!B.fix_points) {
                     // r = C^T (b_l - W^T dx_p) = C^T b_l - sum over the landmark's observations, in ascending edge order, of
                     // Y^T (A~ dx_pose) with Y = X~ C: the 2-vector A~ dx as two fma chains over the six pose coordinates
-                    for (int ll = 0; ll < r.Lg; ++ll) {
+                    for (int ll = 0; ll < r.Lg && ok2; ++ll) {
                         const int l = r.pt_lo + ll;
                         const double* cc = &Cc[6 * (size_t)l];
                         double rq[3] = {cl[3 * (size_t)l], cl[3 * (size_t)l + 1], cl[3 * (size_t)l + 2]};
@@ -635,9 +744,11 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                         const double* rv = &rr[3 * (size_t)l];
                         const double* cc = &Cc[6 * (size_t)l];
                         double d[3] = {cc[0] * rv[0], cc[1] * rv[0] + cc[2] * rv[1], cc[3] * rv[0] + cc[4] * rv[1] + cc[5] * rv[2]};
-                        if (!ok2) d[0] = d[1] = d[2] = 0;
+                        if (!ok2)
+                            for (int c = 0; c < 3; ++c) d[c] = xl[3 * (size_t)l + c];  // the stale step
                         for (int c = 0; c < 3; ++c) {
                             part[ll % kThreads] += d[c] * (lambda * d[c] + B.bl[3 * (size_t)l + c]);
+                            xl[3 * (size_t)l + c] = d[c];
                             B.bak[3 * (size_t)l + c] = B.pts[3 * (size_t)l + c];
                             B.pts[3 * (size_t)l + c] += d[c];
                         }
@@ -660,8 +771,9 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                 }
             }
             scale += 1e-3;
+            const double chiAtState = tempChi;  // (what the next iteration's computeActiveErrors sees)
             if (!ok2) tempChi = 1.7976931348623157e308;
-            rho = (currentChi - tempChi) / scale;
+            rho = ok2 ? (currentChi - tempChi) / scale : staleRho;
             const bool accept = rho > 0 && std::isfinite(tempChi);
             if (trace && ntrace < trace_cap) {
                 trace[4 * ntrace] = lambda_used;
@@ -675,7 +787,7 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                 alpha = std::fmin(alpha, 2. / 3.);
                 lambda *= std::fmax(1. / 3., alpha);
                 ni = 2;
-                currentChi = tempChi;
+                currentChi = chiAtState;
             } else {
                 lambda *= ni;
                 ni *= 2;

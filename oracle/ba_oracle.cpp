@@ -241,6 +241,77 @@ void buildSystem(const Problem& P, System& S) {
     }
 }
 
+// ---- the dense solve of the reduced system: g2o::LinearSolverDense::solve = Eigen::LDLT<MatrixXd>::compute(H);
+// if (isPositive()) x = solve(b), else leave x untouched and return false  (g2o_ba.cpp:196-197 picks that solver).
+// Two rules, selected by orc_ba_set_solver_rule():
+//   1 (default) "eigen": Eigen 3.3 LDLT.h, ldlt_inplace<Lower>::unblocked restated -- at step k the largest |diagonal entry|
+//      among positions k.. (FIRST maximum; the entries k.. still hold the INPUT matrix's values: the left-looking update only
+//      touches column k) is swapped to k, d_k = a_kk - sum_j l_kj^2 d_j, column k -= A20 (D l_k), column k /= d_k unless
+//      d_k == 0; the factorisation never stops at a bad pivot; sign: Zero -> PositiveSemiDef on the first d > 0 /
+//      NegativeSemiDef on the first d < 0, a later pivot of the other sign -> Indefinite; isPositive() = PositiveSemiDef or
+//      Zero, i.e. "no negative pivot" (zero pivots pass); solve = P^T L^-T D^+ L^-1 P b with D^+ zeroing rows whose
+//      |d| <= DBL_MIN.  Inner products in index order (Eigen's own order depends on its SIMD width: unpinned).
+//   0 "legacy" (rounds 1-5): unpivoted LDL^T, fails at the first pivot that is not > 0.
+int g_solver_rule = 1;
+int g_counters[4] = {0, 0, 0, 0};  // of the last orc_bundle_adjustment: failed solves, failed solves whose stale step was accepted
+
+bool ldltEigen(std::vector<double>& A, const std::vector<double>& b, std::vector<double>& x, int n) {
+    auto M = [&](int i, int j) -> double& { return A[(size_t)i * n + j]; };
+    std::vector<int> tr(n);
+    std::vector<double> temp(n);
+    int sign = 0;  // 0 ZeroSign, 1 PositiveSemiDef, -1 NegativeSemiDef, 2 Indefinite
+    for (int k = 0; k < n; ++k) {
+        int big = k;
+        double best = std::fabs(M(k, k));
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(M(i, i)) > best) best = std::fabs(M(i, i)), big = i;
+        tr[k] = big;
+        if (big != k) {  // symmetric transposition on the lower triangle
+            for (int j = 0; j < k; ++j) std::swap(M(k, j), M(big, j));
+            for (int i = big + 1; i < n; ++i) std::swap(M(i, k), M(i, big));
+            std::swap(M(k, k), M(big, big));
+            for (int i = k + 1; i < big; ++i) std::swap(M(i, k), M(big, i));
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; ++j) temp[j] = M(j, j) * M(k, j);
+            double s = 0;
+            for (int j = 0; j < k; ++j) s += M(k, j) * temp[j];
+            M(k, k) -= s;
+            for (int i = k + 1; i < n; ++i) {
+                double t = 0;
+                for (int j = 0; j < k; ++j) t += M(i, j) * temp[j];
+                M(i, k) -= t;
+            }
+        }
+        const double akk = M(k, k);
+        const bool valid = std::fabs(akk) > 0;
+        if (k == 0 && !valid) {  // the whole diagonal is zero: ZeroSign, identity transpositions
+            for (int j = 0; j < n; ++j) tr[j] = j;
+            break;
+        }
+        if (valid)
+            for (int i = k + 1; i < n; ++i) M(i, k) /= akk;
+        if (sign == 1) {
+            if (akk < 0) sign = 2;
+        } else if (sign == -1) {
+            if (akk > 0) sign = 2;
+        } else if (sign == 0) {
+            if (akk > 0) sign = 1;
+            else if (akk < 0) sign = -1;
+        }
+    }
+    if (!(sign == 1 || sign == 0)) return false;  // LinearSolverDense: x stays what it was
+    x = b;
+    for (int k = 0; k < n; ++k) std::swap(x[k], x[tr[k]]);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < i; ++k) x[i] -= M(i, k) * x[k];
+    for (int i = 0; i < n; ++i) x[i] = std::fabs(M(i, i)) > DBL_MIN ? x[i] / M(i, i) : 0.0;
+    for (int i = n - 1; i >= 0; --i)
+        for (int k = i + 1; k < n; ++k) x[i] -= M(k, i) * x[k];
+    for (int k = n - 1; k >= 0; --k) std::swap(x[k], x[tr[k]]);
+    return true;
+}
+
 // unpivoted LDL^T of a dense symmetric n x n (row-major), solves in place; false if a pivot <= 0
 bool ldltSolve(std::vector<double>& A, std::vector<double>& b, int n) {
     for (int j = 0; j < n; ++j) {
@@ -268,8 +339,10 @@ bool solveSystem(const Problem& P, const System& S, double lambda, std::vector<d
                  std::vector<double>& dxl) {
     const int n = 6 * P.nFreePose;
     std::vector<double> A((size_t)n * n, 0), g(n, 0);
-    dxp.assign((size_t)P.F * 6, 0);
-    dxl.assign((size_t)P.L * 3, 0);
+    if (g_solver_rule == 0 || dxp.size() != (size_t)P.F * 6) {  // (rule 1: x keeps its last content when the solve fails)
+        dxp.assign((size_t)P.F * 6, 0);
+        dxl.assign((size_t)P.L * 3, 0);
+    }
     for (int p = 0; p < P.F; ++p) {
         int s = P.poseSlot[p];
         if (s < 0) continue;
@@ -309,7 +382,17 @@ bool solveSystem(const Problem& P, const System& S, double lambda, std::vector<d
             }
         }
     }
-    if (n > 0 && !ldltSolve(A, g, n)) return false;
+    if (n > 0 && g_solver_rule == 1) {
+        // BlockSolver::solve fills the upper block triangle of H_schur (i1 <= i2), LinearSolverDense::solve mirrors it
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < i; ++j)
+                if (i / 6 != j / 6) A[(size_t)i * n + j] = A[(size_t)j * n + i];
+        std::vector<double> xs;
+        if (!ldltEigen(A, g, xs, n)) return false;
+        g = xs;
+    } else if (n > 0 && !ldltSolve(A, g, n)) {
+        return false;
+    }
     for (int p = 0; p < P.F; ++p)
         if (P.poseSlot[p] >= 0)
             for (int i = 0; i < 6; ++i) dxp[6 * p + i] = g[6 * P.poseSlot[p] + i];
@@ -376,8 +459,10 @@ int orc_bundle_adjustment(orc_ba_problem* in, orc_ba_stats* st) {
     Problem P;
     loadProblem(in, P);
     System S;
+    g_counters[0] = g_counters[1] = 0;
     double lambda = 0, ni = 2;
     int it = 0, trials = 0, terminated = 0;
+    std::vector<double> dxp, dxl;  // the solver's x: lives across trials and iterations
     double chi0 = robustChi2(P), chiFinal = chi0;
     const bool anyFree = (P.nFreePose + P.nFreePt) > 0;
     for (it = 0; anyFree && it < in->max_iterations; ++it) {
@@ -396,16 +481,19 @@ int orc_bundle_adjustment(orc_ba_problem* in, orc_ba_stats* st) {
         }
         double rho = 0;
         int qmax = 0;
-        std::vector<double> dxp, dxl;
         do {
             std::vector<Pose> savedPoses = P.poses;  // _optimizer->push()
             std::vector<double> savedPts = P.pts;
             bool ok2 = solveSystem(P, S, lambda, dxp, dxl);
             trials++;
-            if (!ok2) {
+            if (!ok2) g_counters[0]++;
+            if (!ok2 && g_solver_rule == 0) {
                 std::fill(dxp.begin(), dxp.end(), 0.0);
                 std::fill(dxl.begin(), dxl.end(), 0.0);
             }
+            // (rule 1: OptimizationAlgorithmLevenberg::solve applies _solver->x() whether or not the solve succeeded; after a
+            // failed solve that is still the PREVIOUS solution -- BlockSolver::solve returns before touching x -- and
+            // computeScale() below sees it too.  Zero before the first successful solve.)
             for (int p = 0; p < P.F; ++p)
                 if (!P.poseFixed[p]) poseOplus(P.poses[p], &dxp[6 * p]);
             for (int l = 0; l < P.L; ++l)
@@ -424,12 +512,13 @@ int orc_bundle_adjustment(orc_ba_problem* in, orc_ba_stats* st) {
             scale += 1e-3;
             rho /= scale;
             if (rho > 0 && std::isfinite(tempChi)) {
+                if (!ok2) g_counters[1]++;
                 double alpha = 1. - std::pow((2 * rho - 1), 3);
                 alpha = std::min(alpha, 2. / 3.);
                 double scaleFactor = std::max(1. / 3., alpha);
                 lambda *= scaleFactor;
                 ni = 2;
-                currentChi = tempChi;
+                currentChi = ok2 ? tempChi : robustChi2(P);  // (the next iteration evaluates the state it finds)
             } else {
                 lambda *= ni;
                 ni *= 2;
@@ -474,6 +563,17 @@ int orc_bundle_adjustment(orc_ba_problem* in, orc_ba_stats* st) {
     }
     return 0;
 }
+
+// Eigen::LDLT<MatrixXd>(A).isPositive() ? x = solve(b) : x untouched -- the restatement the LM loop uses, for known-answer tests
+int orc_ldlt_eigen(const double* A, const double* b, int n, double* x) {
+    std::vector<double> M(A, A + (size_t)n * n), rhs(b, b + n), xs;
+    if (!ldltEigen(M, rhs, xs, n)) return 0;
+    std::copy(xs.begin(), xs.end(), x);
+    return 1;
+}
+void orc_ba_set_solver_rule(int rule) { g_solver_rule = rule ? 1 : 0; }
+int orc_ba_get_solver_rule(void) { return g_solver_rule; }
+void orc_ba_last_counters(int32_t* out) { out[0] = g_counters[0]; out[1] = g_counters[1]; }
 
 int orc_ba_linearize(const orc_ba_problem* in, double* H, double* b, double* chi2, int ncap) {
     Problem P;

@@ -136,6 +136,18 @@ typedef struct {
 
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317). */
 int orc_bundle_adjustment(orc_ba_problem* prob, orc_ba_stats* stats);
+/* How the reduced system is solved and what a failed solve does (ba_oracle.cpp):
+ *   1 (default) g2o's LinearSolverDense as it is: Eigen::LDLT with its diagonal pivoting and sign rule, x left STALE by a
+ *     failed solve and applied / scored all the same (OptimizationAlgorithmLevenberg::solve);
+ *   0 the simplification of rounds 1-5 (unpivoted LDL^T, zero step after a failed solve), kept to quantify the difference. */
+void orc_ba_set_solver_rule(int rule);
+int orc_ba_get_solver_rule(void);
+/* of the last orc_bundle_adjustment: out[0] = failed solves, out[1] = failed solves whose stale step was accepted */
+void orc_ba_last_counters(int32_t* out);
+/* Eigen::LDLT<MatrixXd> on a dense symmetric row-major A (lower triangle read): returns isPositive(); x = solve(b) only then. */
+int orc_ldlt_eigen(const double* A, const double* b, int n, double* x);
+/* The order in which Eigen::LDLT takes the rows of a matrix with this diagonal: perm[k] = row at position k. */
+void orc_eigen_pivot_order(const double* diag, int n, int32_t* perm);
 /* The same algorithm with the BLOCKED summation order the device declares (ba_blocked_oracle.cpp): G landmark ranges
  * (wg_pt_start: G + 1 entries), nsplit column pieces per Schur chain (bits 0..15 of `nsplit`; bits 16..: K > 1 = the Schur
  * exchange adds the ranges g = k mod K per group k first, then the K group sums).  trace (may be NULL): rows {lambda, chi2, rho,

@@ -265,6 +265,17 @@ def test_windows_of_changing_shape_on_one_context(mvo, O, simctx):
 
 
 
+def test_stale_step_after_a_failed_solve(mvo, O, simctx, simlib):
+    """g2o's behaviour after a failed linear solve (the solver's x stays, is applied and scored; a negative predicted decrease
+    accepts it), on a benchmark window that meets both outcomes: the kernel source equals the blocked oracle trial by trial."""
+    simctx.ba_set_mode("throughput")
+    simlib.mvo_debug_set(b"ba_service", 2)
+    try:
+        gpu_ba_tests._stale_step_window(mvo, O, simctx)
+    finally:
+        simlib.mvo_debug_set(b"ba_service", 1)
+
+
 def test_measurements_in_lds_or_device_memory(mvo, O, simctx, simlib):
     """A > 512-edge range keeps its measurements in LDS when that costs no extra chunk of U (BA5 on 14 workgroups), in device
     memory otherwise (forced here with the A/B knob on 13 workgroups, where the LDS form needs three chunks): the oracle's bits

@@ -47,8 +47,9 @@ def test_algorithmic_work_table_names_the_kernels_of_a_frame():
     args = bench.parse([])
     work = bench.algorithmic_work(args)
     # (k_brief: latency-mode contexts; k_blur + k_brief_sample: the throughput-mode contexts of the headline run)
-    assert set(work) == {"k_pyramid", "k_fast_harris", "k_brief", "k_blur", "k_brief_sample", "k_knn2"}
+    assert set(work) == {"k_pyramid", "k_fast_harris", "k_brief", "k_blur", "k_brief_sample", "k_knn2", "k_knn2_mfma"}
     assert work["k_knn2"] == ("valu", 16.0 * 2000 * 2000)
+    assert work["k_knn2_mfma"] == ("mfma_i8", 512.0 * 2000 * 2000)      # the kernel that runs: an i8 Gram on the matrix cores
     # BA5 is 11.2 MFLOP per LM trial
     assert abs(bench.ba_trial_flops(9386, 2000, 5, False) / 1e6 - 11.2) < 0.3
 
@@ -68,3 +69,18 @@ def test_roofline_side_figures_come_from_the_newest_rounds_profile_files():
     assert res and res["vgpr"] == 256 and res["source"].startswith("profiles/r05")
     fh = bench.kernel_resources("k_fast_harris")
     assert fh["vgpr"] <= 64 and fh["scratch_bytes_per_lane"] == 0 and fh["occupancy"] == 8
+
+
+def test_ba_flop_count_credits_each_stage_where_it_runs():
+    """SURVEY 8d's F_trial split by stage: the linearisation once per iteration, Schur + factorisation per trial, back-substitution
+    + chi2 only for the trials whose step is applied (a trial that ends at the failed factorisation runs neither)."""
+    import bench
+    E, L, F = 9386, 2000, 5
+    full = bench.ba_trial_flops(E, L, F, False)
+    # one iteration, one applied trial = one full trial
+    assert abs(bench.ba_solve_flops(E, L, F, False, 1, 1, 1) - full) < 1e-6 * full
+    # the benchmarked window: 50 iterations, ~85 trials of which ~35 end at the failed factorisation -> ~817 MFLOP, not 85 x 11.3
+    w = bench.ba_solve_flops(E, L, F, False, 50, 85.1, 50.0)
+    assert 780e6 < w < 850e6 and w < 0.9 * 85.1 * full
+    # pose-only: no landmark terms
+    assert bench.ba_solve_flops(E, L, F, True, 1, 1, 1) == 330 * E + (6 * F) ** 3 / 3 + 60 * E

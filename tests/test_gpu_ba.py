@@ -271,7 +271,7 @@ def test_config4_ba10_window(mvo, O, ctx):
 # Bit-exact parity: the device declares the association of every sum of the solve; the oracle restates the
 # same LM algorithm with that blocked order (oracle/ba_blocked_oracle.cpp).  Then ALL 50 iterations must agree exactly:
 # every trial's damping, robust chi2, gain ratio and accept/reject decision, and the final poses and landmarks bit for bit.
-def _bitwise(mvo, O, ctx, pb, **kw):
+def _bitwise(mvo, O, ctx, pb, trace_out=None, **kw):
     ctx.ba_trace_enable(True)
     try:
         P, X, st = ctx.bundle_adjustment(*_args(pb), **kw)
@@ -293,6 +293,8 @@ def _bitwise(mvo, O, ctx, pb, **kw):
     assert st["lambda_final"] == sto["lambda_final"], msg
     assert np.array_equal(P, Po), msg + "\nmax pose difference %g" % np.abs(P - Po).max()
     assert np.array_equal(X, Xo), msg + "\nmax landmark difference %g" % np.abs(X - Xo).max()
+    if trace_out is not None:
+        trace_out.append(tr)
     return st, plan
 
 
@@ -301,6 +303,31 @@ def test_bitwise_the_benchmarked_window_all_50_iterations(mvo, O, ctx):
     iterations): north-star '1e-4 on poses and landmarks' is met with zero difference."""
     st, plan = _bitwise(mvo, O, ctx, mvo.synth.ba_problem(5, 2000, 7), fix_points=False)
     assert st["iterations"] == 50 and st["trials"] > 60 and plan["wgs"] == 28  # (one XCD minus the 4 CUs left to other kernels)
+
+
+def _stale_step_window(mvo, O, ctx):
+    """A window of bench.py's pool (shard 3, window 0) whose 14-workgroup solve runs into g2o's stale-step rule: a failed
+    factorisation leaves the solver's x what it was, OptimizationAlgorithmLevenberg applies and scores it with tempChi = DBL_MAX,
+    and a negative computeScale() of that stale step ACCEPTS it (g2o_ba.cpp:196-197 picks LinearSolverDense, :288 runs the loop)."""
+    pb = mvo.synth.ba_problem(5, 2000, 3007)
+    out = []
+    st, plan = _bitwise(mvo, O, ctx, pb, trace_out=out, fix_points=False)
+    tr = out[0]
+    failed = tr[:, 1] > 1e300
+    assert plan["wgs"] == 14 and failed.sum() > 5 and (failed & (tr[:, 3] > 0)).sum() > 0, (plan["wgs"], failed.sum(), (failed & (tr[:, 3] > 0)).sum())
+    assert (failed & (tr[:, 3] == 0)).sum() > 0          # and the usual outcome (positive stale scale: rejected) next to it
+    return st
+
+
+def test_bitwise_stale_step_after_a_failed_solve(mvo, O):
+    c = mvo.Context(0)
+    try:
+        c.ba_set_mode("throughput")
+        mvo.debug_set("ba_service", 2)
+        _stale_step_window(mvo, O, c)
+    finally:
+        mvo.debug_set("ba_service", 1)
+        c.close()
 
 
 def _bench_windows(mvo):

@@ -239,3 +239,113 @@ def test_orders_meet_at_the_optimum_ba10(O, mvo):
     Pb, Xb, stb, _ = O.bundle_adjustment_blocked(*_args(pb), plan=plan, **kw)
     assert sts["terminated"] and stb["terminated"] and sts["iterations"] < 1000 and stb["iterations"] < 1000
     assert np.abs(Pb - Ps).max() < 1e-9 and _rel(Xb, Xs) < 1e-7, (np.abs(Pb - Ps).max(), _rel(Xb, Xs))
+
+
+# ---------------------------------------------------------------- g2o's LinearSolverDense = Eigen::LDLT (round 6)
+def _eigen_pivot_order_py(diag):
+    """Eigen LDLT.h, ldlt_inplace<Lower>::unblocked: at step k the FIRST largest |diagonal entry| among k.. is swapped to k; the
+    entries behind k are still the input's (left-looking), so the order is a function of the diagonal alone."""
+    a = [abs(float(v)) for v in diag]
+    perm = list(range(len(a)))
+    for k in range(len(a)):
+        big = k
+        for i in range(k + 1, len(a)):
+            if a[i] > a[big]:
+                big = i
+        a[k], a[big] = a[big], a[k]
+        perm[k], perm[big] = perm[big], perm[k]
+    return perm
+
+
+def _ldlt_eigen(O, A, b):
+    import ctypes as C
+    A = np.ascontiguousarray(A, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    x = np.full(len(b), 777.0)
+    ok = O.lib().orc_ldlt_eigen(A.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), len(b), x.ctypes.data_as(C.c_void_p))
+    return ok, x
+
+
+def test_eigen_pivot_order_with_and_without_ties(O):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    cases = [rng.standard_normal(30), np.array([3.0, 1.0, 3.0, 2.0, 1.0, 3.0]), np.array([1.0, 1.0, 1.0, 1.0]),
+             np.repeat(rng.uniform(1, 9, 10), 3)[rng.permutation(30)], -rng.uniform(1, 2, 7), np.zeros(5)]
+    for _ in range(50):                               # the pose-only shape: equal x / y translation entries inside every 6-block
+        d = rng.uniform(1, 1e3, 30)
+        d[4::6] = d[3::6]
+        cases.append(d)
+    for d in cases:
+        d = np.ascontiguousarray(d, np.float64)
+        perm = np.zeros(len(d), np.int32)
+        O.lib().orc_eigen_pivot_order(d.ctypes.data_as(C.c_void_p), len(d), perm.ctypes.data_as(C.c_void_p))
+        assert list(perm) == _eigen_pivot_order_py(d)
+        assert sorted(perm) == list(range(len(d)))
+        assert np.all(np.diff(np.abs(d)[perm]) <= 0)   # descending |diagonal|
+    # a swap moves the displaced entry BEHIND equal ones: not the stable order
+    assert _eigen_pivot_order_py([1.0, 2.0, 1.0]) == [1, 0, 2] and _eigen_pivot_order_py([1.0, 1.0, 2.0, 1.0]) == [2, 1, 0, 3]
+
+
+def test_eigen_ldlt_restatement_solves_and_classifies(O):
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 7, 30, 60):
+        B = rng.standard_normal((n, n + 3))
+        A = B @ B.T + 1e-3 * np.eye(n)
+        b = rng.standard_normal(n)
+        ok, x = _ldlt_eigen(O, A, b)
+        assert ok == 1 and np.abs(x - np.linalg.solve(A, b)).max() < 1e-9 * max(1, np.abs(x).max())
+        # only the lower triangle is read (LDLT<MatrixXd, Lower>)
+        ok2, x2 = _ldlt_eigen(O, np.tril(A) + 5 * np.triu(np.ones((n, n)), 1), b)
+        assert ok2 == 1 and np.array_equal(x, x2)
+    # indefinite / negative: "not positive" -> x is left alone (g2o's LinearSolverDense returns false without touching it)
+    for A in (np.diag([2.0, -1.0, 3.0]), -np.eye(4), np.array([[1.0, 2.0], [2.0, 1.0]])):
+        ok, x = _ldlt_eigen(O, A, np.ones(len(A)))
+        assert ok == 0 and np.all(x == 777.0)
+    # zero pivots pass isPositive() (PositiveSemiDef); the solve zeroes their rows (pseudo-inverse of D)
+    ok, x = _ldlt_eigen(O, np.diag([2.0, 0.0, 1.0]), np.array([4.0, 5.0, 6.0]))
+    assert ok == 1 and np.array_equal(x, [2.0, 0.0, 6.0])
+    ok, x = _ldlt_eigen(O, np.zeros((3, 3)), np.ones(3))
+    assert ok == 1 and np.array_equal(x, np.zeros(3))
+    # a negative pivot that only shows AFTER elimination, and one that the unpivoted order would meet first
+    A = np.array([[4.0, 6.0], [6.0, 5.0]])      # d0 = 5 (pivoted to the front), then 4 - 36 / 5 < 0
+    assert _ldlt_eigen(O, A, np.ones(2))[0] == 0
+
+
+def test_failed_solve_keeps_and_scores_the_stale_step(O, S):
+    """OptimizationAlgorithmLevenberg::solve after a failed linear solve: x is still the previous solution, tempChi = DBL_MAX (finite),
+    rho = (chi - DBL_MAX) / computeScale(stale x): a negative scale ACCEPTS the stale step.  The gauge-free benchmark windows hover
+    at the damping where the reduced system stops being numerically positive, so both outcomes occur there."""
+    import ctypes as C
+    lib = O.lib()
+    assert lib.orc_ba_get_solver_rule() == 1
+    seen_fail = seen_accept = 0
+    c = (C.c_int32 * 4)()
+    for seed in (7, 1007):
+        pb = S.ba_problem(5, 2000, seed)
+        P1, X1, st1 = O.bundle_adjustment(*_args(pb), fix_points=False)
+        lib.orc_ba_last_counters(c)
+        seen_fail += c[0]
+        seen_accept += c[1]
+        assert np.isfinite(st1["chi2_final"]) and st1["chi2_final"] < st1["chi2_initial"]
+        try:
+            lib.orc_ba_set_solver_rule(0)
+            P0, X0, st0 = O.bundle_adjustment(*_args(pb), fix_points=False)
+            lib.orc_ba_last_counters(c)
+            assert c[1] == 0                       # the rounds 1-5 rule never applies a step after a failed solve
+        finally:
+            lib.orc_ba_set_solver_rule(1)
+        # both rules reach the same basin: the robust objective agrees to 1e-4 relative
+        assert abs(st0["chi2_final"] - st1["chi2_final"]) < 1e-4 * st0["chi2_final"]
+    assert seen_fail > 20 and seen_accept > 0
+    # a well-posed window (two poses anchored) never fails a solve: both rules are the same run up to the pivot order's rounding
+    pb = S.ba_problem(5, 600, 3)
+    fixed = np.array([1, 1, 0, 0, 0], np.uint8)
+    P1, X1, st1 = O.bundle_adjustment(*_args(pb), fix_points=False, pose_fixed=fixed)
+    lib.orc_ba_last_counters(c)
+    assert c[0] == 0
+    try:
+        lib.orc_ba_set_solver_rule(0)
+        P0, X0, st0 = O.bundle_adjustment(*_args(pb), fix_points=False, pose_fixed=fixed)
+    finally:
+        lib.orc_ba_set_solver_rule(1)
+    assert st0["trials"] == st1["trials"] and np.abs(P0 - P1).max() < 1e-8 and np.abs(X0 - X1).max() < 1e-6

@@ -12,6 +12,6 @@ for nq, nt in ((2000, 2000), (4000, 4000), (1000, 2000)):
             ctx.profile_enable(True); ctx.profile_reset()
             for _ in range(50): ctx.match_knn2(q, t)
             pr = ctx.profile_get(); ctx.profile_enable(False)
-            n, ms = pr["k_knn2"]
+            n, ms = pr.get("k_knn2_mfma", pr.get("k_knn2"))
             print("%dx%d mfma=%d host_out=%d: %.2f us per launch" % (nq, nt, mfma, host, ms / n * 1e3))
 mvo.debug_set("match_mfma", 1); mvo.debug_set("match_host_out", 1)
