@@ -46,14 +46,60 @@ typedef ba_u64 u64;
     } while (0)
 
 // ------------------------------------------------------------------------------------------------ small helpers
+// The value lane (lane ^ O) holds, O = 32, 16, 8, 4, 2, 1 -- what __shfl_xor(v, O) returns, without its round trip through the LDS
+// crossbar (ds_bpermute: ~100 cycles per step; a block sum sits on the critical path of every LM trial several times):
+// v_permlane32_swap / v_permlane16_swap (gfx950) for the two wide steps, DPP row operations for the four inside a row of 16.
+template <int O>
+__device__ __forceinline__ double xor_partner_d(double v) {
+#ifndef MVO_KERNEL_SIM
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    unsigned plo, phi;
+    if (O == 32) {  // swap(a, a): first result = the lower half twice, second = the upper half twice
+        const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const bool up = (threadIdx.x & 32) != 0;
+        plo = up ? l2[0] : l2[1];
+        phi = up ? h2[0] : h2[1];
+    } else if (O == 16) {  // swap(a, a): first result = rows 0 0 2 2, second = rows 1 1 3 3
+        const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const bool odd = (threadIdx.x & 16) != 0;
+        plo = odd ? l2[0] : l2[1];
+        phi = odd ? h2[0] : h2[1];
+    } else if (O == 8) {  // row_ror:8
+        plo = __builtin_amdgcn_update_dpp(0u, lo, 0x128, 0xf, 0xf, false);
+        phi = __builtin_amdgcn_update_dpp(0u, hi, 0x128, 0xf, 0xf, false);
+    } else if (O == 4) {  // banks 0, 2 read lane + 4 (row_shl:4), banks 1, 3 read lane - 4 (row_shr:4)
+        plo = __builtin_amdgcn_update_dpp(0u, lo, 0x104, 0xf, 0x5, false);
+        plo = __builtin_amdgcn_update_dpp(plo, lo, 0x114, 0xf, 0xa, false);
+        phi = __builtin_amdgcn_update_dpp(0u, hi, 0x104, 0xf, 0x5, false);
+        phi = __builtin_amdgcn_update_dpp(phi, hi, 0x114, 0xf, 0xa, false);
+    } else {  // quad_perm [2, 3, 0, 1] / [1, 0, 3, 2]
+        plo = __builtin_amdgcn_update_dpp(0u, lo, O == 2 ? 0x4e : 0xb1, 0xf, 0xf, false);
+        phi = __builtin_amdgcn_update_dpp(0u, hi, O == 2 ? 0x4e : 0xb1, 0xf, 0xf, false);
+    }
+    return __hiloint2double((int)phi, (int)plo);
+#else
+    return __shfl_xor(v, O);
+#endif
+}
+// xor butterfly 32, 16, .. 1 (part of the canonical arithmetic: ba_types.h)
 __device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v += xor_partner_d<32>(v);
+    v += xor_partner_d<16>(v);
+    v += xor_partner_d<8>(v);
+    v += xor_partner_d<4>(v);
+    v += xor_partner_d<2>(v);
+    v += xor_partner_d<1>(v);
     return v;
 }
 __device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    v = fmax(v, xor_partner_d<32>(v));
+    v = fmax(v, xor_partner_d<16>(v));
+    v = fmax(v, xor_partner_d<8>(v));
+    v = fmax(v, xor_partner_d<4>(v));
+    v = fmax(v, xor_partner_d<2>(v));
+    v = fmax(v, xor_partner_d<1>(v));
     return v;
 }
 // deterministic block reductions (xor butterfly inside a wave, waves combined in index order)
@@ -355,45 +401,63 @@ __device__ __forceinline__ int wave_min_i(int v) {
 #endif
 }
 
-// The pivot order of Eigen::LDLT (g2o's LinearSolverDense, g2o_ba.cpp:196-197), run by ONE wave.  Eigen's factorisation
-// (LDLT.h, ldlt_inplace<Lower>::unblocked) swaps, at step k, the largest |diagonal entry| among the positions k .. n-1 --
-// the FIRST maximum -- to position k; it is left-looking, so the entries behind k still hold the INPUT diagonal when they are
-// compared: the order is a function of diag(S) alone.  ab[0 .. n) = |diag S| (LDS, n <= 128: position lane and lane + 64 per
-// lane); perm[k] = row of S that ends up at position k.  Without equal entries that is the descending order (ranks by
-// counting); with equal entries -- the rule in pose-only windows: the x and y translation entries of a pose block are the
-// same sums -- the swap sequence itself is replayed on integer keys (dense rank << 7 | position: the wave minimum is the
-// first maximum).  A NaN on the diagonal: identity (the factorisation then stops at that pivot).
-__device__ __forceinline__ void ba_pivot_order(const double* ab, int n, short* perm, int lane) {
-    const int p0 = lane, p1 = lane + 64;
-    const double a0 = p0 < n ? ab[p0] : -1.0, a1 = p1 < n ? ab[p1] : -1.0;
-    int r0 = 0, r1 = 0;
-    bool tie = false;
-    for (int j = 0; j < n; ++j) {
-        const double b = ab[j];
-        r0 += b > a0 ? 1 : 0;
-        r1 += b > a1 ? 1 : 0;
-        tie = tie || (b == a0 && j != p0) || (b == a1 && j != p1);
-    }
-    const bool isnan_ = (p0 < n && a0 != a0) || (p1 < n && a1 != a1);
-    if (__ballot(isnan_) != 0) {
-        if (p0 < n) perm[p0] = (short)p0;
-        if (p1 < n) perm[p1] = (short)p1;
-        return;
-    }
-    if (__ballot(tie) == 0) {
-        if (p0 < n) perm[r0] = (short)p0;
-        if (p1 < n) perm[r1] = (short)p1;
-        return;
-    }
+// Sum of a 32-bit value over the aligned group of `width` (4 / 8 / 16) consecutive lanes, in every lane of the group.
+__device__ __forceinline__ int group_sum_i(int v, int width) {
+#ifndef MVO_KERNEL_SIM
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);   // quad_perm [1, 0, 3, 2]: lane ^ 1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);   // quad_perm [2, 3, 0, 1]: lane ^ 2 -> every lane: its quad's sum
+    if (width >= 8) v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror: the other quad of the 8
+    if (width >= 16) v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false); // row_mirror: the other half of the 16
+    return v;
+#else
+    for (int o = 1; o < width; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+#endif
+}
+
+// The pivot order of Eigen::LDLT (g2o's LinearSolverDense, g2o_ba.cpp:196-197).  Eigen's factorisation (LDLT.h,
+// ldlt_inplace<Lower>::unblocked) swaps, at step k, the largest |diagonal entry| among the positions k .. n-1 -- the FIRST
+// maximum -- to position k; it is left-looking, so the entries behind k still hold the INPUT diagonal when they are compared:
+// the order is a function of diag(S) alone.  Without equal entries that is the descending order: dense ranks by counting,
+// made by the whole workgroup (ba_window).  With equal entries -- the rule in pose-only windows: the x and y translation entries
+// of a pose block are the same sums -- the swap sequence itself is replayed by ONE wave on integer keys (dense rank << 7 |
+// position: the wave minimum is the first maximum); position lane and lane + 64 per lane (n <= 128).  rank[i]: number of
+// entries strictly larger than entry i.  perm[k] = row of S that ends up at position k.
+// (uniform value `val` into lane `l` of `old`)
+__device__ __forceinline__ int writelane_i(int old, int val, int l) {
+#ifndef MVO_KERNEL_SIM
+    // (no clang builtin for it in ROCm 7.2; gfx9 allows ONE scalar register per vector instruction: the lane select goes through m0)
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
+    return old;
+#else
+    return (int)(threadIdx.x & 63) == l ? val : old;
+#endif
+}
+// (out of line: run by one wave on the rare path; inlined, its registers would count against the whole LM loop)
+__device__ __attribute__((noinline)) void ba_pivot_replay(const short* rank, int n, short* perm, int lane) {
     const int done = 0x7fffffff;
-    int k0 = p0 < n ? (r0 << 7) | p0 : done, k1 = p1 < n ? (r1 << 7) | p1 : done;
+    if (n <= 64) {  // one position per lane: every step is a wave minimum, three v_readlane and four v_writelane
+        int key = lane < n ? ((int)rank[lane] << 7) | lane : done, el = lane;
+        for (int k = 0; k < n; ++k) {
+            const int big = wave_min_i(key) & 127;  // position of the first maximum among k .. n-1
+            const int ek = __builtin_amdgcn_readlane(el, k), kk = __builtin_amdgcn_readlane(key, k), eb = __builtin_amdgcn_readlane(el, big);
+            el = writelane_i(el, ek, big);          // what sat at position k goes to position `big` ...
+            key = writelane_i(key, (kk & ~127) | big, big);
+            el = writelane_i(el, eb, k);            // ... and position k is final
+            key = writelane_i(key, done, k);
+        }
+        if (lane < n) perm[lane] = (short)el;
+        return;
+    }
+    const int p0 = lane, p1 = lane + 64;
+    int k0 = p0 < n ? ((int)rank[p0] << 7) | p0 : done, k1 = p1 < n ? ((int)rank[p1] << 7) | p1 : done;
     int e0 = p0, e1 = p1;
     for (int k = 0; k < n; ++k) {
-        const int big = wave_min_i(min(k0, k1)) & 127;  // position of the first maximum among k .. n-1
+        const int big = wave_min_i(min(k0, k1)) & 127;
         const int ek = k < 64 ? __builtin_amdgcn_readlane(e0, k) : __builtin_amdgcn_readlane(e1, k - 64);
         const int kk = k < 64 ? __builtin_amdgcn_readlane(k0, k) : __builtin_amdgcn_readlane(k1, k - 64);
         const int eb = big < 64 ? __builtin_amdgcn_readlane(e0, big) : __builtin_amdgcn_readlane(e1, big - 64);
-        const int kmoved = (kk & ~127) | big;  // what sat at position k goes to position `big`
+        const int kmoved = (kk & ~127) | big;
         if (p0 == big) e0 = ek, k0 = kmoved;
         if (p1 == big) e1 = ek, k1 = kmoved;
         if (p0 == k) e0 = eb, k0 = done;
@@ -404,6 +468,34 @@ __device__ __forceinline__ void ba_pivot_order(const double* ab, int n, short* p
 }
 
 #include "ba_solve.h"  // readlane_d, ba_rcp_pivot, the one-wave solver of the 5-pose class (solve_wave_32), the block solver (solve_block)
+
+// computeScale() of the landmark part of the solver's current x over one range: sum over its landmarks l (lane = l mod 64, then one
+// 64-lane butterfly) of x_l . (lambda x_l + b_l).  x: device memory (L1-bypassing loads), b_l: LDS at offset bl_off of the dynamic
+// segment.  Out of line and run by ONE wave beside the Schur chains: its registers do not count against the LM loop's.
+__device__ __attribute__((noinline)) double ba_stale_scale_landmarks(const u64* dxl, int bl_off, int Lg, double lambda, int lane) {
+    const double* bl = ba_dyn_lds + bl_off;
+    double sp = 0;
+    for (int l0 = lane; l0 < Lg; l0 += 4 * 64) {
+        double xs[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int l = l0 + 64 * u;
+                xs[u][c] = l < Lg ? __longlong_as_double((long long)__hip_atomic_load(dxl + 3 * l + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0.0;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int l = l0 + 64 * u;
+            if (l < Lg) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sp += xs[u][c] * (lambda * xs[u][c] + bl[3 * l + c]);
+            }
+        }
+    }
+    return wave_sum_d(sp);
+}
+
 
 // the same arithmetic for more than 63 unknowns (> 10 free poses): one wave, matrix in LDS (row pitch n + 2)
 __device__ __attribute__((noinline)) int solve_lds(int sl_off, int cb_off, int n, int lane) {
@@ -474,8 +566,9 @@ struct WgLds {
     double* bl;     // maxLg x 3
     double* Cc;     // maxLg x 6 (pitch BA_XS)   Cholesky factor of (H_ll + lambda I)^-1
     double* cl;     // maxLg x 3   C^T b_l
-    double* dxl;    // Lg x 3 in DEVICE memory (BaDev::dxl_dev, this range's part): landmark part of the solver's x = the step of
-                    // the last SUCCESSFUL solve (g2o keeps it when a solve fails); element l is only ever touched by thread l % 512
+    double* dxl;    // Lg x 3 in DEVICE memory (BaDev::dxl_dev, this range's part): landmark part of the solver's x = the step of the
+                    // last SUCCESSFUL solve (g2o keeps it when a solve fails).  Written by the landmark's thread when a step is
+                    // applied, read (L1-bypassing) by the last wave beside the Schur chains and when a stale step is applied.
     double* U;      // `uarea` doubles: see above
     double* E2;     // rows [a0 | a1 | x | e~] (pitch BA_E2S) of the edges that do not keep them in registers: all edges
                     // (SLOTS = 0) or the edges 512 .. Eg - 1
@@ -654,8 +747,9 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     __shared__ int sFlag[4];
     __shared__ double sStale[BA_WAVES + 2];  // wave partials of the stale step's predicted decrease; [8]: rho of a failed solve
     __shared__ short sPerm[6 * BA_MAX_POSES];  // Eigen's pivot order of the trial's reduced system
+    __shared__ short sRank[6 * BA_MAX_POSES];  // dense ranks of |diag S| (only read when entries tie)
     __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
-    if (threadIdx.x == 0) sFlag[2] = 0;
+    if (threadIdx.x == 0) sFlag[1] = sFlag[2] = sFlag[3] = 0;  // [1] NaN on the diagonal, [2] exchange timed out, [3] equal diagonal entries
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = B.n, G = B.G, nfree = B.nfree, urows = B.ldu, ldu = B.ldu + 1, nlow = B.nlow, npk = B.npk;
@@ -894,6 +988,14 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     }
     __syncthreads();
 
+    // pivot order of every trial (T3): the H_pp diagonal entries this thread compares -- row i = tid >> lsh against j = jj, jj + LPR --
+    // as offsets into sHpp, three times 10 bits (constant for the whole solve)
+    int piv_hoff = 0;
+    if (n > 0) {
+        const int lsh = n <= 32 ? 4 : (n <= 64 ? 3 : 2), LPR = 1 << lsh, jj = tid & (LPR - 1);
+        const int qi = min(tid >> lsh, n - 1), q0 = min(jj, n - 1), q1 = min(jj + LPR, n - 1);
+        piv_hoff = (36 * sSlotPose[qi / 6] + 7 * (qi % 6)) | (36 * sSlotPose[q0 / 6] + 7 * (q0 % 6)) << 10 | (36 * sSlotPose[q1 / 6] + 7 * (q1 % 6)) << 20;
+    }
     for (it = 0; any_free && !error && it < B.max_it; ++it) {
         // ================= LIN: whitened Jacobians of the own edges (EdgeProjectXYZ2UV::linearizeOplus), kept in registers;
         // X~ and e~ also go to the staging area for the landmark blocks
@@ -1171,15 +1273,9 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
         do {
             STAMP(0);
             // ============= T1: (H_ll + lambda I)^-1 = C C^T and C^T b_l of the own landmarks
-            double stale_l = 0;
             int ist = nlow;  // where the summed stale-scale entry ends up in Rl
             if (!B.fix_points) {
                 for (int l = tid; l < Lg; l += BA_THREADS) {
-                    double xs[3] = {0, 0, 0};  // (device memory: fetched first, used last)
-                    if (do_schur) {
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) xs[c] = W.dxl[3 * l + c];
-                    }
                     const double* h = W.Hll + BA_XS * l;
                     const double D[9] = {h[0] + lambda, h[1], h[2], h[1], h[3] + lambda, h[4], h[2], h[4], h[5] + lambda};
                     double Di[9];
@@ -1198,14 +1294,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     W.cl[3 * l] = c00 * b[0] + c10 * b[1] + c20 * b[2];
                     W.cl[3 * l + 1] = c11 * b[1] + c21 * b[2];
                     W.cl[3 * l + 2] = c22 * b[2];
-                    if (do_schur) {  // computeScale() of the x the solver holds NOW, landmark part (needed if this trial's solve fails)
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) stale_l += xs[c] * (lambda * xs[c] + b[c]);
-                    }
-                }
-                if (do_schur) {
-                    stale_l = wave_sum_d(stale_l);
-                    if (lane == 0) sStale[wave] = stale_l;
                 }
                 __syncthreads();
             }
@@ -1280,6 +1368,16 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                         }
                     }
                     STAMP(3);
+                    if (ch == 0 && wave == BA_WAVES - 1) {
+                        // computeScale() of the x the solver holds NOW (what g2o scores if this trial's solve fails), landmark part of
+                        // this range: lane = landmark mod 64, one 64-lane butterfly.  Read from device memory by the wave that has no
+                        // chain in the 5-pose class (3 tile pairs x 2 pieces on 8 waves): the latency hides beside the chains.
+                        const double sp = ba_stale_scale_landmarks(reinterpret_cast<const u64*>(W.dxl), (int)(W.bl - dyn), Lg, lambda, lane);
+                        if (lane == 0) {
+                            sStale[0] = sp;
+                            if (G == 1) W.Rl[nlow] = sp;
+                        }
+                    }
                     // ---- chains of this chunk; after the last chunk the sums are published (or kept when the window has
                     // one workgroup)
                     const int st0 = ch * npar * msplit;  // first MFMA step of the chunk
@@ -1349,13 +1447,6 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 }
                 STAMP(5);
                 PH_END(4);
-                if (tid == 0) {  // this range's partial (the 8 wave sums in order) rides along as one more packed entry
-                    double sv = 0;
-#pragma unroll
-                    for (int w = 0; w < BA_WAVES; ++w) sv += sStale[w];
-                    stale_l = sv;
-                    if (G == 1) W.Rl[nlow] = sv;
-                }
                 if (G > 1) {
                     __syncthreads();
                     STAMP(6);
@@ -1372,7 +1463,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     const int slicex = (nlowx + Gk - 1) / Gk;
                     ist = nlow + nhpx;
                     for (int q = tid; q < nhpx; q += BA_THREADS) gstore_d(B.xP + 2 * ((size_t)g * npk + nlow + q), tag0 + tagA, W.hpl[q], grp_l2);
-                    if (tid == 0) gstore_d(B.xP + 2 * ((size_t)g * npk + ist), tag0 + tagA, stale_l, grp_l2);
+                    if (tid == 0) gstore_d(B.xP + 2 * ((size_t)g * npk + ist), tag0 + tagA, sStale[0], grp_l2);  // (rides along as one more packed entry)
                     const int sl0 = gj * slicex, sln = max(0, min(slicex, nlowx - sl0));
                     if (sln > 0) {
                         // item q = (w, el): partial of the group's workgroup w (= workgroup w K + gk), entry sl0 + el
@@ -1437,16 +1528,53 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             PH_END(5);
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n] -- rows and columns in the
             // pivot order Eigen::LDLT would choose for it (sPerm, from |diag S|) -- and solves it
-            if (wave == 0 && n > 0) {
-                double* ab = W.colbuf;  // (192 doubles, free until the solve)
-                for (int i = lane; i < n; i += 64) {
-                    const double gsum = do_schur ? W.Rl[i * (i + 1) / 2 + i] : 0.0;
-                    ab[i] = fabs((sHpp[36 * sSlotPose[i / 6] + 7 * (i % 6)] + lambda) - gsum);
+            if (n > 0) {
+                // dense rank of every |diagonal entry| by counting, all 512 threads: row i = tid / LPR compares its entry with the
+                // entries j = jj, jj + LPR, ... (LPR = 512 / P lanes per row, P = 32 / 64 / 128 >= n); every thread forms the entries it
+                // needs itself (no hand-off, no barrier before the counting)
+                const int lsh = n <= 32 ? 4 : (n <= 64 ? 3 : 2), LPR = 1 << lsh;
+                const int i = tid >> lsh, jj = tid & (LPR - 1);  // (shifts: a division by a run-time value costs ~40 instructions)
+// (a macro, not a lambda: behind a by-reference capture the compiler parks the register-resident edge rows in scratch memory)
+#define BA_ADIAG(q, hoff) fabs((sHpp[hoff] + lambda) - (do_schur ? W.Rl[(q) * ((q) + 1) / 2 + (q)] : 0.0))
+                // (two entries per round, formed before they are compared: their LDS reads are in flight together)
+                const int j0 = jj, j1 = jj + LPR;
+                // (clamped indices, values selected afterwards: no branch between the three chains of LDS reads)
+                const int qi = min(i, n - 1), q0 = min(j0, n - 1), q1 = min(j1, n - 1);
+                const double vi = BA_ADIAG(qi, piv_hoff & 1023), v0 = BA_ADIAG(q0, (piv_hoff >> 10) & 1023), v1 = BA_ADIAG(q1, piv_hoff >> 20);
+                const double ai = i < n ? vi : -1.0, b0 = j0 < n ? v0 : -2.0, b1 = j1 < n ? v1 : -2.0;
+                int v = ai != ai ? 1 << 24 : 0;
+                v += (b0 > ai ? 1 : 0) + ((b0 == ai && j0 != i) ? 1 << 12 : 0);
+                v += (b1 > ai ? 1 : 0) + ((b1 == ai && j1 != i) ? 1 << 12 : 0);
+                for (int j = jj + 2 * LPR; j < n; j += 2 * LPR) {
+                    const double c0 = BA_ADIAG(j, 36 * sSlotPose[j / 6] + 7 * (j % 6));
+                    const double c1 = j + LPR < n ? BA_ADIAG(j + LPR, 36 * sSlotPose[(j + LPR) / 6] + 7 * ((j + LPR) % 6)) : -2.0;
+                    v += (c0 > ai ? 1 : 0) + ((c0 == ai && j != i) ? 1 << 12 : 0);
+                    v += (c1 > ai ? 1 : 0) + ((c1 == ai && j + LPR != i) ? 1 << 12 : 0);
                 }
-                __builtin_amdgcn_wave_barrier();
-                ba_pivot_order(ab, n, sPerm, lane);
+                STAMP(24);
+                v = group_sum_i(v, LPR);  // bits 0..11: entries larger than mine, 12..23: entries equal to mine, 24..: NaN
+                if (jj == 0 && i < n) {
+                    const int rk = v & 0xfff;
+                    sRank[i] = (short)rk;
+                    sPerm[rk] = (short)i;  // (the order itself when no two entries are equal)
+                    if (v >> 24) sFlag[1] = 1;
+                    else if ((v >> 12) & 0xfff) sFlag[3] = 1;
+                }
+                STAMP(25);
+                __syncthreads();
+                STAMP(26);
+                if (sFlag[1] | sFlag[3]) {  // (uniform) NaN: identity -- the factorisation stops at that pivot --; equal entries: replay the swaps
+                    if (wave == 0) {
+                        if (sFlag[1]) {
+                            for (int q = lane; q < n; q += 64) sPerm[q] = (short)q;
+                        } else {
+                            ba_pivot_replay(sRank, n, sPerm, lane);
+                        }
+                    }
+                    __syncthreads();
+                }
+                STAMP(27);
             }
-            __syncthreads();
             if (NR != 0) {
                 // register solvers: the system embedded into NR rows (identity rows behind n, the rhs as row NR - 1)
                 constexpr int NRR = NR ? (NR < 0 ? -NR : NR) : 32, RR = NRR - 1, PP = NRR + 1;
@@ -1493,6 +1621,19 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             __syncthreads();
             STAMP(12);
             PH_END(6);
+            if (wave == BA_WAVES - 1) {
+                // what g2o's LM would make of THIS trial if the solve below fails: it applies the solver's x all the same -- still
+                // the previous solution (sDx / dxl) --, sets tempChi = DBL_MAX and divides by computeScale() of that stale x.  Formed
+                // beside the solve (the register solver runs on wave 0 alone): pose part as one 64-lane butterfly + the landmark
+                // part that rode along with the Schur exchange, + 1e-3.
+                double ps = 0;
+                for (int t = lane; t < 6 * B.F; t += 64)
+                    if (sSlot[t / 6] >= 0) ps += sDx[t] * (lambda * sDx[t] + sBp[t]);
+                ps = wave_sum_d(ps);
+                double sc = (do_schur ? W.Rl[ist] : 0.0) + ps;
+                sc += 1e-3;
+                if (lane == 0) sStale[BA_WAVES] = (currentChi - 1.7976931348623157e308) / sc;
+            }
             {
                 const int sl_off = (int)(W.SL - dyn), cb_off = (int)(W.colbuf - dyn);
                 if (n > 0 && (NR == 64 || NR == -32)) {
@@ -1516,6 +1657,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             }
             __syncthreads();
             const int ok2 = sFlag[0];
+            if (tid == 0) sFlag[1] = sFlag[3] = 0;  // (re-armed for the next trial's pivot order: read before the solve, written again many barriers later)
             if (ok2 && tid < 6 * B.F) {
                 const int sl = sSlot[tid / 6];
                 sDx[tid] = sl >= 0 ? sSol[6 * sl + tid % 6] : 0.0;
@@ -1536,17 +1678,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 // along with the Schur exchange), so all of them know the outcome at the same time and without another exchange.  On
                 // the gauge-free window of the benchmark every rejection is of this kind: lambda shrinks by 1/3 per accepted step
                 // until the reduced system stops being numerically positive definite, then bounces.
-                if (wave == 0) {
-                    double ps = 0;
-                    for (int t = lane; t < 6 * B.F; t += 64)
-                        if (sSlot[t / 6] >= 0) ps += sDx[t] * (lambda * sDx[t] + sBp[t]);
-                    ps = wave_sum_d(ps);
-                    double sc = (do_schur ? W.Rl[ist] : 0.0) + ps;
-                    sc += 1e-3;
-                    if (lane == 0) sStale[BA_WAVES] = (currentChi - 1.7976931348623157e308) / sc;
-                }
-                __syncthreads();
-                stale_rho = sStale[BA_WAVES];
+                stale_rho = sStale[BA_WAVES];  // (formed by the last wave beside the solve, above)
                 ++failed_solves;
                 if (stale_rho > 0) ++stale_steps;
                 if (!(stale_rho > 0)) {
@@ -1629,7 +1761,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     double d[3] = {cc[0] * r[0], cc[1] * r[0] + cc[2] * r[1], cc[3] * r[0] + cc[4] * r[1] + cc[5] * r[2]};
                     if (!ok2) {  // (the stale step)
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) d[c] = W.dxl[3 * l + c];
+                        for (int c = 0; c < 3; ++c)
+                            d[c] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(W.dxl) + 3 * l + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {

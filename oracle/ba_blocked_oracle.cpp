@@ -21,8 +21,8 @@
 //     (g2o's LinearSolverDense; the pivot order depends on the input diagonal only, see eigenPivotOrder); landmark
 //     back-substitution per observation (C^T b_l - sum_e Y_e^T (A~_e dx), edges in ascending order);
 //   * a failed factorisation leaves the solver's x what it was (g2o applies and scores that STALE step: see the trial loop);
-//     its predicted decrease: landmark part per range at the START of the trial (per-"thread" partials, block sum) riding
-//     along with the Schur exchange (added like its entries), pose part as one 64-lane butterfly, then + 1e-3;
+//     its predicted decrease: landmark part per range (lane = landmark mod 64, one 64-lane butterfly) riding along with the
+//     Schur exchange (added like its entries), pose part as one 64-lane butterfly, then + 1e-3;
 //   * sin / cos by the fixed polynomial below instead of libm.
 // PARITY UNPINNED like the rest of the oracle (oracle.h).
 #include <algorithm>
@@ -576,13 +576,13 @@ int orc_bundle_adjustment_blocked(orc_ba_problem* in, int G, const int32_t* wg_p
                     double sum = 0;
                     for (int g = k; g < G; g += K) {
                         const Range& r = B.rg[g];
-                        double part[kThreads] = {0};
+                        double part[64] = {0};  // (one wave of the range's workgroup forms it: lane = landmark mod 64)
                         for (int ll = 0; ll < r.Lg; ++ll) {
                             const int l = r.pt_lo + ll;
                             for (int c = 0; c < 3; ++c)
-                                part[ll % kThreads] += xl[3 * (size_t)l + c] * (lambda * xl[3 * (size_t)l + c] + B.bl[3 * (size_t)l + c]);
+                                part[ll % 64] += xl[3 * (size_t)l + c] * (lambda * xl[3 * (size_t)l + c] + B.bl[3 * (size_t)l + c]);
                         }
-                        const double tot = blockSum(part);
+                        const double tot = waveSum(part);
                         sum = G == 1 ? tot : sum + tot;
                     }
                     total = K == 1 ? sum : total + sum;

@@ -31,8 +31,9 @@ for kind, kw in kinds:
                   % (dt*1e3, st["trials"], ph["x15"], ph["schur.loop"], ph["schur.wait"], ph["schur.acc"] / 1e3))
         else:
             tot = ph["total"]
-            raw = ctx.ba_trace(h, raw_rows=412)[400:406].ravel()
+            raw = ctx.ba_trace(h, raw_rows=412)[400:408].ravel()
             print("   timeline of trial 6 (cycles between stamps 0..23):", [int(raw[i + 1] - raw[i]) for i in range(23)])
+            print("   pivot order inside 11 -> 12 (stamps 24..27 relative to 11; 12 relative to 11):", [int(raw[i] - raw[11]) for i in (24, 25, 26, 27, 12)])
             print("   instrumented: ms/solve %.3f" % (dt*1e3), "cyc/us %.0f" % (tot/ (dt*1e6)), {k: round(v/max(st["trials"],1)) for k,v in ph.items() if k not in ("wgs", "x15")})
     mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
