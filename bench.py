@@ -82,7 +82,9 @@ def parse(argv=None):
     ap.add_argument("--keyframe-every", type=int, default=10,
                     help="with --track: run the keyframe row (findEssentialMat inlier filter + triangulation + culling, "
                          "vo_addFrame.cpp:93-118) on every N-th frame")
-    ap.add_argument("--frames", type=int, default=16, help="distinct pre-rendered frames per shard (cycled)")
+    ap.add_argument("--frames", type=int, default=150,
+                    help="frames of every shard's sequence (SURVEY.md 8d config 2: 150 frames rendered from a 2048 x 2048 texture; cycled)")
+    ap.add_argument("--tex-size", type=int, default=2048, help="side of the world texture a sequence is rendered from")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the oracle check of the timed loop's outputs (the `parity` object)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-sequence and resident-window runs")
@@ -143,6 +145,44 @@ def frame_loop_lib():
     return _frame_loop
 
 
+def render_sequences(args, sids):
+    """S640 as SURVEY.md 8d config 2 specifies it: every shard its own sequence (seed 1234 + shard), `--frames` (150) frames
+    rendered from a `--tex-size` (2048) square texture, BGR.  32 shards x 150 frames are 4800 renderings of ~30 ms plus 32
+    textures of ~2 s: done by worker PROCESSES (`python synth.py render ...`: numpy / scipy only, no torch, no HIP; one per shard,
+    as many at a time as this process has CPUs) that write .npy files under /dev/shm (or the temp directory); the files are mapped
+    and unlinked at once.  Returns {shard id: uint8 array [frames, H, W, 3]}."""
+    import shutil
+    import subprocess
+    import tempfile
+    synth_path = os.path.join(graft.PKG_DIR, "synth.py")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tmp = tempfile.mkdtemp(prefix="mvo_bench_frames_", dir=base)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    todo = [(sid, os.path.join(tmp, "shard_%d.npy" % sid)) for sid in sids]
+    out, running = {}, []
+    try:
+        pending = list(todo)
+        while pending or running:
+            while pending and len(running) < max(1, ncpu):
+                sid, path = pending.pop(0)
+                cmd = [sys.executable, synth_path, "render", path, str(args.width), str(args.height), str(args.frames), str(1234 + sid),
+                       str(args.tex_size)]
+                running.append((sid, path, subprocess.Popen(cmd, env=env)))
+            sid, path, pr = running.pop(0)
+            if pr.wait(timeout=900) != 0:
+                raise RuntimeError("rendering the sequence of shard %d failed" % sid)
+            out[sid] = np.load(path, mmap_mode="r")
+    finally:
+        for _, _, pr in running:
+            pr.kill()
+        shutil.rmtree(tmp, ignore_errors=True)               # (the mappings keep the pages until the arrays go)
+    return out
+
+
 def window_pool(mvo, args, shard_id, n):
     """`n` distinct synthetic BA windows of a shard (SURVEY.md 8d config 3 generator, different seeds)."""
     K = mvo.synth.FR1_K if args.width == 640 else mvo.synth.KITTI_K
@@ -171,9 +211,13 @@ class Shard:
             separate = os.environ.get("MVO_BENCH_SEPARATE_CTX") == "1"
             self.ctx_ba = (mvo.Context(device, max_keypoints=args.max_kp) if separate else self.ctx.sibling()) if pipeline else self.ctx
         if frames is None:
-            seq = mvo.synth.Sequence(args.width, args.height, args.frames, seed=1234 + shard_id, tex_size=1024)
-            host = [seq.frame(i) for i in range(args.frames)]
-            frames = (host, [torch.from_numpy(f).to("cuda:%d" % device) for f in host])
+            frames = render_sequences(args, [shard_id])[shard_id]
+        if isinstance(frames, np.ndarray):
+            # one rendered block [frames, H, W, 3]: ONE upload, the frames are views of it (host and device)
+            block = np.array(frames, dtype=np.uint8, order="C")   # (out of the unlinked /dev/shm mapping: its pages go with it)
+            dev = torch.from_numpy(block).to("cuda:%d" % device)
+            frames = ([block[i] for i in range(len(block))], [dev[i] for i in range(len(block))])
+            self._host_block = block
         self.host_frames, self.dev_frames = frames
         self.K = mvo.synth.FR1_K if args.width == 640 else mvo.synth.KITTI_K
         self.pool = pool if pool is not None else window_pool(mvo, args, shard_id, max(1, args.windows))
@@ -200,7 +244,9 @@ class Shard:
         c.fix_points = 1 if self.fix_points else 0
         c.chain = 1 if self.chain else 0
         if self.from_host:   # the same frames in pinned host memory: handed over as host images (H2D inside the loop)
-            self._pinned = [self.torch.from_numpy(f).pin_memory() for f in self.host_frames]
+            # (one pinned block per shard, the frames are views of it)
+            self._pinned_block = self.torch.from_numpy(np.ascontiguousarray(np.stack(self.host_frames))).pin_memory()
+            self._pinned = [self._pinned_block[i] for i in range(len(self.host_frames))]
             self._hf = (C.c_void_p * len(self._pinned))(*[t.data_ptr() for t in self._pinned])
             c.h_frames = C.cast(self._hf, C.POINTER(C.c_void_p))
         # (tracking rows / the PnP chain in the loop: the frames wait for those stages, not for the solver -> SHARED mode)
@@ -556,6 +602,9 @@ class GpuEnv:
     def sync(self):
         self.torch.cuda.synchronize()
 
+    def render(self, args, sids):
+        return render_sequences(args, sids)
+
     def make_shard(self, shard_id, args, ba_mode, pipeline, **kw):
         return Shard(self.mvo, self.torch, self.local, shard_id, args, ba_mode, pipeline, **kw)
 
@@ -571,7 +620,10 @@ def run_benchmark(args, env):
         env.init_process_group(dist)
     pipeline = args.pipeline == 1
     kw = {"chain": True} if getattr(args, "chain", False) else {}
-    shards = [env.make_shard(sid, args, args.ba_mode, pipeline, **kw) for sid in shard_ids(rank, args.streams)]
+    sids = shard_ids(rank, args.streams)
+    rendered = env.render(args, sids) if hasattr(env, "render") else {}
+    shards = [env.make_shard(sid, args, args.ba_mode, pipeline, **(dict(kw, frames=rendered[sid]) if sid in rendered else kw)) for sid in sids]
+    rendered = None
     env.sync()
 
     def barrier():
@@ -909,15 +961,15 @@ def main(argv=None, env=None):
             "metric": METRIC, "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8 (extract/match) + f64 (BA)", "data": "synthetic",
-            "config": {"workload": "S%d: %dx%d BGR frames resident in HBM (every shard cycles %d pre-rendered frames of its own "
-                                   "sequence, rendered from a 1024x1024 texture; SURVEY 8d plans 150 frames from 2048x2048), <=%d kp "
+            "config": {"workload": "S%d: %dx%d BGR frames resident in HBM (SURVEY 8d config 2: every shard its own sequence -- seed 1234 + shard --"
+                                   " of %d frames rendered from a %dx%d texture, cycled), <=%d kp "
                                    "(ORB 8000 -> grid), 2-NN Hamming + "
                                    "Lowe 0.8 + de-dup vs previous frame, BA%d %s with the BA window rebuilt per frame "
                                    "(%d distinct SYNTHETIC windows per shard rotated -- SURVEY 8d config 3 generator, independent of "
                                    "the extracted frames; secondary.chained_fps is the loop whose windows come from PnP inliers --; marshalled from Frame/MapPoint objects like "
                                    "vo.cpp:408-449, flattened, uploaded, solved, written back: %d poses / %d landmarks / "
                                    "~%d edges, 50 LM iterations)"
-                                   % (args.width, args.width, args.height, args.frames, args.max_kp + 1, args.ba_poses, args.ba,
+                                   % (args.width, args.width, args.height, args.frames, args.tex_size, args.tex_size, args.max_kp + 1, args.ba_poses, args.ba,
                                       len(s0.pool), args.ba_poses, args.ba_points, int(E_avg))
                        if args.ba_mode == "rebuild" else "S%d extract+match, BA mode %s" % (args.width, args.ba_mode),
                        "streams_per_gpu": args.streams, "frames_per_step": args.streams * world * max(1, args.frames_per_step),

@@ -423,30 +423,23 @@ __device__ __forceinline__ int group_sum_i(int v, int width) {
 // of a pose block are the same sums -- the swap sequence itself is replayed by ONE wave on integer keys (dense rank << 7 |
 // position: the wave minimum is the first maximum); position lane and lane + 64 per lane (n <= 128).  rank[i]: number of
 // entries strictly larger than entry i.  perm[k] = row of S that ends up at position k.
-// (uniform value `val` into lane `l` of `old`)
-__device__ __forceinline__ int writelane_i(int old, int val, int l) {
-#ifndef MVO_KERNEL_SIM
-    // (no clang builtin for it in ROCm 7.2; gfx9 allows ONE scalar register per vector instruction: the lane select goes through m0)
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(val), "s"(l) : "m0");
-    return old;
-#else
-    return (int)(threadIdx.x & 63) == l ? val : old;
-#endif
-}
 // (out of line: run by one wave on the rare path; inlined, its registers would count against the whole LM loop)
 __device__ __attribute__((noinline)) void ba_pivot_replay(const short* rank, int n, short* perm, int lane) {
     const int done = 0x7fffffff;
-    if (n <= 64) {  // one position per lane: every step is a wave minimum, three v_readlane and four v_writelane
-        int key = lane < n ? ((int)rank[lane] << 7) | lane : done, el = lane;
+    if (n <= 64) {
+        // one position per lane, everything about it in ONE word: rank << 14 | position << 7 | element.  The wave minimum is the
+        // first maximum AND names the element that sits there; a step is that minimum, one v_readlane and three selects.
+        int key = lane < n ? ((int)rank[lane] << 14) | (lane << 7) | lane : done, out = 0;
         for (int k = 0; k < n; ++k) {
-            const int big = wave_min_i(key) & 127;  // position of the first maximum among k .. n-1
-            const int ek = __builtin_amdgcn_readlane(el, k), kk = __builtin_amdgcn_readlane(key, k), eb = __builtin_amdgcn_readlane(el, big);
-            el = writelane_i(el, ek, big);          // what sat at position k goes to position `big` ...
-            key = writelane_i(key, (kk & ~127) | big, big);
-            el = writelane_i(el, eb, k);            // ... and position k is final
-            key = writelane_i(key, done, k);
+            const int m = wave_min_i(key);
+            const int big = (m >> 7) & 127, eb = m & 127;           // position of the first maximum among k .. n-1, the element there
+            const int kk = __builtin_amdgcn_readlane(key, k);       // what sits at position k ...
+            const int moved = (kk & ~(127 << 7)) | (big << 7);      // ... goes to position `big`
+            key = lane == big ? moved : key;
+            key = lane == k ? done : key;                           // position k is final
+            out = lane == k ? eb : out;
         }
-        if (lane < n) perm[lane] = (short)el;
+        if (lane < n) perm[lane] = (short)out;
         return;
     }
     const int p0 = lane, p1 = lane + 64;

@@ -310,3 +310,19 @@ class Scene3D:
         img = img + rng.normal(0, noise, img.shape)
         g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
         return np.repeat(g[:, :, None], 3, axis=2)
+
+
+if __name__ == "__main__":
+    # python synth.py render <out.npy> <width> <height> <frames> <seed> <tex_size>: one sequence as a [frames, H, W, 3] uint8 .npy file
+    # (bench.py renders the shards' sequences with worker processes of this form)
+    import sys
+    if len(sys.argv) == 8 and sys.argv[1] == "render":
+        out_path = sys.argv[2]
+        w, h, n, seed, tex = (int(v) for v in sys.argv[3:8])
+        seq = Sequence(w, h, n, seed=seed, tex_size=tex)
+        arr = np.lib.format.open_memmap(out_path, mode="w+", dtype=np.uint8, shape=(n, h, w, 3))
+        for i in range(n):
+            arr[i] = seq.frame(i)
+        arr.flush()
+    else:
+        raise SystemExit("usage: synth.py render <out.npy> <width> <height> <frames> <seed> <tex_size>")
