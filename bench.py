@@ -161,7 +161,16 @@ def render_sequences(args, sids):
         ncpu = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         ncpu = os.cpu_count() or 1
-    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    # (the workers are plain numpy programs: a profiler wrapped around bench.py -- rocprofv3 preloads its tool library into every
+    # child -- must not follow them, it would write a trace per worker and slow each by seconds)
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "ROCTX", "HSA_TOOLS"))}
+    if "LD_PRELOAD" in env:
+        keep = [x for x in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in x.lower()]
+        if keep:
+            env["LD_PRELOAD"] = ":".join(keep)
+        else:
+            env.pop("LD_PRELOAD")
+    env.update(OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
     todo = [(sid, os.path.join(tmp, "shard_%d.npy" % sid)) for sid in sids]
     out, running = {}, []
     try:

@@ -296,3 +296,26 @@ def test_every_function_of_the_replaced_headers_runs_like_the_reference(mvo, O, 
     assert np.abs(T_ba - Ph[0]).max() < 1e-6
     # the pose came back to the truth (identity) within the pixel noise
     assert np.abs(T_pose_only - np.eye(4)).max() < 2e-3
+
+
+MULTI = os.path.join(ROOT, "monocular-visual-odometry_amd", "host", "driver", "multi_gpu_shards")
+
+
+def test_multi_gpu_example_is_built_against_rccl_and_the_hip_library_only():
+    assert os.path.exists(MULTI), "run __graft_entry__.build()"
+    ldd = subprocess.run(["ldd", MULTI], capture_output=True, text=True).stdout
+    assert "libmvo_hip.so" in ldd and "librccl" in ldd and "liboracle" not in ldd and "torch" not in ldd
+
+
+@pytest.mark.gpu
+def test_cpp_host_shards_sequences_and_gathers_the_trajectories(tmp_path):
+    """SURVEY 8(e) from the C++ host (host/driver/multi_gpu_shards.cpp): one mvo_ctx per GPU rank, no collective while the
+    sequences run, one RCCL all-gather of the frames x 12 trajectory blocks (vo_io.cpp:58-75 row format).  A 1-GPU box runs it with
+    one rank; the gathered rows must be what the rank computed and the file the reference's trajectory format."""
+    prefix = str(tmp_path / "traj")
+    r = subprocess.run([MULTI, "8", "6", prefix], capture_output=True, text=True, timeout=300)     # ranks are clamped to the GPUs present
+    assert r.returncode == 0 and any(line.startswith("ok:") for line in r.stdout.splitlines()), r.stdout + r.stderr    # (RCCL prints a banner first)
+    rows = np.loadtxt(prefix + "_shard0.txt")
+    assert rows.shape == (6, 12) and np.allclose(rows[:, 3:], np.eye(3).T.reshape(-1))
+    # the scene moves 3 px per frame to the left: the example's pose (median image shift) follows it
+    assert np.allclose(np.diff(rows[:, 0]), 3.0, atol=0.5) and np.allclose(rows[:, 1], 0.0, atol=0.5)

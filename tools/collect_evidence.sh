@@ -37,6 +37,10 @@ pmc() {  # pmc <name> <seconds> "<counters>" <command...>   -> $OUT/<name>.txt (
   run_bounded $t $OUT/$name.log rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/$name -o bench -- "$@" || return 1
   python tools/pmc_summary.py table $OUT/$name/bench_counter_collection.csv $OUT/$name.txt "$*"
 }
+sec0() {
+# 0. what the FP64 roofline is priced against, measured on this box (tools/probes/fp64_peak_probe.hip)
+run_bounded 120 $OUT/fp64_peak_probe.txt bash -c "hipcc --offload-arch=gfx950 -O3 -o /tmp/fp64_peak_probe tools/probes/fp64_peak_probe.hip && /tmp/fp64_peak_probe"
+}
 sec1() {
 # 1. tests + the bench lines
 run_bounded 300 $OUT/pytest_gpu.log python -m pytest tests -m gpu -q
@@ -91,7 +95,7 @@ trim
 sec6() {
 run_bounded 600 $OUT/bench_default.err bash -c "python bench.py > $OUT/bench_default.json"
 }
-for sct in ${SECTIONS:-1 2 3 4 5 6}; do sec$sct; done
+for sct in ${SECTIONS:-0 1 2 3 4 5 6}; do sec$sct; done
 trim
 du -sh $OUT; ls $OUT
 tail -3 $OUT/pytest_gpu.log
