@@ -24,6 +24,24 @@
 #include "mvo_internal.h"
 
 typedef ba_u64 u64;
+// Pointers into device memory that are LOADED from the descriptor (not kernel arguments) are generic to the compiler: it emits
+// FLAT instructions for them, which also count against the LDS counter (every later wait for an LDS read then waits for them too).
+// The per-trial accesses to such memory go through this explicitly global type instead (global_load / global_store).
+#ifndef MVO_KERNEL_SIM
+typedef __attribute__((address_space(1))) double gdouble;
+typedef __attribute__((address_space(1))) const u64 gcu64;
+typedef __attribute__((address_space(1))) u64 gu64;
+#define BA_AS_GLOBAL_D(p) ((gdouble*)(p))
+#define BA_AS_GLOBAL_CU64(p) ((gcu64*)(p))
+#define BA_AS_GLOBAL_U64(p) ((gu64*)(p))
+#else
+typedef double gdouble;
+typedef const u64 gcu64;
+typedef u64 gu64;
+#define BA_AS_GLOBAL_D(p) (p)
+#define BA_AS_GLOBAL_CU64(p) (p)
+#define BA_AS_GLOBAL_U64(p) (p)
+#endif
 
 // per-phase cycle counters: only in the instrumented instantiation of the kernel (debug knob "ba_profile"); the
 // production kernel carries none of it (s_memtime drains the memory counters, the 16 counters cost 32 SGPRs)
@@ -131,7 +149,8 @@ __device__ double block_max(double v, double* scratch) {
 // the first exchange, which always uses the write-through form) -> the stores may stay in that XCD's L2 (plain
 // stores), where the consumers' L1-bypassing loads find them an order of magnitude sooner than behind the fabric.
 // Placement changes only which of the two store flavours is used, never the result.
-__device__ __forceinline__ void gstore_d(u64* g, unsigned tag, double v, bool same_l2) {
+__device__ __forceinline__ void gstore_d(u64* g_, unsigned tag, double v, bool same_l2) {
+    gu64* g = BA_AS_GLOBAL_U64(g_);  // (exchange areas: device memory, always)
     const u64 b = (u64)__double_as_longlong(v);
     const u64 lo = ((u64)tag << 32) | (b & 0xffffffffull), hi = ((u64)tag << 32) | (b >> 32);
     if (same_l2) {
@@ -142,7 +161,8 @@ __device__ __forceinline__ void gstore_d(u64* g, unsigned tag, double v, bool sa
         __hip_atomic_store(g + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ bool gtry_d(const u64* g, unsigned tag, double& v) {
+__device__ __forceinline__ bool gtry_d(const u64* g_, unsigned tag, double& v) {
+    gcu64* g = BA_AS_GLOBAL_CU64(g_);
     const u64 a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const u64 b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     v = __longlong_as_double((long long)((a & 0xffffffffull) | (b << 32)));
@@ -465,7 +485,7 @@ __device__ __attribute__((noinline)) void ba_pivot_replay(const short* rank, int
 // computeScale() of the landmark part of the solver's current x over one range: sum over its landmarks l (lane = l mod 64, then one
 // 64-lane butterfly) of x_l . (lambda x_l + b_l).  x: device memory (L1-bypassing loads), b_l: LDS at offset bl_off of the dynamic
 // segment.  Out of line and run by ONE wave beside the Schur chains: its registers do not count against the LM loop's.
-__device__ __attribute__((noinline)) double ba_stale_scale_landmarks(const u64* dxl, int bl_off, int Lg, double lambda, int lane) {
+__device__ __attribute__((noinline)) double ba_stale_scale_landmarks(gcu64* dxl, int bl_off, int Lg, double lambda, int lane) {
     const double* bl = ba_dyn_lds + bl_off;
     double sp = 0;
     for (int l0 = lane; l0 < Lg; l0 += 4 * 64) {
@@ -825,7 +845,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     }
     for (int i = tid; i < 3 * Lg; i += BA_THREADS) W.pts[i] = B.pts_in[3 * (size_t)pt_lo + i];
     if (!B.fix_points)
-        for (int l = tid; l < Lg; l += BA_THREADS) W.dxl[3 * l] = W.dxl[3 * l + 1] = W.dxl[3 * l + 2] = 0.0;  // (the solver's x before the first solve)
+        for (int l = tid; l < Lg; l += BA_THREADS)
+            BA_AS_GLOBAL_D(W.dxl)[3 * l] = BA_AS_GLOBAL_D(W.dxl)[3 * l + 1] = BA_AS_GLOBAL_D(W.dxl)[3 * l + 2] = 0.0;  // (the solver's x before the first solve)
     if (tid < 6 * B.F) sDx[tid] = 0.0;
     for (int i = tid; i <= Lg; i += BA_THREADS) W.pts0[i] = (short)(B.pt_edge_start[pt_lo + i] - e_lo);
     for (int i = tid; i < Lg * nfree; i += BA_THREADS) W.eof[i] = B.eof[(size_t)pt_lo * nfree + i];
@@ -985,7 +1006,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     // as offsets into sHpp, three times 10 bits (constant for the whole solve)
     int piv_hoff = 0;
     if (n > 0) {
-        const int lsh = n <= 32 ? 4 : (n <= 64 ? 3 : 2), LPR = 1 << lsh, jj = tid & (LPR - 1);
+        const int lsh = NR == 32 ? 4 : (n <= 32 ? 4 : (n <= 64 ? 3 : 2)), LPR = 1 << lsh, jj = tid & (LPR - 1);
         const int qi = min(tid >> lsh, n - 1), q0 = min(jj, n - 1), q1 = min(jj + LPR, n - 1);
         piv_hoff = (36 * sSlotPose[qi / 6] + 7 * (qi % 6)) | (36 * sSlotPose[q0 / 6] + 7 * (q0 % 6)) << 10 | (36 * sSlotPose[q1 / 6] + 7 * (q1 % 6)) << 20;
     }
@@ -1365,7 +1386,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                         // computeScale() of the x the solver holds NOW (what g2o scores if this trial's solve fails), landmark part of
                         // this range: lane = landmark mod 64, one 64-lane butterfly.  Read from device memory by the wave that has no
                         // chain in the 5-pose class (3 tile pairs x 2 pieces on 8 waves): the latency hides beside the chains.
-                        const double sp = ba_stale_scale_landmarks(reinterpret_cast<const u64*>(W.dxl), (int)(W.bl - dyn), Lg, lambda, lane);
+                        const double sp = ba_stale_scale_landmarks(BA_AS_GLOBAL_CU64(reinterpret_cast<const u64*>(W.dxl)), (int)(W.bl - dyn), Lg, lambda, lane);
                         if (lane == 0) {
                             sStale[0] = sp;
                             if (G == 1) W.Rl[nlow] = sp;
@@ -1525,7 +1546,8 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 // dense rank of every |diagonal entry| by counting, all 512 threads: row i = tid / LPR compares its entry with the
                 // entries j = jj, jj + LPR, ... (LPR = 512 / P lanes per row, P = 32 / 64 / 128 >= n); every thread forms the entries it
                 // needs itself (no hand-off, no barrier before the counting)
-                const int lsh = n <= 32 ? 4 : (n <= 64 ? 3 : 2), LPR = 1 << lsh;
+                // (the 5-pose class -- NR == 32: n <= 31 -- has its geometry at compile time: 16 lanes per row, two entries per thread)
+                const int lsh = NR == 32 ? 4 : (n <= 32 ? 4 : (n <= 64 ? 3 : 2)), LPR = 1 << lsh;
                 const int i = tid >> lsh, jj = tid & (LPR - 1);  // (shifts: a division by a run-time value costs ~40 instructions)
 // (a macro, not a lambda: behind a by-reference capture the compiler parks the register-resident edge rows in scratch memory)
 #define BA_ADIAG(q, hoff) fabs((sHpp[hoff] + lambda) - (do_schur ? W.Rl[(q) * ((q) + 1) / 2 + (q)] : 0.0))
@@ -1538,7 +1560,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 int v = ai != ai ? 1 << 24 : 0;
                 v += (b0 > ai ? 1 : 0) + ((b0 == ai && j0 != i) ? 1 << 12 : 0);
                 v += (b1 > ai ? 1 : 0) + ((b1 == ai && j1 != i) ? 1 << 12 : 0);
-                for (int j = jj + 2 * LPR; j < n; j += 2 * LPR) {
+                for (int j = jj + 2 * LPR; NR != 32 && j < n; j += 2 * LPR) {
                     const double c0 = BA_ADIAG(j, 36 * sSlotPose[j / 6] + 7 * (j % 6));
                     const double c1 = j + LPR < n ? BA_ADIAG(j + LPR, 36 * sSlotPose[(j + LPR) / 6] + 7 * ((j + LPR) % 6)) : -2.0;
                     v += (c0 > ai ? 1 : 0) + ((c0 == ai && j != i) ? 1 << 12 : 0);
@@ -1755,12 +1777,14 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     if (!ok2) {  // (the stale step)
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
-                            d[c] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const u64*>(W.dxl) + 3 * l + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                            d[c] = __longlong_as_double((long long)__hip_atomic_load(BA_AS_GLOBAL_CU64(reinterpret_cast<const u64*>(W.dxl)) + 3 * l + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                     }
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         scale += d[c] * (lambda * d[c] + W.bl[3 * l + c]);
-                        W.dxl[3 * l + c] = d[c];
+                        // (x of a successful solve; a stale step that is applied leaves x what it is.  Parking the values in the idle U
+                        // area and storing them at the top of the next phase was tried: 2.88 vs 2.82 ms per window, profiles/r06_ab_runs.txt)
+                        if (ok2) BA_AS_GLOBAL_D(W.dxl)[3 * l + c] = d[c];
                         W.bak[3 * l + c] = W.pts[3 * l + c];
                         W.pts[3 * l + c] += d[c];
                     }
