@@ -447,16 +447,20 @@ __device__ __forceinline__ int group_sum_i(int v, int width) {
 __device__ __attribute__((noinline)) void ba_pivot_replay(const short* rank, int n, short* perm, int lane) {
     const int done = 0x7fffffff;
     if (n <= 64) {
-        // one position per lane, everything about it in ONE word: rank << 14 | position << 7 | element.  The wave minimum is the
-        // first maximum AND names the element that sits there; a step is that minimum, one v_readlane and three selects.
-        int key = lane < n ? ((int)rank[lane] << 14) | (lane << 7) | lane : done, out = 0;
+        // one position per lane: rk = dense rank of the element sitting there (-1 once the position is final), el = the element.
+        // Dense ranks are the cumulative group sizes, so the group that is being taken at step k is known without a reduction: a new
+        // one starts at step k exactly when some element has rank k, else the running one continues; its member at the lowest
+        // position is the first maximum: one ballot + s_ff1 instead of a six-step wave minimum.
+        int rk = lane < n ? (int)rank[lane] : -1, el = lane, out = 0, cur = 0;
         for (int k = 0; k < n; ++k) {
-            const int m = wave_min_i(key);
-            const int big = (m >> 7) & 127, eb = m & 127;           // position of the first maximum among k .. n-1, the element there
-            const int kk = __builtin_amdgcn_readlane(key, k);       // what sits at position k ...
-            const int moved = (kk & ~(127 << 7)) | (big << 7);      // ... goes to position `big`
-            key = lane == big ? moved : key;
-            key = lane == k ? done : key;                           // position k is final
+            const unsigned long long fresh = __ballot(rk == k), running = __ballot(rk == cur);
+            const unsigned long long m = fresh ? fresh : running;
+            cur = fresh ? k : cur;
+            const int big = m ? (int)__builtin_ctzll(m) : k;         // position of the first maximum among k .. n-1
+            const int kr = __builtin_amdgcn_readlane(rk, k), ke = __builtin_amdgcn_readlane(el, k), eb = __builtin_amdgcn_readlane(el, big);
+            rk = lane == big ? kr : rk;                              // what sat at position k goes to position `big` ...
+            el = lane == big ? ke : el;
+            rk = lane == k ? -1 : rk;                                // ... and position k is final
             out = lane == k ? eb : out;
         }
         if (lane < n) perm[lane] = (short)out;
