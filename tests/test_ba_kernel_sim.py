@@ -265,6 +265,10 @@ def test_windows_of_changing_shape_on_one_context(mvo, O, simctx):
 
 
 
+def test_windows_of_more_than_ten_poses(mvo, O, simctx):
+    gpu_ba_tests._many_pose_windows(mvo, O, simctx)
+
+
 def test_stale_step_after_a_failed_solve(mvo, O, simctx, simlib):
     """g2o's behaviour after a failed linear solve (the solver's x stays, is applied and scored; a negative predicted decrease
     accepts it), on a benchmark window that meets both outcomes: the kernel source equals the blocked oracle trial by trial."""

@@ -330,6 +330,27 @@ def test_bitwise_stale_step_after_a_failed_solve(mvo, O):
         c.close()
 
 
+def _many_pose_windows(mvo, O, ctx):
+    """Windows of more than 10 free poses (vo.h keeps up to 20 frames): the reduced system has more than 63 unknowns -- the LDS solver,
+    four lanes per row in the pivot ranks, and in the pose-only form (equal x / y translation entries in every pose block) the replay of
+    Eigen's swaps with two positions per lane."""
+    pb = mvo.synth.ba_problem(12, 700, 41)
+    _bitwise(mvo, O, ctx, pb, fix_points=False, max_iterations=4)
+    _bitwise(mvo, O, ctx, pb, fix_points=True, max_iterations=6)
+    pb = mvo.synth.ba_problem(14, 500, 42)
+    _bitwise(mvo, O, ctx, pb, fix_points=False, pose_fixed=_fix(14, 1), max_iterations=3)
+    _bitwise(mvo, O, ctx, pb, fix_points=True, max_iterations=3)
+    # beyond what the LDS-resident solver holds (the reduced system of 18 free poses alone is 96 KB): a clean capacity error
+    pb = mvo.synth.ba_problem(20, 300, 43)
+    with pytest.raises(mvo.MvoError) as e:
+        ctx.bundle_adjustment(*_args(pb), fix_points=False, pose_fixed=_fix(20, 2), max_iterations=2)
+    assert e.value.code == -3 and "too large" in str(e.value)
+
+
+def test_bitwise_windows_of_more_than_ten_poses(mvo, O, ctx):
+    _many_pose_windows(mvo, O, ctx)
+
+
 def _bench_windows(mvo):
     """The first windows of shard 0 / shard 1 of bench.py's pool (bench.window_pool: seed 7 + 1000 x shard + k)."""
     return [mvo.synth.ba_problem(5, 2000, 7), mvo.synth.ba_problem(5, 2000, 8), mvo.synth.ba_problem(5, 2000, 1007)]
