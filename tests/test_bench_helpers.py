@@ -56,8 +56,9 @@ def test_algorithmic_work_table_names_the_kernels_of_a_frame():
 
 def test_roofline_side_figures_come_from_the_newest_rounds_profile_files():
     """What bench.py's roofline block reads for the resident solver grid: the matrix-core counters measured ON the grid
-    (profiles/r05_pmc_grid_mfma_busy.txt), the HBM-side bytes per window of the newest round (round 5: the launch-path form of the same
-    cut -- the WRITE_SIZE pass next to the resident grid hung), the compiler's register report of the shipped build."""
+    (profiles/r06_pmc_grid_mfma_busy.txt), the HBM-side bytes per window of the newest round (round 6: FETCH_SIZE / WRITE_SIZE passes ON the
+    grid, profiles/r06_pmc_fetch_write_size_per_kernel.csv; round 5 had to fall back to the launch-path form of the same cut), the compiler's
+    register report of the shipped build."""
     import bench
     gb = bench.pmc_grid_busy()
     assert gb and gb["source"].startswith("profiles/r") and gb["workgroups_per_window"] == 14 and gb["windows"] >= 1000
@@ -65,8 +66,10 @@ def test_roofline_side_figures_come_from_the_newest_rounds_profile_files():
     assert 0.03 < busy < 0.3, busy
     lp = bench.pmc_traffic("k_ba_lm_per_window", "r[0-9]*_pmc_launch_path_fetch_write_size.csv")
     assert lp and 1e5 < lp[0] < 1e8
+    tg = bench.pmc_traffic("k_ba_service_per_window")
+    assert tg and tg[1].startswith("profiles/r06") and 1e6 < tg[0] < 5e7      # bytes per window, measured on the resident grid itself
     res = bench.kernel_resources("k_ba_service<32,2>")
-    assert res and res["vgpr"] == 256 and res["source"].startswith("profiles/r05")
+    assert res and res["vgpr"] == 256 and res["source"].startswith("profiles/r06")
     fh = bench.kernel_resources("k_fast_harris")
     assert fh["vgpr"] <= 64 and fh["scratch_bytes_per_lane"] == 0 and fh["occupancy"] == 8
 
