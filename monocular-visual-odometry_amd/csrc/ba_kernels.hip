@@ -2008,6 +2008,8 @@ __global__ __launch_bounds__(BA_THREADS) void k_ba_service(BaServiceArgs a) {
         last = seq;
         BaRun run = {(unsigned)flags, (int)((flags >> 32) & 1), (int)((flags >> 33) & 1)};
         const BaDev* D = reinterpret_cast<const BaDev*>(desc);
+        // (inlined on purpose: called out of line -- an allocation of its own, one call per window -- the body ran 5 % slower,
+        // 2.97 vs 2.83 ms per window, profiles/r06_ab_runs.txt; the spill COUNT of this kernel is not what its time follows)
         ba_window<false, NR, SLOTS>(D, run, g);
         // ---- completion: every workgroup of the slot counts itself off once its results are on their way to the host (every
         // wave drains its own stores first); workgroup 0 waits for all of them and then posts the job's sequence number
