@@ -761,12 +761,15 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     double* const sX = dyn + ba_pose_doubles(B.F);  // 2 G
     __shared__ int sSlot[BA_MAX_POSES], sSlotPose[BA_MAX_POSES], sPoseStart[BA_MAX_POSES + 1];
     __shared__ short sSlc[3][BA_HP_PASSES][BA_MAX_POSES];  // pose-block chains: slices of the staging passes (below)
-    __shared__ int sFlag[4];
+    __shared__ int sFlag[6];
     __shared__ double sStale[BA_WAVES + 2];  // wave partials of the stale step's predicted decrease; [8]: rho of a failed solve
-    __shared__ short sPerm[6 * BA_MAX_POSES];  // Eigen's pivot order of the trial's reduced system
-    __shared__ short sRank[6 * BA_MAX_POSES];  // dense ranks of |diag S| (only read when entries tie)
+    __shared__ short sPermAll[2][6 * BA_MAX_POSES];  // Eigen's pivot order of the trial's reduced system: [0] by ranks, [1] by replay
+    short* const sPerm = sPermAll[0];
+    __shared__ short sRank[6 * BA_MAX_POSES];  // dense ranks of |diag S| of the last trial
+    short* const sPermTie = sPermAll[1];  // the replayed order that belongs to sRank whenever sRank has equal entries
     __shared__ long long sStamp[PROF ? 32 : 1];  // (parked in LDS: a store to host memory in front of a barrier would be timed)
-    if (threadIdx.x == 0) sFlag[1] = sFlag[2] = sFlag[3] = 0;  // [1] NaN on the diagonal, [2] exchange timed out, [3] equal diagonal entries
+    if (threadIdx.x == 0) sFlag[1] = sFlag[2] = sFlag[3] = sFlag[4] = 0;  // [1] NaN on the diagonal, [2] exchange timed out, [3] equal diagonal entries, [4] ranks changed
+    if (threadIdx.x < 6 * BA_MAX_POSES) sRank[threadIdx.x] = -1;  // (no order replayed yet)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = B.n, G = B.G, nfree = B.nfree, urows = B.ldu, ldu = B.ldu + 1, nlow = B.nlow, npk = B.npk;
@@ -1546,6 +1549,9 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
             PH_END(5);
             // ============= T3: every workgroup assembles S = H_pp + lambda I - G, g = b_p - G[:, n] -- rows and columns in the
             // pivot order Eigen::LDLT would choose for it (sPerm, from |diag S|) -- and solves it
+            int pw = 0;  // the trial's pivot order = sPermAll[pw]: by ranks, or the replayed one when entries tie (an index, not a
+                         // pointer: a pointer selected between two LDS arrays is generic to the compiler)
+#define perm sPermAll[pw]
             if (n > 0) {
                 // dense rank of every |diagonal entry| by counting, all 512 threads: row i = tid / LPR compares its entry with the
                 // entries j = jj, jj + LPR, ... (LPR = 512 / P lanes per row, P = 32 / 64 / 128 >= n); every thread forms the entries it
@@ -1574,6 +1580,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 v = group_sum_i(v, LPR);  // bits 0..11: entries larger than mine, 12..23: entries equal to mine, 24..: NaN
                 if (jj == 0 && i < n) {
                     const int rk = v & 0xfff;
+                    if (sRank[i] != rk) sFlag[4] = 1;
                     sRank[i] = (short)rk;
                     sPerm[rk] = (short)i;  // (the order itself when no two entries are equal)
                     if (v >> 24) sFlag[1] = 1;
@@ -1582,15 +1589,19 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 STAMP(25);
                 __syncthreads();
                 STAMP(26);
-                if (sFlag[1] | sFlag[3]) {  // (uniform) NaN: identity -- the factorisation stops at that pivot --; equal entries: replay the swaps
-                    if (wave == 0) {
-                        if (sFlag[1]) {
-                            for (int q = lane; q < n; q += 64) sPerm[q] = (short)q;
-                        } else {
-                            ba_pivot_replay(sRank, n, sPerm, lane);
-                        }
-                    }
+                if (sFlag[1]) {  // (uniform) NaN: identity -- the factorisation stops at that pivot
+                    if (wave == 0)
+                        for (int q = lane; q < n; q += 64) sPerm[q] = (short)q;
                     __syncthreads();
+                } else if (sFlag[3]) {
+                    // equal entries: the order is the replay of Eigen's swaps -- a function of the dense ranks alone, so it is only
+                    // replayed when the ranks differ from the last trial's (in a pose-only window they hardly ever do: adding
+                    // the damping to every entry keeps their order), else the order of the last replay still stands
+                    if (sFlag[4]) {
+                        if (wave == 0) ba_pivot_replay(sRank, n, sPermTie, lane);
+                        __syncthreads();
+                    }
+                    pw = 1;
                 }
                 STAMP(27);
             }
@@ -1603,7 +1614,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     if (i < n) {
                         v = 0.0;
                         if (k <= i) {
-                            const int a_ = sPerm[i], b_ = sPerm[k], hi = max(a_, b_), lo = min(a_, b_);  // entry (hi, lo) of S
+                            const int a_ = perm[i], b_ = perm[k], hi = max(a_, b_), lo = min(a_, b_);  // entry (hi, lo) of S
                             const double gsum = do_schur ? W.Rl[hi * (hi + 1) / 2 + lo] : 0.0;
                             const int pi = sSlotPose[hi / 6], pj = sSlotPose[lo / 6];
                             v = ((pi == pj) ? sHpp[36 * pi + 6 * (hi % 6) + (lo % 6)] + (hi == lo ? lambda : 0.0) : 0.0) - gsum;
@@ -1611,7 +1622,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     } else if (i == RR) {
                         v = 0.0;
                         if (k < n) {
-                            const int kk = sPerm[k];
+                            const int kk = perm[k];
                             const double gsum = do_schur ? W.Rl[n * (n + 1) / 2 + kk] : 0.0;
                             v = sBp[6 * sSlotPose[kk / 6] + kk % 6] - gsum;
                         }
@@ -1626,11 +1637,11 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     packed_ij(idx, n, i, j);  // j <= i < n, or i == n (rhs row)
                     const int pitch = n + 2;
                     if (i == n) {
-                        const int kk = sPerm[j];
+                        const int kk = perm[j];
                         const double gsum = do_schur ? W.Rl[n * (n + 1) / 2 + kk] : 0.0;
                         W.SL[n * pitch + j] = sBp[6 * sSlotPose[kk / 6] + kk % 6] - gsum;
                     } else {
-                        const int a_ = sPerm[i], b_ = sPerm[j], hi = max(a_, b_), lo = min(a_, b_);
+                        const int a_ = perm[i], b_ = perm[j], hi = max(a_, b_), lo = min(a_, b_);
                         const double gsum = do_schur ? W.Rl[hi * (hi + 1) / 2 + lo] : 0.0;
                         const int pi = sSlotPose[hi / 6], pj = sSlotPose[lo / 6];
                         W.SL[i * pitch + j] = ((pi == pj) ? sHpp[36 * pi + 6 * (hi % 6) + (lo % 6)] + (hi == lo ? lambda : 0.0) : 0.0) - gsum;
@@ -1659,15 +1670,15 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                     // workgroup-wide block factorisation (all waves take part: barriers inside)
                     const int ok = solve_block<(NR == 64 ? 64 : 32)>(sl_off, (int)(W.pan - dyn), cb_off + 128, n, tid);
                     if (tid == 0) sFlag[0] = ok;
-                    if (ok && tid < n) sSol[sPerm[tid]] = W.colbuf[128 + tid];  // x = P^T x'; a failed solve leaves x what it was
+                    if (ok && tid < n) sSol[perm[tid]] = W.colbuf[128 + tid];  // x = P^T x'; a failed solve leaves x what it was
                 } else if (wave == 0 && n > 0) {
                     int ok;
                     if (NR == 32) {
                         ok = solve_wave_32(sl_off, cb_off, n, lane);
-                        if (ok && lane < n) sSol[sPerm[lane]] = W.colbuf[128 + lane];  // x = P^T x'; a failed solve leaves x what it was
+                        if (ok && lane < n) sSol[perm[lane]] = W.colbuf[128 + lane];  // x = P^T x'; a failed solve leaves x what it was
                     } else {
                         ok = solve_lds(sl_off, cb_off, n, lane);
-                        for (int j = lane; ok && j < n; j += 64) sSol[sPerm[j]] = W.colbuf[j];
+                        for (int j = lane; ok && j < n; j += 64) sSol[perm[j]] = W.colbuf[j];
                     }
                     if (lane == 0) sFlag[0] = ok;
                 } else if (n == 0 && tid == 0) {
@@ -1675,8 +1686,9 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 }
             }
             __syncthreads();
+#undef perm
             const int ok2 = sFlag[0];
-            if (tid == 0) sFlag[1] = sFlag[3] = 0;  // (re-armed for the next trial's pivot order: read before the solve, written again many barriers later)
+            if (tid == 0) sFlag[1] = sFlag[3] = sFlag[4] = 0;  // (re-armed for the next trial's pivot order: read before the solve, written again many barriers later)
             if (ok2 && tid < 6 * B.F) {
                 const int sl = sSlot[tid / 6];
                 sDx[tid] = sl >= 0 ? sSol[6 * sl + tid % 6] : 0.0;
