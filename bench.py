@@ -155,7 +155,13 @@ def render_sequences(args, sids):
     import subprocess
     import tempfile
     synth_path = os.path.join(graft.PKG_DIR, "synth.py")
-    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    need = len(sids) * args.frames * args.width * args.height * 3
+    base = tempfile.gettempdir()
+    try:   # (memory-backed when it has the room -- a container's /dev/shm may be a few MB --, else the temp directory)
+        if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > 1.25 * need + (64 << 20):
+            base = "/dev/shm"
+    except OSError:
+        pass
     tmp = tempfile.mkdtemp(prefix="mvo_bench_frames_", dir=base)
     try:
         ncpu = len(os.sched_getaffinity(0))
