@@ -168,7 +168,10 @@ typedef struct {
 } mvo_ba_stats;
 
 /* optimization::bundleAdjustment (g2o_ba.cpp:172-317; caller VisualOdometry::callBundleAdjustment_,
- * src/vo/vo.cpp:458-462). */
+ * src/vo/vo.cpp:458-462).  The solver stack g2o_ba.cpp:193-200 builds is followed to the letter: Levenberg-Marquardt with
+ * g2o's lambda / nu rules, Schur complement on the points, the reduced system through Eigen::LDLT's pivot order and sign rule
+ * (LinearSolverDense), and -- as OptimizationAlgorithmLevenberg::solve does -- a FAILED linear solve still applies the solver's
+ * previous x and scores it with chi2 = DBL_MAX (stats->failed_solves / ->stale_steps). */
 int mvo_bundle_adjustment(mvo_ctx* ctx, mvo_ba_problem* problem, mvo_ba_stats* stats);
 /* How this ctx shares the GPU (no reference counterpart: g2o and cv::ORB are single-threaded).
  * LATENCY (default): one sequence wants its frame back as fast as possible -- a window is cut into ~300 observations per

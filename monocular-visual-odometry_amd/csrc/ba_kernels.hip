@@ -12,8 +12,9 @@
 // Cross-workgroup traffic per LM trial: the packed partial Schur system (lower triangle + rhs) is published as
 // data-tagged 8-byte granules, every workgroup sums ONE slice of it over the G partials in workgroup order and
 // republishes the slice, every workgroup reads the summed entries, solves the reduced 6F x 6F system itself (no
-// broadcast hop) and, after the update, exchanges its robust chi2 / predicted-decrease partial all-to-all (this is
-// also the barrier of the trial).  Tags carry the launch sequence number: nothing is ever zeroed between launches.
+// broadcast hop) -- rows in Eigen::LDLT's pivot order, as g2o's LinearSolverDense takes them -- and, after the update,
+// exchanges its robust chi2 / predicted-decrease partial all-to-all (this is also the barrier of the trial).  A solve
+// that fails leaves the solver's x what it was; g2o applies and scores that stale step (ba_window, "T3" onwards).  Tags carry the launch sequence number: nothing is ever zeroed between launches.
 //
 // Arithmetic: f64 like g2o; the Gram-type sums run on the f64 matrix cores (v_mfma_f64_16x16x4_f64) as ONE chain of
 // instructions per 16x16 tile, which is bit for bit a chain of IEEE fused multiply-adds over the rows in storage order

@@ -62,15 +62,18 @@ extern __shared__ __attribute__((aligned(16))) double ba_dyn_lds[];
 
 // ------------------------------------------------------------------------------------------------ reduced solve
 // Solves the reduced (n x n) system with ONE wave.  SL (LDS, row pitch NR + 1) holds row i = S[i][0..i] for i < n and
-// row n = the rhs g^T: the lower triangle of the symmetric matrix [[S, g], [g^T, .]].  Right-looking LDL^T without
-// pivoting, canonical arithmetic per step j: r = 1 / d_j, l_i = c_i r, a_ik = fma(-l_i, c_k, a_ik) (c = column j).
+// row n = the rhs g^T: the lower triangle of the symmetric matrix [[S, g], [g^T, .]].  The caller has ASSEMBLED S in the order in which
+// Eigen::LDLT takes its rows (round 6: ba_window forms that pivot order from |diag S| before the assembly; the solution is scattered
+// back through it), so the elimination itself takes the rows as they come.  Right-looking LDL^T,
+// canonical arithmetic per step j: r = 1 / d_j, l_i = c_i r, a_ik = fma(-l_i, c_k, a_ik) (c = column j).
 // Lane i keeps row i in registers; the system is embedded into NR - 1 rows (identity rows behind n: exact no-ops) with
 // the rhs as row NR - 1, so that the whole elimination is straight-line code: at step j every lane first finishes
 // its entry of column j + 1, parks it in LDS and fetches the pivot with v_readlane -- the division of step j + 1 and
 // the LDS round trip of its column overlap with the remaining updates of step j.  The rhs row comes out as
 // z = D^-1 L^-1 g.  L is written transposed (row j = column j of L) over SL; x = L^-T z by a column sweep with
-// v_readlane broadcasts: x_j = fma(-l_ij, x_i, x_j) for i = n-1 .. j+1.  Returns 0 when a pivot is not positive
-// (g2o: LDLT "not positive" -> the step is rejected).
+// v_readlane broadcasts: x_j = fma(-l_ij, x_i, x_j) for i = n-1 .. j+1.  Returns 0 when a pivot is not usable -- negative
+// (Eigen: "not positive" -> LinearSolverDense::solve returns false, the LM loop then applies and scores the solver's stale x) or outside
+// BA_PIVOT_MIN .. BA_PIVOT_MAX (never met; Eigen would carry on with such a pivot).
 // A step is bound by the ~45 instructions ONE wave has to issue for it (8999 cycles per solve = 290 per pivot,
 // tools/probes/solve_probe.hip).  Round 4 tried to take the LDS hand-off of the finished column off the path from one pivot to
 // the next -- pivot and next-column entry forwarded as scalars (three v_readlane pairs per step), the other half's c_i through

@@ -10,7 +10,11 @@
 //     consecutive column ranges whose chain results are added in range order;
 //   * range results are added in range order g = 0 .. G-1;
 //   * scalar sums (chi2, predicted decrease) are per-thread partials (thread = edge / landmark index mod 512),
-//     a 64-lane xor butterfly (32, 16, .. 1), the 8 waves in order, the ranges in order.
+//     a 64-lane xor butterfly (32, 16, .. 1), the 8 waves in order, the ranges in order;
+//   * the reduced system is eliminated in the order Eigen::LDLT takes its rows (largest |diagonal entry| of the input first,
+//     first maximum on ties: g2o's LinearSolverDense), right-looking, r = 1 / d, l = c r, fma updates;
+//   * the predicted decrease of the solver's STALE step (scored when a solve fails): landmark part per range with lane =
+//     landmark mod 64 and one butterfly, added over the ranges like a Schur entry; pose part as one butterfly; then + 1e-3.
 #ifndef MVO_BA_TYPES_H
 #define MVO_BA_TYPES_H
 #include <stddef.h>

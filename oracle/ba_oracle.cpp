@@ -3,9 +3,11 @@
 // machinery it drives (not vendored): SparseOptimizer::optimize(50) with
 // OptimizationAlgorithmLevenberg over BlockSolver<6,3> + LinearSolverDense, VertexSE3Expmap,
 // VertexSBAPointXYZ, EdgeProjectXYZ2UV with RobustKernelHuber -- semantics per SURVEY.md Appendix A.3.
-// PARITY UNPINNED (see oracle.h).  Deliberate, documented simplifications: the dense reduced system is
-// factorised by an unpivoted LDL^T (g2o: Eigen's pivoted LDLT; same solution up to rounding, same
-// "not positive -> step rejected" rule); a failed factorisation yields a zero step.
+// PARITY UNPINNED (see oracle.h).  Since round 6 the dense reduced system is solved as g2o's LinearSolverDense solves it
+// (Eigen::LDLT: its pivot order, its sign rule, its pseudo-inverse of D -- ldltEigen below) and a failed solve leaves the
+// solver's x what it was, as BlockSolver / OptimizationAlgorithmLevenberg do (the LM loop applies and scores that stale
+// step).  The simplification of rounds 1-5 -- unpivoted LDL^T, zero step after a failed solve -- is kept as rule 0
+// (orc_ba_set_solver_rule) to quantify the difference.
 #include "oracle.h"
 
 #include <algorithm>
