@@ -87,3 +87,22 @@ def test_ba_flop_count_credits_each_stage_where_it_runs():
     assert 780e6 < w < 850e6 and w < 0.9 * 85.1 * full
     # pose-only: no landmark terms
     assert bench.ba_solve_flops(E, L, F, True, 1, 1, 1) == 330 * E + (6 * F) ** 3 / 3 + 60 * E
+
+
+def test_sequences_are_rendered_by_worker_processes_like_the_generator_itself():
+    """bench.render_sequences (every shard its own sequence, seed 1234 + shard): worker processes `python synth.py render`
+    write .npy blocks; what comes back is the generator's output, frame for frame."""
+    import bench
+    import __graft_entry__ as graft
+    args = bench.parse(["--frames", "3", "--width", "160", "--height", "120", "--tex-size", "256"])
+    blocks = bench.render_sequences(args, [0, 5])
+    synth = graft.load_package().synth
+    for sid, block in blocks.items():
+        assert block.shape == (3, 120, 160, 3) and block.dtype == np.uint8
+        seq = synth.Sequence(160, 120, 3, seed=1234 + sid, tex_size=256)
+        for i in range(3):
+            assert np.array_equal(block[i], seq.frame(i))
+    assert not np.array_equal(blocks[0][0], blocks[5][0])          # different shards, different scenes
+    # the defaults are the contract's: 150 frames from a 2048 x 2048 texture
+    d = bench.parse([])
+    assert d.frames == 150 and d.tex_size == 2048 and d.width == 640 and d.height == 480
