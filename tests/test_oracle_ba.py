@@ -349,3 +349,24 @@ def test_failed_solve_keeps_and_scores_the_stale_step(O, S):
     finally:
         lib.orc_ba_set_solver_rule(1)
     assert st0["trials"] == st1["trials"] and np.abs(P0 - P1).max() < 1e-8 and np.abs(X0 - X1).max() < 1e-6
+
+
+@pytest.mark.parametrize("seed,min_failed", [(8, 2), (30, 1), (34, 1)])
+def test_lm_loop_against_an_independent_numpy_transcription(O, S, seed, min_failed):
+    """A second, independent transcription of g2o's LM (tests/g2o_lm_numpy.py: dense numpy, its own Eigen-LDLT, its own Schur complement, its
+    own SE3 exponential) next to the C++ oracle on small gauge-free windows: the same dampings to 1e-9, the same failed solves (Eigen's sign
+    rule on the pivoted reduced system) and the same accept / reject decisions for at least the first ten trials -- failed solves among
+    them -- until rounding separates the two runs (such windows are chaotic: a 5th-digit difference in chi2 a few trials earlier is enough)."""
+    import g2o_lm_numpy
+    pb = S.ba_problem(3, 30, seed=seed, f32_storage=False)
+    tr = g2o_lm_numpy.lm(pb, max_it=30)
+    plan = dict(wgs=1, nsplit=1, wg_pt_start=np.array([0, len(pb["points0"])], np.int32))
+    _, _, _, tro = O.bundle_adjustment_blocked(*_args(pb), plan=plan, fix_points=False, max_iterations=30)
+    n = min(len(tr), len(tro))
+    same = (tr[:n, 2] == tro[:n, 3]) & ((tr[:n, 1] > 1e300) == (tro[:n, 1] > 1e300))
+    agree = int(np.argmin(same)) if not same.all() else n
+    assert agree >= 10, agree
+    assert np.abs(tr[:agree, 0] - tro[:agree, 0]).max() <= 1e-9 * tro[:agree, 0].max()
+    ok = tro[:agree, 1] < 1e300
+    assert np.abs(tr[:agree, 1][ok] - tro[:agree, 1][ok]).max() <= 1e-3 * tro[:agree, 1][ok].max()      # chi2 of the trials both solved
+    assert int((~ok).sum()) >= min_failed                                                                # failed solves inside the common prefix
