@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
     // pivot order of every trial (T3): the H_pp diagonal entries this thread compares -- row i = tid >> lsh against j = jj, jj + LPR --
     // as offsets into sHpp, three times 10 bits (constant for the whole solve)
     int piv_hoff = 0;
-    if (n > 0) {
+    if (NR == 32 && n > 0) {  // (the larger classes form their entries once per trial into LDS instead)
         const int lsh = NR == 32 ? 4 : (n <= 32 ? 4 : (n <= 64 ? 3 : 2)), LPR = 1 << lsh, jj = tid & (LPR - 1);
         const int qi = min(tid >> lsh, n - 1), q0 = min(jj, n - 1), q1 = min(jj + LPR, n - 1);
         piv_hoff = (36 * sSlotPose[qi / 6] + 7 * (qi % 6)) | (36 * sSlotPose[q0 / 6] + 7 * (q0 % 6)) << 10 | (36 * sSlotPose[q1 / 6] + 7 * (q1 % 6)) << 20;
@@ -1562,20 +1562,31 @@ __device__ __forceinline__ void ba_window(const BaDev* desc, const BaRun batch, 
                 const int i = tid >> lsh, jj = tid & (LPR - 1);  // (shifts: a division by a run-time value costs ~40 instructions)
 // (a macro, not a lambda: behind a by-reference capture the compiler parks the register-resident edge rows in scratch memory)
 #define BA_ADIAG(q, hoff) fabs((sHpp[hoff] + lambda) - (do_schur ? W.Rl[(q) * ((q) + 1) / 2 + (q)] : 0.0))
-                // (two entries per round, formed before they are compared: their LDS reads are in flight together)
-                const int j0 = jj, j1 = jj + LPR;
-                // (clamped indices, values selected afterwards: no branch between the three chains of LDS reads)
-                const int qi = min(i, n - 1), q0 = min(j0, n - 1), q1 = min(j1, n - 1);
-                const double vi = BA_ADIAG(qi, piv_hoff & 1023), v0 = BA_ADIAG(q0, (piv_hoff >> 10) & 1023), v1 = BA_ADIAG(q1, piv_hoff >> 20);
-                const double ai = i < n ? vi : -1.0, b0 = j0 < n ? v0 : -2.0, b1 = j1 < n ? v1 : -2.0;
-                int v = ai != ai ? 1 << 24 : 0;
-                v += (b0 > ai ? 1 : 0) + ((b0 == ai && j0 != i) ? 1 << 12 : 0);
-                v += (b1 > ai ? 1 : 0) + ((b1 == ai && j1 != i) ? 1 << 12 : 0);
-                for (int j = jj + 2 * LPR; NR != 32 && j < n; j += 2 * LPR) {
-                    const double c0 = BA_ADIAG(j, 36 * sSlotPose[j / 6] + 7 * (j % 6));
-                    const double c1 = j + LPR < n ? BA_ADIAG(j + LPR, 36 * sSlotPose[(j + LPR) / 6] + 7 * ((j + LPR) % 6)) : -2.0;
-                    v += (c0 > ai ? 1 : 0) + ((c0 == ai && j != i) ? 1 << 12 : 0);
-                    v += (c1 > ai ? 1 : 0) + ((c1 == ai && j + LPR != i) ? 1 << 12 : 0);
+                int v;
+                if (NR == 32) {
+                    // (two entries per thread, formed before they are compared: their LDS reads are in flight together)
+                    const int j0 = jj, j1 = jj + LPR;
+                    // (clamped indices, values selected afterwards: no branch between the three chains of LDS reads)
+                    const int qi = min(i, n - 1), q0 = min(j0, n - 1), q1 = min(j1, n - 1);
+                    const double vi = BA_ADIAG(qi, piv_hoff & 1023), v0 = BA_ADIAG(q0, (piv_hoff >> 10) & 1023), v1 = BA_ADIAG(q1, piv_hoff >> 20);
+                    const double ai = i < n ? vi : -1.0, b0 = j0 < n ? v0 : -2.0, b1 = j1 < n ? v1 : -2.0;
+                    v = ai != ai ? 1 << 24 : 0;
+                    v += (b0 > ai ? 1 : 0) + ((b0 == ai && j0 != i) ? 1 << 12 : 0);
+                    v += (b1 > ai ? 1 : 0) + ((b1 == ai && j1 != i) ? 1 << 12 : 0);
+                } else {
+                    // larger systems (8 or 30 entries per thread): the n entries are formed ONCE, by the first n threads, into the column
+                    // buffer (free until the solve), and compared from there -- one barrier more, but the counting loop reads one
+                    // double per entry at a trivial address instead of re-deriving it through the slot table
+                    double* ab = W.colbuf;
+                    if (tid < n) ab[tid] = BA_ADIAG(tid, 36 * sSlotPose[tid / 6] + 7 * (tid % 6));
+                    __syncthreads();
+                    const double ai = i < n ? ab[i] : -1.0;
+                    v = ai != ai ? 1 << 24 : 0;
+#pragma unroll 8
+                    for (int j = jj; j < n; j += LPR) {
+                        const double b = ab[j];
+                        v += (b > ai ? 1 : 0) + ((b == ai && j != i) ? 1 << 12 : 0);
+                    }
                 }
                 STAMP(24);
                 v = group_sum_i(v, LPR);  // bits 0..11: entries larger than mine, 12..23: entries equal to mine, 24..: NaN

@@ -23,5 +23,8 @@ for wgs in [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["
             print("BA10 wgs", ph["wgs"], "ms/solve %.3f trials %d same_l2 %d" % (dt * 1e3, st["trials"], ph["x15"]))
         else:
             print("   instrumented ms/solve %.3f" % (dt * 1e3), {k: round(v / max(st["trials"], 1)) for k, v in ph.items() if k not in ("wgs", "x15")})
+            raw = ctx.ba_trace(h, raw_rows=412)[400:408].ravel()
+            print("   trial 6, cycles from the end of the Schur exchange (stamp 11): ranks formed %d, group sum + stores %d, barrier %d, replay %d, S assembled %d, solved %d"
+                  % tuple(int(raw[i] - raw[11]) for i in (24, 25, 26, 27, 12, 13)))
     mvo.debug_set("ba_profile", 0)
     ctx.ba_release(h)
