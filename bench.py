@@ -682,7 +682,7 @@ def spawn_ranks(args, argv):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "1")
     limit = float(os.environ.get("MVO_BENCH_SPAWN_TIMEOUT", "3600"))
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)  # (a process group of its own)
     found = []
 
     def relay():
@@ -704,7 +704,11 @@ def spawn_ranks(args, argv):
     try:
         rc = proc.wait(timeout=limit)
     except subprocess.TimeoutExpired:
-        proc.kill()          # (the launcher's own process: its ranks go with it)
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)   # (the launcher AND the ranks it started: the group this call created, nothing else)
+        except (ProcessLookupError, PermissionError):
+            proc.kill()
         proc.wait()
         raise SystemExit("bench.py: the %d-rank run did not finish within %.0f s" % (args.gpus, limit))
     th.join(timeout=10)
