@@ -172,7 +172,8 @@ struct BaService {
     // resident solver service (k_ba_service): BA_SERVICE_SLOTS slots of `wgs_per_slot` workgroups stay on the device and
     // pull windows from their mailboxes; the launch thread only assigns slots
     bool resident = false;               // the grid is on the device
-    bool wedged = false;                 // a grid of this service never left the device (stop_resident): do not start another one
+    std::atomic<bool> wedged{false};     // a grid of this service never left the device (stop_resident): no further grid is started, and
+                                         // wanted() says no from then on -- windows take the launch path instead of failing at start_resident()
     BaMail* mail = nullptr;              // pinned host memory
     ba_u64* d_cmd = nullptr;             // device memory: 8 words per slot + one arrival counter per slot
     hipStream_t resident_stream = nullptr;
@@ -460,6 +461,7 @@ bool BaDemand::submit(double now) {
 }
 namespace {
 bool BaService::wanted() {
+    if (wedged.load(std::memory_order_relaxed)) return false;
     if (g_ba_service != 1) return g_ba_service == 2;
     std::lock_guard<std::mutex> lk(m_demand);
     return demand.submit(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
