@@ -996,6 +996,9 @@ def main(argv=None, env=None):
                                % (max(1, args.frames_per_step), args.streams * world, args.streams * world * R["nframes"]),
                        "frame_loop": "native (host/driver/frame_loop.cpp)" + (", extraction of frame i+1 overlapped with BA of frame i (a ctx + its sibling per sequence, THROUGHPUT mode when > 8 sequences)" if pipeline else ""),
                        "keypoints": st.n_kp, "matches": st.n_match,
+                       # (`value` = frames resident in HBM when the timed region starts, as the measurement contract defines it; the same
+                       # loop with every frame handed over as a pinned HOST image like run_vo.cpp:114 -- H2D inside the loop:)
+                       "pcie_inclusive_frames_per_s": secondary.get("h2d_inclusive_fps"),
                        # (copy of the top-level `parity` object's verdicts: what the timed loop produced, held to the oracle)
                        "parity": parity and {k: parity.get(k) for k in ("ba", "ba_windows_checked", "ba_workgroups_per_window", "orb", "match", "error")
                                              if k in parity},
